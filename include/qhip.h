@@ -1,0 +1,294 @@
+/*
+ * qhip.h — C ABI of libqhip.so, the MI355X (gfx950) execution backend for the
+ * filter / hash-aggregate / hash-join path of holicc/qurious.
+ *
+ * This header is the drop-in boundary. Every entry point replaces one reference
+ * operator (cited as file:line under /root/reference/qurious/src) and is what a
+ * Rust `extern "C"` block would bind. Only plain pointers,
+ * sizes and PODs cross the boundary; column data crosses as Arrow C Data
+ * Interface structs (arrow-rs side: arrow::ffi::{to_ffi, from_ffi}).
+ *
+ * Conventions
+ *  - every function returns a qhip_status (0 = ok); qhip_last_error(ctx) gives the
+ *    message. The reference's Result<T, Error> (error.rs:20-31) maps as
+ *    non-zero -> Error::InternalError(msg); QHIP_UNSUPPORTED lets a caller fall
+ *    back to the CPU node. The library never aborts the process.
+ *  - a context is used by one thread at a time (the reference executor is
+ *    single-threaded, physical/plan/mod.rs:25-29); all calls are synchronous.
+ *  - a qhip_table is the device-resident equivalent of the Vec<RecordBatch> that
+ *    PhysicalPlan::execute returns (physical/plan/mod.rs:27): columns live
+ *    concatenated in HBM, the batch boundaries are remembered so that per-batch
+ *    semantics (Filter: one output batch per input batch; HashJoinExec: one
+ *    output batch per non-empty probe batch) are reproduced on download.
+ */
+#ifndef QHIP_H
+#define QHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- Arrow C Data Interface */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+/* ---------------------------------------------------------------- status */
+typedef enum qhip_status {
+  QHIP_OK = 0,
+  QHIP_INVALID_ARGUMENT = 1, /* malformed descriptor / type mismatch (reference: arrow_err!/internal_err!) */
+  QHIP_UNSUPPORTED = 2,      /* valid plan the backend does not accelerate: fall back to the CPU node */
+  QHIP_HIP_ERROR = 3,        /* HIP runtime / hiprtc failure, or no usable gfx950 device */
+  QHIP_OUT_OF_MEMORY = 4,
+  QHIP_EXEC_ERROR = 5,       /* data-dependent failure the reference also reports (divide by zero, cast overflow, AVG overflow) */
+  QHIP_RCCL_ERROR = 6
+} qhip_status;
+
+typedef struct qhip_ctx qhip_ctx;
+typedef struct qhip_table qhip_table;
+typedef struct qhip_join qhip_join;
+
+/* ---------------------------------------------------------------- types */
+/* arrow DataType subset reachable on the path (utils/array.rs:190-210, aggregate/mod.rs:87-116) */
+typedef enum qhip_type_id {
+  QHIP_NULL = 0,
+  QHIP_BOOL = 1,
+  QHIP_INT8 = 2, QHIP_INT16 = 3, QHIP_INT32 = 4, QHIP_INT64 = 5,
+  QHIP_UINT8 = 6, QHIP_UINT16 = 7, QHIP_UINT32 = 8, QHIP_UINT64 = 9,
+  QHIP_FLOAT32 = 10, QHIP_FLOAT64 = 11,
+  QHIP_DATE32 = 12, QHIP_DATE64 = 13,
+  QHIP_DECIMAL128 = 14,
+  QHIP_UTF8 = 15
+} qhip_type_id;
+
+typedef struct qhip_dtype {
+  int32_t id;        /* qhip_type_id */
+  int32_t precision; /* Decimal128 only */
+  int32_t scale;     /* Decimal128 only */
+} qhip_dtype;
+
+/* datatypes/operator.rs:4-20 — same order */
+typedef enum qhip_operator {
+  QHIP_OP_EQ = 0, QHIP_OP_NOTEQ, QHIP_OP_GT, QHIP_OP_GTEQ, QHIP_OP_LT, QHIP_OP_LTEQ,
+  QHIP_OP_AND, QHIP_OP_OR,
+  QHIP_OP_ADD, QHIP_OP_SUB, QHIP_OP_MUL, QHIP_OP_DIV, QHIP_OP_MOD
+} qhip_operator;
+
+/* physical/expr/{column,literal,binary,cast,is_null,is_not_null,negative}.rs */
+typedef enum qhip_expr_kind {
+  QHIP_EXPR_COLUMN = 0,   /* column.rs:24-34   : `column` = index into the input schema */
+  QHIP_EXPR_LITERAL = 1,  /* literal.rs:20-22  : ScalarValue broadcast; value in lit_* by dtype */
+  QHIP_EXPR_BINARY = 2,   /* binary.rs:31-70   : `op`, children `left`,`right` */
+  QHIP_EXPR_CAST = 3,     /* cast.rs:33-37     : child `left`, target `dtype`, safe=false */
+  QHIP_EXPR_IS_NULL = 4,  /* is_null.rs        : child `left` */
+  QHIP_EXPR_IS_NOT_NULL = 5,
+  QHIP_EXPR_NEGATIVE = 6  /* negative.rs       : child `left` */
+} qhip_expr_kind;
+
+/* One node of an expression tree stored as a flat array; children are indices
+ * into the same array (-1 = none). Literals: integers/dates/bools in lit_lo
+ * (sign-extended), Decimal128 in (lit_hi:lit_lo), floats in lit_f64, Utf8 in
+ * lit_str/lit_len; lit_is_null marks a typed NULL literal. */
+typedef struct qhip_expr {
+  int32_t kind;
+  int32_t op;
+  int32_t column;
+  int32_t left;
+  int32_t right;
+  qhip_dtype dtype;
+  int32_t lit_is_null;
+  uint64_t lit_lo;
+  int64_t lit_hi;
+  double lit_f64;
+  const char* lit_str;
+  int64_t lit_len;
+} qhip_expr;
+
+/* physical/expr/aggregate/{sum,avg,count,min,max}.rs */
+typedef enum qhip_agg_kind {
+  QHIP_AGG_SUM = 0, QHIP_AGG_AVG = 1, QHIP_AGG_COUNT = 2, QHIP_AGG_MIN = 3, QHIP_AGG_MAX = 4
+} qhip_agg_kind;
+
+typedef struct qhip_agg {
+  int32_t kind;           /* qhip_agg_kind */
+  int32_t expr;           /* root index of the argument expression in the expr array */
+  qhip_dtype return_type; /* SumAggregateExpr::return_type (sum.rs:15), AvgAggregateExpr::return_type (avg.rs:19), Min/Max return_type */
+} qhip_agg;
+
+/* common/join_type.rs:4-11 — same order */
+typedef enum qhip_join_type {
+  QHIP_JOIN_LEFT = 0, QHIP_JOIN_RIGHT, QHIP_JOIN_INNER, QHIP_JOIN_FULL, QHIP_JOIN_LEFT_SEMI, QHIP_JOIN_LEFT_ANTI
+} qhip_join_type;
+
+/* per-call execution statistics: device time of the dominant kernel, measured with
+ * HIP events on the stream it was launched on (bench.py roofline.achieved) */
+typedef struct qhip_exec_stats {
+  double main_kernel_ms;     /* dominant kernel of the last call (fused filter+aggregate, or join probe) */
+  double total_device_ms;    /* first launch .. last launch of the call */
+  double jit_ms;             /* hiprtc time spent by this call (0 when the kernel cache hit) */
+  int64_t rows_in;           /* rows scanned by the dominant kernel */
+  int64_t rows_out;
+  int64_t groups;            /* groups / matched pairs */
+  int64_t table_capacity;    /* hash-table slots used by the call */
+  int32_t retries;           /* hash-table growth retries */
+  int32_t lds_table_slots;   /* LDS-staged table slots per workgroup */
+  char main_kernel_name[64];
+} qhip_exec_stats;
+
+/* ---------------------------------------------------------------- context */
+/* device_index < 0: current HIP device. Fails with QHIP_HIP_ERROR when no gfx950
+ * device is visible — there is no CPU fallback behind this library. */
+int qhip_ctx_create(int device_index, qhip_ctx** out);
+void qhip_ctx_destroy(qhip_ctx* ctx);
+const char* qhip_last_error(const qhip_ctx* ctx);  /* ctx may be NULL: last create error */
+const char* qhip_version(void);
+/* 1 if a HIP device is visible to this process (does not create a context) */
+int qhip_device_available(void);
+int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out);
+int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
+
+/* ---------------------------------------------------------------- tables (Vec<RecordBatch> in HBM) */
+/* Upload n_batches struct-typed ArrowArrays (one per RecordBatch, children = columns)
+ * sharing `schema` (a struct ArrowSchema). Host buffers are only read during the call
+ * and are not released by the library. Replaces MemoryTable::try_new + the batches a
+ * child node's execute() returned (datasource/memory.rs:29-35). */
+int qhip_table_from_arrow(qhip_ctx* ctx, const struct ArrowSchema* schema,
+                          const struct ArrowArray* const* batches, int64_t n_batches,
+                          qhip_table** out);
+/* Download batch `batch_index` as a struct ArrowArray (+ schema if out_schema != NULL).
+ * Buffers are library-owned host memory freed by the release callbacks. */
+int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
+                        struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+int64_t qhip_table_num_batches(const qhip_table* t);
+int64_t qhip_table_num_rows(const qhip_table* t);
+int64_t qhip_table_num_columns(const qhip_table* t);
+/* bytes resident in HBM for column `col` (all buffers) — used for the roofline's algorithmic bytes */
+int64_t qhip_table_column_bytes(const qhip_table* t, int64_t col);
+void qhip_table_destroy(qhip_table* t);
+
+/* ---------------------------------------------------------------- operators */
+/* Filter::execute (physical/plan/filter.rs:28-44) and MemoryTable::scan with a pushed-down
+ * filter (datasource/memory.rs:69-98): keep rows whose predicate is valid AND true, all
+ * columns compacted, one output batch per input batch (possibly empty), row order kept.
+ * `projection` (n_projection >= 0 column indices, or NULL) is memory.rs:79-88. */
+int qhip_filter_execute(qhip_ctx* ctx, const qhip_table* input,
+                        const qhip_expr* exprs, int32_t n_exprs, int32_t predicate_root,
+                        const int32_t* projection, int32_t n_projection,
+                        qhip_table** out);
+
+/* HashAggregate::execute (physical/plan/aggregate/hash.rs:138-170) with the scan filter of
+ * its input fused in (predicate_root < 0: none). Output: one batch of G rows, columns =
+ * group keys then aggregates in declaration order; zero input batches -> zero output
+ * batches (hash.rs:146-148). n_groups == 0 runs NoGroupingAggregate::execute
+ * (aggregate/no_grouping.rs:30-62): always exactly one row. */
+int qhip_hash_aggregate_execute(qhip_ctx* ctx, const qhip_table* input,
+                                const qhip_expr* exprs, int32_t n_exprs, int32_t predicate_root,
+                                const int32_t* group_roots, int32_t n_groups,
+                                const qhip_agg* aggs, int32_t n_aggs,
+                                const char* const* out_names, /* n_groups + n_aggs names, or NULL */
+                                qhip_table** out);
+
+/* HashJoinExec::execute (physical/plan/join/hash_join.rs:354-384): build = left, probe =
+ * right per batch. on_left[i]/on_right[i] are expression roots over the left/right schema
+ * (JoinOn, join/mod.rs:20). filter_root >= 0: residual JoinFilter (join/mod.rs:125-154)
+ * evaluated over an intermediate schema whose column k is
+ * (filter_sides[k] == 0 ? left : right).column(filter_cols[k]). Output: left ++ right
+ * columns (left only for semi/anti), one batch per non-empty probe batch in probe order,
+ * matches of a probe row in ascending build-row order, then the unmatched-build tail
+ * (hash_join.rs:277-343). */
+int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right,
+                           int32_t join_type,
+                           const qhip_expr* left_exprs, int32_t n_left_exprs,
+                           const qhip_expr* right_exprs, int32_t n_right_exprs,
+                           const int32_t* on_left, const int32_t* on_right, int32_t n_on,
+                           const qhip_expr* filter_exprs, int32_t n_filter_exprs, int32_t filter_root,
+                           const int32_t* filter_sides, const int32_t* filter_cols, int32_t n_filter_cols,
+                           qhip_table** out);
+
+/* ---------------------------------------------------------------- exchange (multi-GPU hash-join repartition) */
+/* Split `input` into n_parts tables by mix64(key) of the join-key expressions so that equal
+ * keys land in the same part on every rank; part p is sent to rank p by the caller's
+ * all-to-all (RCCL over xGMI). Rows keep their relative order inside a part. */
+int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input,
+                          const qhip_expr* exprs, int32_t n_exprs,
+                          const int32_t* key_roots, int32_t n_keys,
+                          int32_t n_parts, qhip_table** out_parts /* n_parts entries */);
+/* Concatenate tables with identical schemas (batches appended in order). */
+int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n, qhip_table** out);
+
+/* Raw device access for the exchange plumbing (torch.distributed moves the bytes):
+ * buffer k of column c: 0 = values (or utf8 offsets), 1 = validity bitmap, 2 = utf8 data. */
+int qhip_table_column_buffer(const qhip_table* t, int64_t col, int32_t which,
+                             void** device_ptr, int64_t* n_bytes);
+/* Build a table from device buffers received from peers; the library copies them. */
+typedef struct qhip_device_column {
+  qhip_dtype dtype;
+  int64_t length;
+  int64_t null_count;
+  const void* values;        /* device: fixed-width values, or int32 offsets (length+1) for utf8 */
+  const void* validity;      /* device bitmap or NULL */
+  const void* data;          /* device utf8 bytes or NULL */
+  int64_t data_bytes;
+} qhip_device_column;
+int qhip_table_from_device(qhip_ctx* ctx, const char* const* names, const qhip_device_column* cols,
+                           int32_t n_cols, int64_t n_rows, qhip_table** out);
+
+/* ---------------------------------------------------------------- plan-only entry points (no GPU needed) */
+/* Return (snprintf-style; *needed = bytes incl. NUL) the policy source libqhip instantiates the kernel
+ * templates of csrc/device/qhip_device.hpp with, for an input whose column c has type col_types[c] and
+ * (col_has_nulls[c] != 0) a validity bitmap. qhip_jit_compile_to_cache compiles such a source for gfx950
+ * with hiprtc and stores the code object in cache_dir, where contexts pick it up instead of compiling. */
+int qhip_plan_aggregate_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                               const qhip_expr* exprs, int32_t n_exprs, int32_t predicate_root,
+                               const int32_t* group_roots, int32_t n_groups, const qhip_agg* aggs, int32_t n_aggs,
+                               char* buf, size_t buflen, size_t* needed);
+int qhip_plan_filter_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                            const qhip_expr* exprs, int32_t n_exprs, int32_t predicate_root,
+                            char* buf, size_t buflen, size_t* needed);
+int qhip_plan_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                          const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
+                          char* buf, size_t buflen, size_t* needed);
+const char* qhip_plan_last_error(void);
+int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
+
+/* ---------------------------------------------------------------- synthetic TPC-H-shaped inputs */
+/* Counter-based generators (splitmix64, seed 0x515552494F555301) writing Arrow-layout host
+ * buffers the caller allocated. Row i of every column depends only on (seed, column, i). */
+int qhip_synth_lineitem(int64_t first_row, int64_t n_rows,
+                        int32_t* l_shipdate, int32_t* l_returnflag_offsets, uint8_t* l_returnflag_data,
+                        int32_t* l_linestatus_offsets, uint8_t* l_linestatus_data,
+                        void* l_quantity /* i128[] */, void* l_extendedprice, void* l_discount, void* l_tax);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QHIP_H */

@@ -1,0 +1,274 @@
+"""ctypes binding of libqhip.so (include/qhip.h) — the only way Python reaches the HIP backend.
+
+There is deliberately no fallback: if the shared library is missing this module raises at import
+of the symbol table, and if no gfx950 device is visible ``get_context()`` raises. Nothing under
+``oracle/`` is ever imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqhip.so")
+
+# status codes (include/qhip.h)
+QHIP_OK, QHIP_INVALID_ARGUMENT, QHIP_UNSUPPORTED, QHIP_HIP_ERROR, QHIP_OUT_OF_MEMORY, QHIP_EXEC_ERROR, QHIP_RCCL_ERROR = range(7)
+
+
+class QuriousError(Exception):
+    """Mirror of qurious::error::Error (error.rs:5-31); ``code`` is the qhip_status."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+class InternalError(QuriousError):
+    pass
+
+
+class ArrowError(QuriousError):
+    pass
+
+
+class UnsupportedError(QuriousError):
+    """QHIP_UNSUPPORTED: a valid plan the HIP backend does not accelerate (a Rust shim would fall back to the CPU node)."""
+
+
+class HipError(QuriousError):
+    pass
+
+
+def _raise(code: int, msg: str):
+    if code == QHIP_UNSUPPORTED:
+        raise UnsupportedError(code, msg)
+    if code in (QHIP_HIP_ERROR, QHIP_OUT_OF_MEMORY, QHIP_RCCL_ERROR):
+        raise HipError(code, msg)
+    if code == QHIP_EXEC_ERROR or msg.startswith("Arrow error") or msg.startswith("Invalid argument error"):
+        raise ArrowError(code, msg)
+    raise InternalError(code, msg)
+
+
+class qhip_dtype(C.Structure):
+    _fields_ = [("id", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32)]
+
+
+class qhip_expr(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("op", C.c_int32), ("column", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
+        ("dtype", qhip_dtype), ("lit_is_null", C.c_int32),
+        ("lit_lo", C.c_uint64), ("lit_hi", C.c_int64), ("lit_f64", C.c_double),
+        ("lit_str", C.c_char_p), ("lit_len", C.c_int64),
+    ]
+
+
+class qhip_agg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("expr", C.c_int32), ("return_type", qhip_dtype)]
+
+
+class qhip_exec_stats(C.Structure):
+    _fields_ = [
+        ("main_kernel_ms", C.c_double), ("total_device_ms", C.c_double), ("jit_ms", C.c_double),
+        ("rows_in", C.c_int64), ("rows_out", C.c_int64), ("groups", C.c_int64), ("table_capacity", C.c_int64),
+        ("retries", C.c_int32), ("lds_table_slots", C.c_int32), ("main_kernel_name", C.c_char * 64),
+    ]
+
+
+class ArrowSchemaStruct(C.Structure):
+    pass
+
+
+class ArrowArrayStruct(C.Structure):
+    pass
+
+
+ArrowSchemaStruct._fields_ = [
+    ("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+    ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(ArrowSchemaStruct))),
+    ("dictionary", C.POINTER(ArrowSchemaStruct)), ("release", C.c_void_p), ("private_data", C.c_void_p),
+]
+ArrowArrayStruct._fields_ = [
+    ("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+    ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)), ("children", C.POINTER(C.POINTER(ArrowArrayStruct))),
+    ("dictionary", C.POINTER(ArrowArrayStruct)), ("release", C.c_void_p), ("private_data", C.c_void_p),
+]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    """Load libqhip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C qurious_amd/csrc``)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP backend has no Python/CPU fallback)")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        P = C.POINTER
+        sigs = {
+            "qhip_ctx_create": (C.c_int, [C.c_int, P(vp)]),
+            "qhip_ctx_destroy": (None, [vp]),
+            "qhip_last_error": (C.c_char_p, [vp]),
+            "qhip_version": (C.c_char_p, []),
+            "qhip_device_available": (C.c_int, []),
+            "qhip_ctx_last_stats": (C.c_int, [vp, P(qhip_exec_stats)]),
+            "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+            "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
+            "qhip_table_to_arrow": (C.c_int, [vp, vp, i64, vp, vp]),
+            "qhip_table_num_batches": (i64, [vp]),
+            "qhip_table_num_rows": (i64, [vp]),
+            "qhip_table_num_columns": (i64, [vp]),
+            "qhip_table_column_bytes": (i64, [vp, i64]),
+            "qhip_table_destroy": (None, [vp]),
+            "qhip_filter_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, i32, P(i32), i32, P(vp)]),
+            "qhip_hash_aggregate_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, i32, P(i32), i32, P(qhip_agg), i32,
+                                                      P(C.c_char_p), P(vp)]),
+            "qhip_hash_join_execute": (C.c_int, [vp, vp, vp, i32, P(qhip_expr), i32, P(qhip_expr), i32, P(i32), P(i32), i32,
+                                                 P(qhip_expr), i32, i32, P(i32), P(i32), i32, P(vp)]),
+            "qhip_partition_by_key": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(vp)]),
+            "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
+            "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),
+            "qhip_synth_lineitem": (C.c_int, [i64, i64] + [vp] * 9),
+            "qhip_jit_compile_to_cache": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class Context:
+    """Owner of one qhip_ctx (one HIP device, one stream). One per process and device is enough."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.qhip_ctx_create(device, C.byref(h))
+        if rc != QHIP_OK:
+            _raise(rc, self.lib.qhip_last_error(None).decode())
+        self.handle = h
+
+    def check(self, rc: int):
+        if rc != QHIP_OK:
+            _raise(rc, self.lib.qhip_last_error(self.handle).decode())
+
+    def last_stats(self) -> dict:
+        st = qhip_exec_stats()
+        self.check(self.lib.qhip_ctx_last_stats(self.handle, C.byref(st)))
+        d = {f[0]: getattr(st, f[0]) for f in qhip_exec_stats._fields_}
+        d["main_kernel_name"] = st.main_kernel_name.decode()
+        return d
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.qhip_ctx_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.qhip_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_ctx = None
+
+
+def get_context() -> Context:
+    """Process-wide context on the current HIP device (LOCAL_RANK under torch.distributed launchers)."""
+    global _ctx
+    if _ctx is None:
+        dev = int(os.environ.get("QHIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _ctx = Context(dev)
+    return _ctx
+
+
+class DeviceTable:
+    """HBM-resident Vec<RecordBatch> (qhip_table)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    @staticmethod
+    def from_batches(ctx: Context, schema: pa.Schema, batches) -> "DeviceTable":
+        lib = ctx.lib
+        c_schema = ArrowSchemaStruct()
+        schema._export_to_c(C.addressof(c_schema))
+        arrays = [ArrowArrayStruct() for _ in batches]
+        try:
+            for b, a in zip(batches, arrays):
+                if b.schema != schema:
+                    b = pa.RecordBatch.from_arrays(b.columns, schema=schema)
+                b._export_to_c(C.addressof(a))
+            ptrs = (C.c_void_p * max(1, len(arrays)))(*[C.addressof(a) for a in arrays])
+            out = C.c_void_p()
+            ctx.check(lib.qhip_table_from_arrow(ctx.handle, C.addressof(c_schema), ptrs, len(arrays), C.byref(out)))
+            return DeviceTable(ctx, out)
+        finally:
+            _release_schema(c_schema)
+            for a in arrays:
+                _release_array(a)
+
+    @property
+    def num_rows(self) -> int:
+        return self.ctx.lib.qhip_table_num_rows(self.handle)
+
+    @property
+    def num_batches(self) -> int:
+        return self.ctx.lib.qhip_table_num_batches(self.handle)
+
+    @property
+    def num_columns(self) -> int:
+        return self.ctx.lib.qhip_table_num_columns(self.handle)
+
+    def column_bytes(self, col: int) -> int:
+        return self.ctx.lib.qhip_table_column_bytes(self.handle, col)
+
+    def to_batches(self):
+        out = []
+        for b in range(self.num_batches):
+            a = ArrowArrayStruct()
+            s = ArrowSchemaStruct()
+            self.ctx.check(self.ctx.lib.qhip_table_to_arrow(self.ctx.handle, self.handle, b, C.addressof(a), C.addressof(s)))
+            out.append(pa.RecordBatch._import_from_c(C.addressof(a), C.addressof(s)))
+        return out
+
+    def schema(self) -> pa.Schema:
+        s = ArrowSchemaStruct()
+        self.ctx.check(self.ctx.lib.qhip_table_to_arrow(self.ctx.handle, self.handle, 0, None, C.addressof(s)))
+        return pa.Schema._import_from_c(C.addressof(s))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.qhip_table_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def _release_schema(s: ArrowSchemaStruct):
+    if s.release:
+        _RELEASE_FN(s.release)(C.addressof(s))
+
+
+def _release_array(a: ArrowArrayStruct):
+    if a.release:
+        _RELEASE_FN(a.release)(C.addressof(a))

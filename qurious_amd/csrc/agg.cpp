@@ -1,0 +1,353 @@
+// agg.cpp — qhip_hash_aggregate_execute: HashAggregate / NoGroupingAggregate with the scan filter fused in.
+//
+// Reference: physical/plan/aggregate/hash.rs:138-170 (execute), :45-87 (GroupAccumulator::update),
+// :89-107 (output); aggregate/no_grouping.rs:30-62; accumulators physical/expr/aggregate/*.rs;
+// fused predicate = MemoryTable::scan (datasource/memory.rs:90-93) / Filter (physical/plan/filter.rs:28-44).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+
+#include "codegen.hpp"
+#include "common.hpp"
+#include "device/qhip_status.h"
+#include "hostcol.hpp"
+#include "jit.hpp"
+#include "kargs_host.hpp"
+#include "kernels.hpp"
+
+namespace qhip {
+
+// ---------------------------------------------------------------- HostColumn
+void HostColumn::init_fixed(const DType& t, int64_t n) {
+  type = t; length = n; null_count = 0;
+  const int w = dtype_width(t);
+  if (w) values.assign((size_t)n * w, 0);
+  else if (t.id == QHIP_BOOL) values.assign((size_t)((n + 7) / 8), 0);
+  else if (t.id == QHIP_UTF8) offsets.assign((size_t)n + 1, 0);
+}
+void HostColumn::set_null(int64_t i) {
+  if (validity.empty()) validity.assign((size_t)((length + 7) / 8), 0xff);
+  validity[(size_t)(i >> 3)] &= (uint8_t)~(1u << (i & 7));
+  ++null_count;
+}
+
+qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, const std::vector<bool>& nullable,
+                            std::vector<HostColumn>& cols, int64_t nrows, bool zero_batches) {
+  std::unique_ptr<qhip_table> t(new qhip_table());
+  t->ctx = ctx;
+  t->names = names;
+  t->nullable = nullable;
+  t->num_rows = nrows;
+  t->batch_offsets.push_back(0);
+  if (!zero_batches) t->batch_offsets.push_back(nrows);
+  for (auto& hc : cols) {
+    DevColumn dc;
+    dc.type = hc.type; dc.length = nrows; dc.null_count = hc.null_count;
+    auto up = [&](const void* src, size_t n) {
+      auto b = std::make_shared<DevBuf>(n);
+      if (n) QHIP_HIP_CHECK(hipMemcpyAsync(b->ptr, src, n, hipMemcpyHostToDevice, ctx->stream));
+      return b;
+    };
+    if (hc.null_count > 0 && hc.type.id != QHIP_NULL) {
+      hc.validity.resize((size_t)((nrows + 7) / 8 + 8), 0);
+      dc.validity = up(hc.validity.data(), hc.validity.size());
+    }
+    if (hc.type.id == QHIP_UTF8) {
+      dc.values = up(hc.offsets.data(), hc.offsets.size() * 4);
+      dc.data = up(hc.data.data(), hc.data.size());
+      dc.data_bytes = (int64_t)hc.data.size();
+    } else if (hc.type.id == QHIP_BOOL) {
+      hc.values.resize((size_t)((nrows + 7) / 8 + 8), 0);
+      dc.values = up(hc.values.data(), hc.values.size());
+    } else if (hc.type.id != QHIP_NULL) {
+      dc.values = up(hc.values.data(), hc.values.size());
+    }
+    t->cols.push_back(std::move(dc));
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return t.release();
+}
+
+// ---------------------------------------------------------------- helpers shared with other operators
+std::vector<InputCol> input_cols_of(const qhip_table* t) {
+  std::vector<InputCol> v;
+  for (auto& c : t->cols) { InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; v.push_back(ic); }
+  return v;
+}
+
+void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& a, DevBuf& strlit_dev) {
+  memset(&a, 0, sizeof(a));
+  for (size_t s = 0; s < b.cols.size(); ++s) {
+    const DevColumn& c = t->cols[(size_t)b.cols[s]];
+    a.c[s].v = c.values ? c.values->ptr : nullptr;
+    a.c[s].n = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
+    a.c[s].d = c.data ? (const uint8_t*)c.data->ptr : nullptr;
+  }
+  for (size_t l = 0; l < b.lit_lo.size(); ++l) { a.lit_lo[l] = b.lit_lo[l]; a.lit_hi[l] = b.lit_hi[l]; }
+  for (size_t l = 0; l < b.stroff.size() && l < (size_t)kMaxLits + 1; ++l) a.stroff[l] = b.stroff[l];
+  strlit_dev.alloc(b.strlits.size());
+  if (!b.strlits.empty())
+    QHIP_HIP_CHECK(hipMemcpyAsync(strlit_dev.ptr, b.strlits.data(), b.strlits.size(), hipMemcpyHostToDevice, ctx->stream));
+  a.strlit = (const uint8_t*)strlit_dev.ptr;
+  a.nrows = t->num_rows;
+}
+
+void check_status_words(const uint32_t* st) {
+  if (st[QS_KEY_TOO_LONG]) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than 7 bytes is not accelerated yet");
+  if (st[QS_DIV_ZERO]) fail(QHIP_EXEC_ERROR, "Arrow error: Divide by zero error");
+  if (st[QS_CAST_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Cast error: value out of range for the target type");
+  if (st[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Arithmetic overflow: Overflow happened on integer division");
+}
+
+static uint32_t pow2_ceil(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return (uint32_t)std::min<uint64_t>(p, 1ULL << 31);
+}
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static double ord_to_f64(uint64_t k) {
+  uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+  double d; memcpy(&d, &b, 8); return d;
+}
+
+// ---------------------------------------------------------------- the operator
+static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, int pred_root,
+                                  const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs,
+                                  const char* const* out_names) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_groups < 0 || n_aggs < 0 || (n_groups > 0 && !group_roots) || (n_aggs > 0 && !aggs) || (n_exprs > 0 && !exprs))
+    fail(QHIP_INVALID_ARGUMENT, "qhip_hash_aggregate_execute: bad arguments");
+  for (int k = 0; k < n_groups; ++k)
+    if (group_roots[k] < 0 || group_roots[k] >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "group expression index out of range");
+  if (pred_root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "predicate index out of range");
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+
+  std::vector<InputCol> icols = input_cols_of(in);
+  ExprSet es;
+  es.build(exprs, n_exprs, icols);
+  AggPlan plan;
+  plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, env_int("QHIP_AGG_R", 4), plan);
+
+  // output schema: keys then aggregates (hash.rs:166-169)
+  std::vector<std::string> names;
+  std::vector<bool> nullable;
+  for (int k = 0; k < n_groups + n_aggs; ++k) {
+    names.push_back(out_names && out_names[k] ? out_names[k] : ("col" + std::to_string(k)));
+    nullable.push_back(true);
+  }
+  const bool zero_batches_in = in->num_batches() == 0;
+  if (n_groups > 0 && zero_batches_in) {
+    // hash.rs:146-148: no input batches -> no output batches
+    std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));
+    for (int k = 0; k < n_groups; ++k) cols[(size_t)k].init_fixed(plan.keys[(size_t)k].type, 0);
+    for (int k = 0; k < n_aggs; ++k) cols[(size_t)(n_groups + k)].init_fixed(plan.aggs[(size_t)k].ret, 0);
+    return table_from_host(ctx, names, nullable, cols, 0, true);
+  }
+
+  std::shared_ptr<Module> mod = get_module(ctx, plan.source, plan.kernel_name);
+  HKArgs ka;
+  DevBuf strlit;
+  fill_kargs(ctx, in, plan.bind, ka, strlit);
+
+  const int64_t N = in->num_rows;
+  const int slot_bytes = plan.slot_words * 8;
+  // LDS-staged table: as many slots as fit the per-workgroup LDS budget
+  uint32_t l_nslots = 0;
+  if (plan.W > 0) {
+    const int lds_budget = env_int("QHIP_AGG_LDS_BYTES", 32 * 1024);
+    l_nslots = 16;
+    while ((uint64_t)l_nslots * 2 * slot_bytes <= (uint64_t)lds_budget) l_nslots *= 2;
+    if ((uint64_t)l_nslots * slot_bytes > 64 * 1024) l_nslots = 0;   // slot too wide for LDS staging
+  }
+  const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
+  const int64_t tile_rows = (int64_t)256 * plan.R;
+  const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
+  const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", 4);
+  unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
+
+  uint32_t cap = plan.W == 0 ? 1 : std::max<uint32_t>(1024, std::min<uint32_t>(pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2), 1u << 22));
+  const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
+  DevBuf gtable;
+  uint32_t status[QS_WORDS];
+  int retries = 0;
+  float main_ms = 0;
+  for (;;) {
+    gtable.alloc((size_t)cap * slot_bytes);
+    QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, (size_t)cap * slot_bytes, ctx->stream));
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+    HAggLaunch L;
+    L.gtable = gtable.as<uint64_t>();
+    L.g_nslots = cap;
+    L.l_nslots = l_nslots;
+    L.status = ctx->status.as<uint32_t>();
+    void* args[] = {&ka, &L};
+    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (N > 0 || plan.W == 0) {
+      if (N > 0)
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+    }
+    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
+    QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
+    check_status_words(status);
+    if (!status[QS_OVERFLOW]) break;
+    if (cap >= cap_max) fail(QHIP_HIP_ERROR, "group table overflow at maximum capacity (internal error)");
+    cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 8, cap_max);
+    ++retries;
+  }
+
+  // ---- dense slots -> host
+  uint32_t G = 0;
+  std::vector<uint64_t> slots;
+  if (plan.W == 0) {
+    G = 1;
+    slots.resize((size_t)plan.slot_words);
+    QHIP_HIP_CHECK(hipMemcpy(slots.data(), gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost));
+  } else {
+    DevBuf counter(8);
+    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, ctx->stream));
+    launch_count_ready(gtable.as<uint64_t>(), cap, plan.slot_words, counter.as<uint32_t>(), ctx->stream);
+    QHIP_HIP_CHECK(hipMemcpyAsync(&G, counter.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    DevBuf dense((size_t)G * slot_bytes);
+    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, ctx->stream));
+    launch_compact_slots(gtable.as<uint64_t>(), cap, plan.slot_words, dense.as<uint64_t>(), counter.as<uint32_t>(), G, ctx->stream);
+    slots.resize((size_t)G * plan.slot_words);
+    if (G) QHIP_HIP_CHECK(hipMemcpyAsync(slots.data(), dense.ptr, (size_t)G * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+
+  // ---- assemble the output columns (GroupAccumulator::output, hash.rs:89-107; accumulator evaluate())
+  std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));
+  const int cell0 = 1 + plan.W;
+  for (int k = 0; k < n_groups; ++k) {
+    const KeyDesc& kd = plan.keys[(size_t)k];
+    HostColumn& hc = cols[(size_t)k];
+    hc.init_fixed(kd.type, G);
+    for (uint32_t g = 0; g < G; ++g) {
+      const uint64_t* slot = &slots[(size_t)g * plan.slot_words];
+      const bool is_null = plan.null_mask_word && ((slot[1] >> k) & 1);
+      const uint64_t w0 = slot[1 + kd.word_off];
+      if (kd.type.id == QHIP_UTF8) {
+        const int len = is_null ? 0 : (int)(w0 >> 56);
+        for (int b = 0; b < len; ++b) hc.data.push_back((uint8_t)(w0 >> (8 * b)));
+        hc.offsets[(size_t)g + 1] = (int32_t)hc.data.size();
+      } else if (kd.type.id == QHIP_DECIMAL128) {
+        hc.as<uint64_t>()[2 * (size_t)g] = w0;
+        hc.as<uint64_t>()[2 * (size_t)g + 1] = slot[1 + kd.word_off + 1];
+      } else {
+        const int w = dtype_width(kd.type);
+        memcpy(hc.values.data() + (size_t)g * w, &w0, (size_t)w);   // little-endian truncation of the sign-extended word
+      }
+      if (is_null) hc.set_null(g);
+    }
+  }
+  for (int k = 0; k < n_aggs; ++k) {
+    const AggDesc& ad = plan.aggs[(size_t)k];
+    HostColumn& hc = cols[(size_t)(n_groups + k)];
+    hc.init_fixed(ad.ret, G);
+    for (uint32_t g = 0; g < G; ++g) {
+      const uint64_t* cell = &slots[(size_t)g * plan.slot_words + cell0];
+      const uint64_t nonnull = cell[plan.cells[(size_t)ad.count_cell].off];
+      const uint64_t* vc = ad.value_cell >= 0 ? cell + plan.cells[(size_t)ad.value_cell].off : nullptr;
+      switch (ad.kind) {
+        case QHIP_AGG_COUNT:   // count.rs:36-48
+          hc.as<int64_t>()[g] = (int64_t)nonnull;
+          break;
+        case QHIP_AGG_SUM:     // sum.rs:71-103: None until a non-null value was seen
+          if (!nonnull) { hc.set_null(g); break; }
+          if (ad.ret.id == QHIP_DECIMAL128) { hc.as<uint64_t>()[2 * (size_t)g] = vc[0]; hc.as<uint64_t>()[2 * (size_t)g + 1] = vc[1]; }
+          else hc.as<uint64_t>()[g] = vc[0];   // Int64 / UInt64 wrapping sum, Float64 bit pattern
+          break;
+        case QHIP_AGG_AVG: {
+          if (!nonnull) { hc.set_null(g); break; }
+          if (ad.ret.id == QHIP_FLOAT64) {   // avg.rs:63-78
+            double s; memcpy(&s, vc, 8);
+            hc.as<double>()[g] = s / (double)nonnull;
+            break;
+          }
+          // avg.rs:91-116 (DecimalAvgAccumulator::evaluate)
+          const DType& at = plan.args[(size_t)ad.arg].type;
+          const i128 sum = (i128)(((u128)vc[1] << 64) | (u128)vc[0]);
+          if (ad.ret.scale < at.scale) fail(QHIP_EXEC_ERROR, "Internal error: Arithmetic Overflow in DecimalAvgAccumulator");
+          const i128 mul = pow10_i128(ad.ret.scale - at.scale);
+          i128 value;
+          if (__builtin_mul_overflow(sum, mul, &value)) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): sum * 10^k overflows i128 (reference yields a mistyped NULL, avg.rs:105-116)");
+          const i128 lim = pow10_i128(ad.ret.precision);
+          if (value >= lim || value <= -lim)
+            fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum exceeds " + dtype_name(ad.ret) + " (reference yields a mistyped NULL, avg.rs:105-116)");
+          const i128 q = value / (i128)nonnull;   // truncating, like i128::div_wrapping
+          hc.as<uint64_t>()[2 * (size_t)g] = (uint64_t)(u128)q;
+          hc.as<uint64_t>()[2 * (size_t)g + 1] = (uint64_t)((u128)q >> 64);
+          break;
+        }
+        case QHIP_AGG_MIN:
+        case QHIP_AGG_MAX: {
+          // PrimitiveAccumulator (aggregate/mod.rs:28-84): seeded with NATIVE::MAX / MIN, Some() as soon as
+          // accumulate ran once — i.e. for every existing group, and for NoGrouping whenever a batch arrived.
+          const bool is_min = ad.kind == QHIP_AGG_MIN;
+          if (plan.W == 0 && zero_batches_in) { hc.set_null(g); break; }
+          const DType& t = ad.ret;
+          if (t.id == QHIP_DECIMAL128) {
+            u128 o = ((u128)vc[1] << 64) | (u128)vc[0];
+            if (is_min) o = ~o;
+            const u128 v = o ^ ((u128)1 << 127);
+            hc.as<uint64_t>()[2 * (size_t)g] = (uint64_t)v;
+            hc.as<uint64_t>()[2 * (size_t)g + 1] = (uint64_t)(v >> 64);
+          } else if (dtype_is_float(t)) {
+            uint64_t o = is_min ? ~vc[0] : vc[0];
+            double v = (vc[0] == 0) ? (is_min ? DBL_MAX : -DBL_MAX) : ord_to_f64(o);
+            if (t.id == QHIP_FLOAT32) {
+              const float lim = FLT_MAX;
+              float fv = (float)v;
+              if (vc[0] == 0 || std::isnan(fv)) fv = is_min ? lim : -lim;
+              if (is_min && fv > lim) fv = lim;
+              if (!is_min && fv < -lim) fv = -lim;
+              hc.as<float>()[g] = fv;
+            } else {
+              if (std::isnan(v)) v = is_min ? DBL_MAX : -DBL_MAX;
+              if (is_min && v > DBL_MAX) v = DBL_MAX;
+              if (!is_min && v < -DBL_MAX) v = -DBL_MAX;
+              hc.as<double>()[g] = v;
+            }
+          } else {
+            uint64_t o = is_min ? ~vc[0] : vc[0];
+            uint64_t raw = dtype_is_signed(t) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 ? (o ^ 0x8000000000000000ULL) : o;
+            memcpy(hc.values.data() + (size_t)g * dtype_width(t), &raw, (size_t)dtype_width(t));
+          }
+          break;
+        }
+      }
+    }
+  }
+  ctx->stats.main_kernel_ms = main_ms;
+  ctx->stats.total_device_ms = main_ms;
+  ctx->stats.rows_in = N;
+  ctx->stats.rows_out = G;
+  ctx->stats.groups = G;
+  ctx->stats.table_capacity = cap;
+  ctx->stats.retries = retries;
+  ctx->stats.lds_table_slots = (int32_t)l_nslots;
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+  return table_from_host(ctx, names, nullable, cols, G, false);
+}
+
+}  // namespace qhip
+
+using namespace qhip;
+
+extern "C" int qhip_hash_aggregate_execute(qhip_ctx* ctx, const qhip_table* input, const qhip_expr* exprs, int32_t n_exprs,
+                                           int32_t predicate_root, const int32_t* group_roots, int32_t n_groups, const qhip_agg* aggs,
+                                           int32_t n_aggs, const char* const* out_names, qhip_table** out) {
+  if (!ctx || !input || !out) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = hash_aggregate(ctx, input, exprs, n_exprs, predicate_root, group_roots, n_groups, aggs, n_aggs, out_names); });
+}

@@ -1,0 +1,666 @@
+// codegen.cpp — expression tree -> HIP policy struct source.
+//
+// Only the per-row expression code (load columns, compare, decimal arithmetic, pack keys) is generated;
+// every algorithmic piece (wave dedup, DPP reductions, LDS/HBM tables, atomics) is the hand-written
+// template code of device/qhip_device.hpp that these policies plug into. Literal VALUES never appear
+// in the generated text (they travel in KArgs.lit_*), so `l_shipdate < DATE x` compiles once for all x.
+#include "codegen.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <sstream>
+
+#include "device/qhip_status.h"
+
+namespace qhip {
+
+static bool is_cmp(int op) { return op >= QHIP_OP_EQ && op <= QHIP_OP_LTEQ; }
+static const char* c_cmp(int op) {
+  switch (op) {
+    case QHIP_OP_EQ: return "==";
+    case QHIP_OP_NOTEQ: return "!=";
+    case QHIP_OP_GT: return ">";
+    case QHIP_OP_GTEQ: return ">=";
+    case QHIP_OP_LT: return "<";
+    case QHIP_OP_LTEQ: return "<=";
+  }
+  return "==";
+}
+
+std::string ExprGen::ctype(const DType& t) {
+  switch (t.id) {
+    case QHIP_BOOL: return "bool";
+    case QHIP_INT8: return "signed char";
+    case QHIP_INT16: return "short";
+    case QHIP_INT32: case QHIP_DATE32: return "int";
+    case QHIP_INT64: case QHIP_DATE64: return "i64";
+    case QHIP_UINT8: return "u8";
+    case QHIP_UINT16: return "u16";
+    case QHIP_UINT32: return "u32";
+    case QHIP_UINT64: return "u64";
+    case QHIP_FLOAT32: return "float";
+    case QHIP_FLOAT64: return "double";
+    case QHIP_DECIMAL128: return "i128";
+    default: return "int";
+  }
+}
+
+std::string ExprGen::i128_const(i128 v) {
+  char buf[96];
+  snprintf(buf, sizeof buf, "qh_mk128(0x%llxULL, (i64)0x%llxULL)", (unsigned long long)(uint64_t)(u128)v,
+           (unsigned long long)(uint64_t)((u128)v >> 64));
+  return buf;
+}
+
+static bool intlike(const DType& t) {
+  return (t.id >= QHIP_INT8 && t.id <= QHIP_UINT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64;
+}
+static bool signed_intlike(const DType& t) { return (t.id >= QHIP_INT8 && t.id <= QHIP_INT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64; }
+static std::string int_min(const DType& t) {
+  switch (t.id) {
+    case QHIP_INT8: return "(-128)";
+    case QHIP_INT16: return "(-32768)";
+    case QHIP_INT32: case QHIP_DATE32: return "(-2147483647-1)";
+    case QHIP_INT64: case QHIP_DATE64: return "(-9223372036854775807LL-1)";
+    default: return "0";
+  }
+}
+static std::string int_max(const DType& t) {
+  switch (t.id) {
+    case QHIP_INT8: return "127";
+    case QHIP_INT16: return "32767";
+    case QHIP_INT32: case QHIP_DATE32: return "2147483647";
+    case QHIP_INT64: case QHIP_DATE64: return "9223372036854775807LL";
+    case QHIP_UINT8: return "255";
+    case QHIP_UINT16: return "65535";
+    case QHIP_UINT32: return "4294967295U";
+    case QHIP_UINT64: return "18446744073709551615ULL";
+    default: return "0";
+  }
+}
+// unsigned type wide enough for wrapping arithmetic on t
+static std::string wrap_type(const DType& t) { return dtype_width(t) == 8 ? "u64" : "u32"; }
+
+ExprGen::ExprGen(const ExprSet& es, const std::vector<InputCol>& in) : es_(es), in_(in), done_(es.nodes.size(), false) {
+  bind.stroff.push_back(0);
+}
+
+std::string ExprGen::ok(int k) const {
+  return es_.at(k).nullable ? "n" + std::to_string(k) : "true";
+}
+
+int ExprGen::col_slot(int table_col) {
+  for (size_t s = 0; s < bind.cols.size(); ++s) if (bind.cols[s] == table_col) return (int)s;
+  if (bind.cols.size() >= 24) fail(QHIP_UNSUPPORTED, "expression references more than 24 distinct columns");
+  bind.cols.push_back(table_col);
+  return (int)bind.cols.size() - 1;
+}
+
+int ExprGen::lit_slot(const ENode& n) {
+  if (bind.lit_lo.size() >= 24) fail(QHIP_UNSUPPORTED, "more than 24 literals in one kernel");
+  uint64_t lo = n.lo; int64_t hi = n.hi;
+  if (n.type.id == QHIP_FLOAT64 || n.type.id == QHIP_FLOAT32) { double f = n.f; memcpy(&lo, &f, 8); hi = 0; }
+  bind.lit_lo.push_back(lo);
+  bind.lit_hi.push_back(hi);
+  if (n.type.id == QHIP_UTF8) bind.strlits += n.s;
+  bind.stroff.push_back((int)bind.strlits.size());
+  return (int)bind.lit_lo.size() - 1;
+}
+
+void ExprGen::emit(int k, std::string& out) {
+  if (done_[(size_t)k]) return;
+  const ENode& n = es_.at(k);
+  const std::string K = std::to_string(k);
+  const std::string v = "v" + K, nn = "n" + K;
+  std::ostringstream o;
+  switch (n.kind) {
+    case QHIP_EXPR_COLUMN: {
+      const int s = col_slot(n.column);
+      const std::string S = std::to_string(s);
+      if (n.type.id == QHIP_UTF8) {
+        o << "    const int* o" << K << " = (const int*)a.c[" << S << "].v; const int b" << K << " = o" << K << "[i];\n";
+        o << "    const int l" << K << " = o" << K << "[i + 1] - b" << K << "; const u8* p" << K << " = a.c[" << S << "].d + b" << K << ";\n";
+      } else if (n.type.id == QHIP_BOOL) {
+        o << "    const bool " << v << " = qh_bit((const u8*)a.c[" << S << "].v, i);\n";
+      } else if (n.type.id == QHIP_NULL) {
+        o << "    const int " << v << " = 0;\n";
+      } else {
+        o << "    const " << ctype(n.type) << " " << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v)[i];\n";
+      }
+      if (n.nullable) {
+        if (n.type.id == QHIP_NULL) o << "    const bool " << nn << " = false;\n";
+        else o << "    const bool " << nn << " = qh_bit(a.c[" << S << "].n, i);\n";
+      }
+      break;
+    }
+    case QHIP_EXPR_LITERAL: {
+      if (n.lit_null) {
+        if (n.type.id == QHIP_UTF8) o << "    const u8* p" << K << " = a.strlit; const int l" << K << " = 0;\n";
+        else o << "    const " << ctype(n.type) << " " << v << " = 0;\n";
+        o << "    const bool " << nn << " = false;\n";
+        break;
+      }
+      const int s = lit_slot(n);
+      const std::string S = std::to_string(s);
+      if (n.type.id == QHIP_UTF8)
+        o << "    const u8* p" << K << " = a.strlit + a.stroff[" << S << "]; const int l" << K << " = a.stroff[" << s + 1 << "] - a.stroff[" << S << "];\n";
+      else if (n.type.id == QHIP_DECIMAL128)
+        o << "    const i128 " << v << " = qh_mk128(a.lit_lo[" << S << "], a.lit_hi[" << S << "]);\n";
+      else if (n.type.id == QHIP_FLOAT64)
+        o << "    const double " << v << " = qh_f64(a.lit_lo[" << S << "]);\n";
+      else if (n.type.id == QHIP_FLOAT32)
+        o << "    const float " << v << " = (float)qh_f64(a.lit_lo[" << S << "]);\n";
+      else if (n.type.id == QHIP_BOOL)
+        o << "    const bool " << v << " = (a.lit_lo[" << S << "] & 1) != 0;\n";
+      else
+        o << "    const " << ctype(n.type) << " " << v << " = (" << ctype(n.type) << ")a.lit_lo[" << S << "];\n";
+      break;
+    }
+    case QHIP_EXPR_BINARY: {
+      emit(n.left, out);
+      emit(n.right, out);
+      const ENode& l = es_.at(n.left);
+      const ENode& r = es_.at(n.right);
+      const std::string lv = val(n.left), rv = val(n.right), lo = ok(n.left), ro = ok(n.right);
+      if (is_cmp(n.op)) {
+        std::string e;
+        if (l.type.id == QHIP_UTF8) {
+          if (n.op == QHIP_OP_EQ) e = "qh_streq(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ")";
+          else if (n.op == QHIP_OP_NOTEQ) e = "!qh_streq(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ")";
+          else e = "(qh_strcmp(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ") " + c_cmp(n.op) + " 0)";
+        } else if (dtype_is_float(l.type)) {
+          // arrow-rs compares floats in IEEE total order
+          e = "(qh_f64_ord((double)" + lv + ") " + c_cmp(n.op) + " qh_f64_ord((double)" + rv + "))";
+        } else if (l.type.id == QHIP_BOOL) {
+          e = "((int)" + lv + " " + c_cmp(n.op) + " (int)" + rv + ")";
+        } else {
+          e = "(" + lv + " " + c_cmp(n.op) + " " + rv + ")";
+        }
+        if (n.nullable) {
+          o << "    const bool " << nn << " = " << lo << " && " << ro << ";\n";
+          if (l.type.id == QHIP_UTF8) o << "    const bool " << v << " = " << nn << " ? " << e << " : false;\n";
+          else o << "    const bool " << v << " = " << e << ";\n";
+        } else {
+          o << "    const bool " << v << " = " << e << ";\n";
+        }
+      } else if (n.op == QHIP_OP_AND) {
+        // Kleene AND (binary.rs:44-46): false AND NULL = false
+        if (n.nullable) {
+          o << "    const bool " << nn << " = (" << lo << " && " << ro << ") || (" << lo << " && !" << lv << ") || (" << ro << " && !" << rv << ");\n";
+          o << "    const bool " << v << " = (!" << lo << " || " << lv << ") && (!" << ro << " || " << rv << ");\n";
+        } else {
+          o << "    const bool " << v << " = " << lv << " && " << rv << ";\n";
+        }
+      } else if (n.op == QHIP_OP_OR) {
+        if (n.nullable) {
+          o << "    const bool " << nn << " = (" << lo << " && " << ro << ") || (" << lo << " && " << lv << ") || (" << ro << " && " << rv << ");\n";
+          o << "    const bool " << v << " = (" << lo << " && " << lv << ") || (" << ro << " && " << rv << ");\n";
+        } else {
+          o << "    const bool " << v << " = " << lv << " || " << rv << ";\n";
+        }
+      } else {
+        if (n.nullable) o << "    const bool " << nn << " = " << lo << " && " << ro << ";\n";
+        const std::string T = ctype(n.type);
+        const bool ld = l.type.id == QHIP_DECIMAL128, rd = r.type.id == QHIP_DECIMAL128;
+        if (ld || rd) {
+          if (n.op == QHIP_OP_DIV) {
+            auto tof = [&](const ENode& x, const std::string& xv) {
+              if (x.type.id == QHIP_DECIMAL128) {
+                char b[64]; snprintf(b, sizeof b, "1e%d", x.type.scale);
+                return "((double)" + xv + " / " + b + ")";
+              }
+              return "(double)" + xv;
+            };
+            o << "    const double " << v << " = " << tof(l, lv) << " / " << tof(r, rv) << ";\n";
+          } else if (n.op == QHIP_OP_MUL) {
+            o << "    const i128 " << v << " = (i128)((u128)" << lv << " * (u128)" << rv << ");\n";
+          } else {
+            const int s = n.type.scale;
+            std::string a = "(u128)" + lv, b = "(u128)" + rv;
+            if (s > l.type.scale) a = "(" + a + " * (u128)" + i128_const(pow10_i128(s - l.type.scale)) + ")";
+            if (s > r.type.scale) b = "(" + b + " * (u128)" + i128_const(pow10_i128(s - r.type.scale)) + ")";
+            o << "    const i128 " << v << " = (i128)(" << a << (n.op == QHIP_OP_ADD ? " + " : " - ") << b << ");\n";
+          }
+        } else if (dtype_is_float(n.type)) {
+          if (n.op == QHIP_OP_MOD) o << "    const " << T << " " << v << " = (" << T << ")fmod((double)" << lv << ", (double)" << rv << ");\n";
+          else {
+            const char* c = n.op == QHIP_OP_ADD ? "+" : n.op == QHIP_OP_SUB ? "-" : n.op == QHIP_OP_MUL ? "*" : "/";
+            o << "    const " << T << " " << v << " = " << lv << " " << c << " " << rv << ";\n";
+          }
+        } else {
+          const std::string U = wrap_type(n.type);
+          if (n.op == QHIP_OP_ADD || n.op == QHIP_OP_SUB || n.op == QHIP_OP_MUL) {
+            const char* c = n.op == QHIP_OP_ADD ? "+" : n.op == QHIP_OP_SUB ? "-" : "*";
+            o << "    const " << T << " " << v << " = (" << T << ")((" << U << ")" << lv << " " << c << " (" << U << ")" << rv << ");\n";
+          } else {
+            // arrow `div`/`rem` are checked: DivideByZero, and MIN / -1 overflows (evaluated on valid rows only)
+            o << "    " << T << " " << v << " = 0;\n";
+            o << "    if (" << (n.nullable ? nn : std::string("true")) << ") {\n";
+            o << "      if (" << rv << " == 0) atomicOr(&status[" << QS_DIV_ZERO << "], 1u);\n";
+            if (signed_intlike(n.type)) {
+              if (n.op == QHIP_OP_DIV)
+                o << "      else if (" << lv << " == " << int_min(n.type) << " && " << rv << " == -1) atomicOr(&status[" << QS_ARITH_OVERFLOW << "], 1u);\n";
+              else
+                o << "      else if (" << rv << " == -1) " << v << " = 0;\n";
+            }
+            o << "      else " << v << " = (" << T << ")(" << lv << (n.op == QHIP_OP_DIV ? " / " : " % ") << rv << ");\n";
+            o << "    }\n";
+          }
+        }
+      }
+      break;
+    }
+    case QHIP_EXPR_CAST: {
+      emit(n.left, out);
+      const ENode& ch = es_.at(n.left);
+      const std::string cv = val(n.left), co = ok(n.left);
+      const DType& from = ch.type;
+      const DType& to = n.type;
+      const std::string T = ctype(to);
+      if (n.nullable) o << "    const bool " << nn << " = " << co << ";\n";
+      const std::string live = n.nullable ? nn : std::string("true");
+      auto flag = [&](const std::string& cond) {
+        o << "    if (" << live << " && (" << cond << ")) atomicOr(&status[" << QS_CAST_OVERFLOW << "], 1u);\n";
+      };
+      if (from == to) {
+        o << "    const " << T << " " << v << " = " << cv << ";\n";
+      } else if (from.id == QHIP_BOOL) {
+        o << "    const " << T << " " << v << " = " << cv << " ? 1 : 0;\n";
+      } else if (intlike(from) && intlike(to)) {
+        if (from.id == QHIP_DATE32 && to.id == QHIP_DATE64) o << "    const i64 " << v << " = (i64)" << cv << " * 86400000LL;\n";
+        else if (from.id == QHIP_DATE64 && to.id == QHIP_DATE32) o << "    const int " << v << " = (int)(" << cv << " / 86400000LL);\n";
+        else {
+          // range check in i128 so that every (from, to) pair is handled uniformly
+          const std::string wide = std::string(from.id == QHIP_UINT64 ? "(i128)(u128)" : "(i128)") + cv;
+          const std::string lo = signed_intlike(to) ? "(i128)" + int_min(to) : "(i128)0";
+          flag(wide + " < " + lo + " || " + wide + " > (i128)" + int_max(to));
+          o << "    const " << T << " " << v << " = (" << T << ")" << cv << ";\n";
+        }
+      } else if (intlike(from) && dtype_is_float(to)) {
+        o << "    const " << T << " " << v << " = (" << T << ")" << cv << ";\n";
+      } else if (dtype_is_float(from) && dtype_is_float(to)) {
+        o << "    const " << T << " " << v << " = (" << T << ")" << cv << ";\n";
+      } else if (dtype_is_float(from) && intlike(to)) {
+        const std::string tr = "trunc((double)" + cv + ")";
+        const std::string lo = signed_intlike(to) ? "(double)" + int_min(to) : "0.0";
+        flag("!(" + tr + " >= " + lo + " && " + tr + " <= (double)" + int_max(to) + ")");
+        o << "    const " << T << " " << v << " = (" << T << ")" << tr << ";\n";
+      } else if (intlike(from) && to.id == QHIP_DECIMAL128) {
+        const std::string wide = std::string(from.id == QHIP_UINT64 ? "(i128)(u128)" : "(i128)") + cv;
+        o << "    const i128 " << v << " = " << wide << " * " << i128_const(pow10_i128(to.scale)) << ";\n";
+        const std::string lim = i128_const(pow10_i128(to.precision));
+        flag(v + " >= " + lim + " || " + v + " <= -" + lim);
+      } else if (from.id == QHIP_DECIMAL128 && to.id == QHIP_DECIMAL128) {
+        if (to.scale >= from.scale) {
+          o << "    const i128 " << v << " = " << cv << " * " << i128_const(pow10_i128(to.scale - from.scale)) << ";\n";
+        } else {
+          const std::string d = i128_const(pow10_i128(from.scale - to.scale));
+          o << "    i128 " << v << " = " << cv << " / " << d << "; { const i128 rm = " << cv << " % " << d << ", hf = " << d << " / 2;"
+            << " if (rm >= hf) " << v << " += 1; else if (-rm >= hf) " << v << " -= 1; }\n";
+        }
+        const std::string lim = i128_const(pow10_i128(to.precision));
+        flag(v + " >= " + lim + " || " + v + " <= -" + lim);
+      } else if (from.id == QHIP_DECIMAL128 && dtype_is_float(to)) {
+        char b[64]; snprintf(b, sizeof b, "1e%d", from.scale);
+        o << "    const " << T << " " << v << " = (" << T << ")((double)" << cv << " / " << b << ");\n";
+      } else if (from.id == QHIP_DECIMAL128 && intlike(to)) {
+        o << "    const i128 w" << K << " = " << cv << " / " << i128_const(pow10_i128(from.scale)) << ";\n";
+        const std::string lo = signed_intlike(to) ? "(i128)" + int_min(to) : "(i128)0";
+        flag("w" + K + " < " + lo + " || w" + K + " > (i128)" + int_max(to));
+        o << "    const " << T << " " << v << " = (" << T << ")w" << K << ";\n";
+      } else if (dtype_is_float(from) && to.id == QHIP_DECIMAL128) {
+        char b[64]; snprintf(b, sizeof b, "1e%d", to.scale);
+        o << "    const double f" << K << " = round((double)" << cv << " * " << b << ");\n";
+        char lim[64]; snprintf(lim, sizeof lim, "1e%d", to.precision);
+        flag("!(fabs(f" + K + ") < " + lim + ")");
+        o << "    const i128 " << v << " = (fabs(f" << K << ") < 1.7e38) ? (i128)f" << K << " : (i128)0;\n";
+      } else {
+        fail(QHIP_UNSUPPORTED, "device cast " + dtype_name(from) + " -> " + dtype_name(to));
+      }
+      break;
+    }
+    case QHIP_EXPR_IS_NULL:
+    case QHIP_EXPR_IS_NOT_NULL: {
+      emit(n.left, out);
+      o << "    const bool " << v << " = " << (n.kind == QHIP_EXPR_IS_NULL ? "!" : "") << "(" << ok(n.left) << ");\n";
+      break;
+    }
+    case QHIP_EXPR_NEGATIVE: {
+      emit(n.left, out);
+      if (n.nullable) o << "    const bool " << nn << " = " << ok(n.left) << ";\n";
+      const std::string T = ctype(n.type);
+      if (dtype_is_float(n.type)) o << "    const " << T << " " << v << " = -" << val(n.left) << ";\n";
+      else if (n.type.id == QHIP_DECIMAL128) o << "    const i128 " << v << " = (i128)((u128)0 - (u128)" << val(n.left) << ");\n";
+      else o << "    const " << T << " " << v << " = (" << T << ")((" << wrap_type(n.type) << ")0 - (" << wrap_type(n.type) << ")" << val(n.left) << ");\n";
+      break;
+    }
+  }
+  out += o.str();
+  done_[(size_t)k] = true;
+}
+
+// ---------------------------------------------------------------- key packing shared by aggregate / join / partition kernels
+// create_hashes (utils/array.rs:190-210) accepts exactly these key types; anything else is an InternalError there.
+static void check_key_type(const DType& t) {
+  switch (t.id) {
+    case QHIP_INT64: case QHIP_UINT8: case QHIP_INT32: case QHIP_UTF8: case QHIP_DATE32: case QHIP_DATE64: case QHIP_DECIMAL128:
+      return;
+    default:
+      fail(QHIP_INVALID_ARGUMENT, "Internal error: Unsupported data type in hasher: " + dtype_name(t));
+  }
+}
+
+static void layout_keys(const ExprSet& es, const int32_t* roots, int n, bool with_null_mask, std::vector<KeyDesc>& keys, int& W,
+                        bool& mask_word) {
+  keys.clear();
+  mask_word = false;
+  if (with_null_mask)
+    for (int k = 0; k < n; ++k) if (es.at(roots[k]).nullable) mask_word = true;
+  int off = mask_word ? 1 : 0;
+  for (int k = 0; k < n; ++k) {
+    const ENode& nd = es.at(roots[k]);
+    check_key_type(nd.type);
+    KeyDesc kd;
+    kd.root = roots[k]; kd.type = nd.type; kd.nullable = nd.nullable; kd.word_off = off;
+    kd.words = nd.type.id == QHIP_DECIMAL128 ? 2 : 1;
+    off += kd.words;
+    keys.push_back(kd);
+  }
+  W = off;
+  if (n > 60) fail(QHIP_UNSUPPORTED, "more than 60 key columns");
+}
+
+// statements storing the key words of the current row into `dst[...]`; `valid_all` receives the conjunction of validities
+static void emit_key_words(ExprGen& g, const ExprSet& es, const std::vector<KeyDesc>& keys, bool mask_word, const std::string& dst,
+                           std::string& out, std::string* valid_all) {
+  std::ostringstream o;
+  std::string all = "true";
+  if (mask_word) o << "    u64 nm = 0;\n";
+  for (size_t k = 0; k < keys.size(); ++k) {
+    const KeyDesc& kd = keys[k];
+    std::string code;
+    g.emit(kd.root, code);
+    o << code;
+    const std::string okx = g.ok(kd.root);
+    const std::string w = dst + "[" + std::to_string(kd.word_off) + "]";
+    std::string value;
+    if (kd.type.id == QHIP_UTF8) {
+      o << "    bool tl" << k << " = false; const u64 ks" << k << " = qh_pack_str7(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ", &tl" << k << ");\n";
+      o << "    if (" << okx << " && tl" << k << ") atomicOr(&status[" << QS_KEY_TOO_LONG << "], 1u);\n";
+      value = "ks" + std::to_string(k);
+    } else if (kd.type.id == QHIP_DECIMAL128) {
+      value = "(u64)(u128)" + g.val(kd.root);
+    } else {
+      value = "(u64)(i64)" + g.val(kd.root);
+    }
+    if (kd.nullable) {
+      o << "    " << w << " = " << okx << " ? " << value << " : 0ULL;\n";
+      if (kd.type.id == QHIP_DECIMAL128)
+        o << "    " << dst << "[" << kd.word_off + 1 << "] = " << okx << " ? (u64)((u128)" << g.val(kd.root) << " >> 64) : 0ULL;\n";
+      if (mask_word) o << "    nm |= " << okx << " ? 0ULL : " << (1ULL << k) << "ULL;\n";
+      all += " && " + okx;
+    } else {
+      o << "    " << w << " = " << value << ";\n";
+      if (kd.type.id == QHIP_DECIMAL128) o << "    " << dst << "[" << kd.word_off + 1 << "] = (u64)((u128)" << g.val(kd.root) << " >> 64);\n";
+    }
+  }
+  if (mask_word) o << "    " << dst << "[0] = nm;\n";
+  out += o.str();
+  if (valid_all) *valid_all = all;
+}
+
+// ---------------------------------------------------------------- aggregate policy
+static std::string ord64(const DType& t, const std::string& v) {
+  if (dtype_is_float(t)) return "qh_f64_ord((double)" + v + ")";
+  if (signed_intlike(t)) return "((u64)(i64)" + v + " ^ 0x8000000000000000ULL)";
+  return "(u64)" + v;
+}
+
+void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, const int32_t* group_roots, int n_groups,
+                    const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& P) {
+  P = AggPlan();
+  P.R = rows_per_thread;
+  if (predicate_root >= 0 && es.at(predicate_root).type.id != QHIP_BOOL)
+    fail(QHIP_INVALID_ARGUMENT, "filter predicate must be Boolean, got " + dtype_name(es.at(predicate_root).type));
+  layout_keys(es, group_roots, n_groups, true, P.keys, P.W, P.null_mask_word);
+  if (P.W > 8) fail(QHIP_UNSUPPORTED, "group key wider than 8 words");
+
+  // cells: cell 0 counts the rows of the group
+  auto add_cell = [&](int kind, int arg, bool is_min, int words) {
+    for (size_t c = 0; c < P.cells.size(); ++c)
+      if (P.cells[c].kind == kind && P.cells[c].arg == arg && P.cells[c].is_min == is_min) return (int)c;
+    CellDesc cd; cd.kind = kind; cd.arg = arg; cd.is_min = is_min; cd.words = words; cd.off = 0;
+    P.cells.push_back(cd);
+    return (int)P.cells.size() - 1;
+  };
+  add_cell(CELL_ROWS, -1, false, 1);
+  auto arg_index = [&](int root) {
+    const ENode& nd = es.at(root);
+    for (size_t a = 0; a < P.args.size(); ++a) if (es.at(P.args[a].root).canon == nd.canon) return (int)a;
+    ArgDesc ad; ad.root = root; ad.type = nd.type; ad.nullable = nd.nullable;
+    P.args.push_back(ad);
+    return (int)P.args.size() - 1;
+  };
+  for (int k = 0; k < n_aggs; ++k) {
+    const qhip_agg& a = aggs[k];
+    if (a.expr < 0 || a.expr >= (int)es.nodes.size()) fail(QHIP_INVALID_ARGUMENT, "aggregate argument index out of range");
+    const ENode& arg = es.at(a.expr);
+    AggDesc ad; ad.kind = a.kind; ad.ret = DType(a.return_type); ad.value_cell = -1; ad.count_cell = 0;
+    // a NULL-typed / all-null literal argument never contributes
+    ad.arg = arg_index(a.expr);
+    const bool nullable = arg.nullable;
+    auto count_cell = [&]() { return nullable ? add_cell(CELL_CNT, ad.arg, false, 1) : 0; };
+    switch (a.kind) {
+      case QHIP_AGG_COUNT:
+        ad.ret = DType(QHIP_INT64);
+        ad.count_cell = count_cell();
+        break;
+      case QHIP_AGG_SUM: {
+        // sum.rs:36-51: only these return types have an accumulator, and the argument array is downcast to it
+        if (!(ad.ret.id == QHIP_UINT64 || ad.ret.id == QHIP_INT64 || ad.ret.id == QHIP_FLOAT64 || ad.ret.id == QHIP_DECIMAL128))
+          fail(QHIP_INVALID_ARGUMENT, "Internal error: Sum not supported for " + arg.canon + ": " + dtype_name(ad.ret));
+        if (arg.type.id != ad.ret.id)
+          fail(QHIP_INVALID_ARGUMENT, "SUM argument type " + dtype_name(arg.type) + " does not match return type " + dtype_name(ad.ret));
+        const int kind = ad.ret.id == QHIP_DECIMAL128 ? CELL_SUM_I128 : ad.ret.id == QHIP_FLOAT64 ? CELL_SUM_F64 : CELL_SUM_U64;
+        ad.value_cell = add_cell(kind, ad.arg, false, kind == CELL_SUM_I128 ? 2 : 1);
+        ad.count_cell = count_cell();
+        break;
+      }
+      case QHIP_AGG_AVG: {
+        // avg.rs:36-61
+        if (arg.type.id == QHIP_DECIMAL128 && ad.ret.id == QHIP_DECIMAL128) {
+          ad.value_cell = add_cell(CELL_SUM_I128, ad.arg, false, 2);
+        } else if (arg.type.id == QHIP_FLOAT64 && ad.ret.id == QHIP_FLOAT64) {
+          ad.value_cell = add_cell(CELL_SUM_F64, ad.arg, false, 1);
+        } else {
+          fail(QHIP_INVALID_ARGUMENT, "Internal error: Unsupported data type [" + dtype_name(ad.ret) + "] for AVG aggregate over " + dtype_name(arg.type));
+        }
+        ad.count_cell = count_cell();
+        break;
+      }
+      case QHIP_AGG_MIN:
+      case QHIP_AGG_MAX: {
+        if (arg.type != ad.ret) fail(QHIP_INVALID_ARGUMENT, "MIN/MAX argument type differs from return type");
+        const bool is_min = a.kind == QHIP_AGG_MIN;
+        if (arg.type.id == QHIP_DECIMAL128) ad.value_cell = add_cell(CELL_MAXORD128, ad.arg, is_min, 3);
+        else if (intlike(arg.type) || dtype_is_float(arg.type)) ad.value_cell = add_cell(CELL_MAXORD64, ad.arg, is_min, 1);
+        else fail(QHIP_UNSUPPORTED, "MIN/MAX over " + dtype_name(arg.type));
+        ad.count_cell = count_cell();
+        break;
+      }
+      default:
+        fail(QHIP_INVALID_ARGUMENT, "unknown aggregate kind " + std::to_string(a.kind));
+    }
+    P.aggs.push_back(ad);
+  }
+  int off = 0;
+  for (auto& c : P.cells) { c.off = off; off += c.words; }
+  P.slot_words = 1 + P.W + off;
+
+  // ---- source
+  ExprGen g(es, input);
+  std::ostringstream s;
+  const int KW = P.W > 0 ? P.W : 1;
+  s << "struct P {\n";
+  s << "  static constexpr int W = " << P.W << ";\n  static constexpr int R = " << P.R << ";\n  static constexpr int SLOT_WORDS = " << P.slot_words << ";\n";
+  s << "  struct Row {\n    bool pass;\n    u64 key[" << KW << "];\n";
+  for (size_t a = 0; a < P.args.size(); ++a) {
+    const ArgDesc& ad = P.args[a];
+    bool value_needed = false;
+    for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
+    if (value_needed) s << "    " << ExprGen::ctype(ad.type) << " a" << a << ";\n";
+    if (ad.nullable) s << "    bool h" << a << ";\n";
+  }
+  s << "  };\n";
+  s << "  struct Part {\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const char* t = "u64";
+    if (P.cells[c].kind == CELL_SUM_I128) t = "i128";
+    else if (P.cells[c].kind == CELL_SUM_F64) t = "double";
+    else if (P.cells[c].kind == CELL_MAXORD128) t = "u128";
+    s << "    " << t << " c" << c << ";\n";
+  }
+  s << "  };\n";
+  // eval
+  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 i, Row& r, u32* status) {\n";
+  std::string code;
+  if (predicate_root >= 0) {
+    g.emit(predicate_root, code);
+    s << code;
+    s << "    r.pass = " << g.ok(predicate_root) << " && " << g.val(predicate_root) << ";\n";
+  } else {
+    s << "    r.pass = true;\n";
+  }
+  s << "    if (r.pass) {\n";
+  code.clear();
+  emit_key_words(g, es, P.keys, P.null_mask_word, "r.key", code, nullptr);
+  s << code;
+  for (size_t a = 0; a < P.args.size(); ++a) {
+    code.clear();
+    g.emit(P.args[a].root, code);
+    s << code;
+    bool value_needed = false;
+    for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
+    if (value_needed) s << "    r.a" << a << " = " << g.val(P.args[a].root) << ";\n";
+    if (P.args[a].nullable) s << "    r.h" << a << " = " << g.ok(P.args[a].root) << ";\n";
+  }
+  s << "    }\n  }\n";
+  // part_init
+  s << "  __device__ static __forceinline__ void part_init(Part& p) {\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";
+  s << "  }\n";
+  // part_add
+  s << "  __device__ static __forceinline__ void part_add(Part& p, const Row& r, const bool m) {\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const CellDesc& cd = P.cells[c];
+    const std::string C = "p.c" + std::to_string(c);
+    if (cd.kind == CELL_ROWS) { s << "    " << C << " += m ? 1ULL : 0ULL;\n"; continue; }
+    const ArgDesc& ad = P.args[(size_t)cd.arg];
+    const std::string A = "r.a" + std::to_string(cd.arg);
+    const std::string take = ad.nullable ? "(m && r.h" + std::to_string(cd.arg) + ")" : std::string("m");
+    switch (cd.kind) {
+      case CELL_SUM_I128: s << "    " << C << " = (i128)((u128)" << C << " + (u128)(" << take << " ? " << A << " : (i128)0));\n"; break;
+      case CELL_SUM_U64: s << "    " << C << " += " << take << " ? (u64)" << A << " : 0ULL;\n"; break;
+      case CELL_SUM_F64: s << "    " << C << " += " << take << " ? (double)" << A << " : 0.0;\n"; break;
+      case CELL_CNT: s << "    " << C << " += " << take << " ? 1ULL : 0ULL;\n"; break;
+      case CELL_MAXORD64: {
+        const std::string o = std::string(cd.is_min ? "~" : "") + ord64(ad.type, A);
+        s << "    { const u64 o = " << take << " ? " << o << " : 0ULL; " << C << " = o > " << C << " ? o : " << C << "; }\n";
+        break;
+      }
+      case CELL_MAXORD128: {
+        const std::string o = std::string(cd.is_min ? "~" : "") + "((u128)" + A + " ^ ((u128)1 << 127))";
+        s << "    { const u128 o = " << take << " ? " << o << " : (u128)0; " << C << " = o > " << C << " ? o : " << C << "; }\n";
+        break;
+      }
+    }
+  }
+  s << "  }\n";
+  // part_reduce
+  s << "  __device__ static __forceinline__ void part_reduce(Part& p) {\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const std::string C = "p.c" + std::to_string(c);
+    switch (P.cells[c].kind) {
+      case CELL_ROWS: case CELL_CNT: case CELL_SUM_U64: s << "    " << C << " = qh_wave_sum_u64(" << C << ");\n"; break;
+      case CELL_SUM_I128: s << "    " << C << " = qh_wave_sum_i128(" << C << ");\n"; break;
+      case CELL_SUM_F64: s << "    " << C << " = qh_wave_sum_f64(" << C << ");\n"; break;
+      case CELL_MAXORD64: s << "    " << C << " = qh_wave_max_u64(" << C << ");\n"; break;
+      case CELL_MAXORD128: s << "    " << C << " = qh_wave_max_u128(" << C << ");\n"; break;
+    }
+  }
+  s << "  }\n";
+  // slot_update
+  s << "  template <class M> __device__ static __forceinline__ void slot_update(u64* slot, const Part& p) {\n";
+  s << "    u64* cell = slot + " << 1 + P.W << ";\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const CellDesc& cd = P.cells[c];
+    const std::string C = "p.c" + std::to_string(c);
+    const std::string at = "cell + " + std::to_string(cd.off);
+    switch (cd.kind) {
+      case CELL_ROWS: case CELL_CNT: case CELL_SUM_U64: s << "    qh_acc_add_u64<M>(" << at << ", " << C << ");\n"; break;
+      case CELL_SUM_I128: s << "    qh_acc_add_i128<M>(" << at << ", " << C << ");\n"; break;
+      case CELL_SUM_F64: s << "    qh_acc_add_f64<M>(" << at << ", " << C << ");\n"; break;
+      case CELL_MAXORD64: s << "    if (" << C << ") qh_acc_max_u64<M>(" << at << ", " << C << ");\n"; break;
+      case CELL_MAXORD128: s << "    if (" << C << ") qh_acc_max_u128<M>(" << at << ", " << C << ");\n"; break;
+    }
+  }
+  s << "  }\n";
+  // slot_merge: LDS slot (plain reads, after the workgroup barrier) -> HBM slot
+  s << "  __device__ static __forceinline__ void slot_merge(u64* gs, const u64* ls) {\n";
+  s << "    const u64* cell = ls + " << 1 + P.W << ";\n    Part q;\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const CellDesc& cd = P.cells[c];
+    const std::string at = "cell[" + std::to_string(cd.off) + "]";
+    const std::string at1 = "cell[" + std::to_string(cd.off + 1) + "]";
+    switch (cd.kind) {
+      case CELL_SUM_I128: s << "    q.c" << c << " = qh_mk128(" << at << ", (i64)" << at1 << ");\n"; break;
+      case CELL_SUM_F64: s << "    q.c" << c << " = qh_f64(" << at << ");\n"; break;
+      case CELL_MAXORD128: s << "    q.c" << c << " = ((u128)" << at1 << " << 64) | (u128)" << at << ";\n"; break;
+      default: s << "    q.c" << c << " = " << at << ";\n"; break;
+    }
+  }
+  s << "    slot_update<MemHbm>(gs, q);\n  }\n";
+  s << "};\n";
+  P.kernel_name = "qk_filter_agg";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P>(a, L); }\n";
+  P.source = s.str();
+  P.bind = g.bind;
+}
+
+void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, int root, MaskPlan& out) {
+  if (root < 0 || root >= (int)es.nodes.size()) fail(QHIP_INVALID_ARGUMENT, "predicate root out of range");
+  if (es.at(root).type.id != QHIP_BOOL)
+    fail(QHIP_INVALID_ARGUMENT, "filter predicate must be Boolean, got " + dtype_name(es.at(root).type));
+  ExprGen g(es, input);
+  std::string code;
+  g.emit(root, code);
+  std::ostringstream s;
+  s << "struct P {\n  __device__ static __forceinline__ bool pred(const KArgs& a, const i64 i, u32* status) {\n" << code;
+  s << "    return " << g.ok(root) << " && " << g.val(root) << ";\n  }\n};\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_pred_mask(KArgs a, u64* mask, u32* wave_count, u32* status) { "
+       "qh_pred_mask_body<P>(a, mask, wave_count, status); }\n";
+  out.source = s.str();
+  out.kernel_name = "qk_pred_mask";
+  out.bind = g.bind;
+}
+
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out) {
+  out = KeysPlan();
+  layout_keys(es, roots, n, false, out.keys, out.W, out.null_mask_word);
+  if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
+  ExprGen g(es, input);
+  std::string code, all;
+  emit_key_words(g, es, out.keys, false, "k", code, &all);
+  std::ostringstream s;
+  s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
+  s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32* status) {\n" << code;
+  s << "    return " << all << ";\n  }\n};\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
+       "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
+  out.source = s.str();
+  out.kernel_name = "qk_eval_keys";
+  out.bind = g.bind;
+}
+
+}  // namespace qhip

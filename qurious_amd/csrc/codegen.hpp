@@ -1,0 +1,89 @@
+// codegen.hpp — turns typed expression trees into the policy structs the hand-written kernel
+// templates of device/qhip_device.hpp are instantiated with.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "expr.hpp"
+
+namespace qhip {
+
+// what a generated kernel needs bound at launch: which table column sits in KArgs.c[slot], literal values
+struct KernelBindings {
+  std::vector<int> cols;          // slot -> input column index
+  std::vector<uint64_t> lit_lo;
+  std::vector<int64_t> lit_hi;
+  std::string strlits;            // concatenated Utf8 literals
+  std::vector<int> stroff;        // per literal slot: offset into strlits (size = nlits + 1)
+};
+
+class ExprGen {
+ public:
+  ExprGen(const ExprSet& es, const std::vector<InputCol>& in);
+  // append the statements that compute node k (and whatever it needs that was not emitted yet)
+  void emit(int k, std::string& out);
+  std::string val(int k) const { return "v" + std::to_string(k); }
+  std::string ok(int k) const;                       // validity expression ("true" when never null)
+  std::string ptr(int k) const { return "p" + std::to_string(k); }
+  std::string len(int k) const { return "l" + std::to_string(k); }
+  KernelBindings bind;
+  static std::string ctype(const DType& t);
+  static std::string i128_const(i128 v);
+
+ private:
+  int col_slot(int table_col);
+  int lit_slot(const ENode& n);
+  const ExprSet& es_;
+  const std::vector<InputCol>& in_;
+  std::vector<bool> done_;
+};
+
+// ---------------------------------------------------------------- aggregate plan
+enum CellKind { CELL_ROWS = 0, CELL_SUM_I128, CELL_SUM_U64, CELL_SUM_F64, CELL_CNT, CELL_MAXORD64, CELL_MAXORD128 };
+
+struct KeyDesc {
+  int root; DType type; bool nullable;
+  int word_off;   // first key word (after the optional null-mask word)
+  int words;
+};
+struct ArgDesc { int root; DType type; bool nullable; };
+struct CellDesc {
+  int kind; int arg;   // arg = index into args (-1 for CELL_ROWS)
+  bool is_min;         // MAXORD cells: true stores ~ord(v) so that the running maximum is the minimum
+  int off;             // word offset inside the slot's cell area
+  int words;
+};
+struct AggDesc {
+  int kind; DType ret; int arg;
+  int value_cell;      // SUM/AVG: sum cell, MIN/MAX: maxord cell, COUNT: -1
+  int count_cell;      // cell counting the non-null argument values (the CELL_ROWS cell when the argument is never null)
+};
+struct AggPlan {
+  int W = 0;                   // key words (incl. null-mask word)
+  bool null_mask_word = false;
+  int R = 4;
+  int slot_words = 0;          // 1 + W + cell words
+  std::vector<KeyDesc> keys;
+  std::vector<ArgDesc> args;
+  std::vector<CellDesc> cells;
+  std::vector<AggDesc> aggs;
+  KernelBindings bind;
+  std::string source;          // policy struct + extern "C" kernel, to be appended to the device header
+  std::string kernel_name;
+};
+
+// group_roots / aggs refer to nodes of `es`; predicate_root < 0 = no filter
+void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, const int32_t* group_roots,
+                    int n_groups, const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& out);
+
+struct MaskPlan { KernelBindings bind; std::string source; std::string kernel_name; };
+void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, MaskPlan& out);
+
+struct KeysPlan {
+  int W = 0; bool null_mask_word = false;   // join keys never carry a null mask (NULL keys never match); partition keys do not need one either
+  std::vector<KeyDesc> keys;
+  KernelBindings bind; std::string source; std::string kernel_name;
+};
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out);
+
+}  // namespace qhip

@@ -1,0 +1,143 @@
+// common.hpp — host-side core types of libqhip: context, errors, device buffers, tables.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/qhip.h"
+
+namespace qhip {
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+// ---------------------------------------------------------------- errors
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] inline void fail(int code, const std::string& msg) { throw Error(code, msg); }
+
+#define QHIP_HIP_CHECK(expr)                                                                           \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      ::qhip::fail(_e == hipErrorOutOfMemory ? QHIP_OUT_OF_MEMORY : QHIP_HIP_ERROR,                    \
+                   std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+    }                                                                                                  \
+  } while (0)
+
+// ---------------------------------------------------------------- dtypes
+struct DType {
+  int id = QHIP_NULL;
+  int precision = 0;
+  int scale = 0;
+  DType() {}
+  DType(int i, int p = 0, int s = 0) : id(i), precision(p), scale(s) {}
+  DType(const qhip_dtype& d) : id(d.id), precision(d.precision), scale(d.scale) {}
+  bool operator==(const DType& o) const {
+    return id == o.id && (id != QHIP_DECIMAL128 || (precision == o.precision && scale == o.scale));
+  }
+  bool operator!=(const DType& o) const { return !(*this == o); }
+  qhip_dtype pod() const { qhip_dtype d; d.id = id; d.precision = precision; d.scale = scale; return d; }
+};
+std::string dtype_name(const DType& t);       // arrow-rs Display spelling: Int64, Decimal128(15, 2), Utf8 ...
+int dtype_width(const DType& t);              // bytes per value of a fixed-width type; 0 for Utf8/Bool/Null
+bool dtype_is_integer(const DType& t);
+bool dtype_is_signed(const DType& t);
+bool dtype_is_float(const DType& t);
+std::string dtype_to_format(const DType& t);  // Arrow C Data Interface format string
+DType dtype_from_format(const char* fmt);     // throws QHIP_UNSUPPORTED
+
+// ---------------------------------------------------------------- device memory
+struct Ctx;
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n);   // n == 0 still yields a valid (tiny) allocation so kernels never see nullptr
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+// One column of a device table, concatenated over all batches, Arrow layout.
+struct DevColumn {
+  DType type;
+  int64_t length = 0;
+  int64_t null_count = 0;
+  std::shared_ptr<DevBuf> values;    // fixed-width values | int32 offsets (length+1) | bit-packed booleans
+  std::shared_ptr<DevBuf> validity;  // bitmap, present iff null_count > 0
+  std::shared_ptr<DevBuf> data;      // utf8 bytes
+  int64_t data_bytes = 0;
+  int64_t resident_bytes() const;
+};
+
+}  // namespace qhip
+
+// C handle types
+struct qhip_table {
+  qhip::Ctx* ctx = nullptr;
+  std::vector<std::string> names;
+  std::vector<bool> nullable;             // schema-level nullability flag
+  std::vector<qhip::DevColumn> cols;
+  int64_t num_rows = 0;
+  std::vector<int64_t> batch_offsets;     // size = num_batches + 1; batch b = rows [off[b], off[b+1])
+  int64_t num_batches() const { return (int64_t)batch_offsets.size() - 1; }
+};
+
+namespace qhip {
+
+struct Module;  // jit.cpp
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string last_error;
+  std::string device_name;
+  int num_cus = 256;
+  qhip_exec_stats stats;
+  std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
+  DevBuf status;       // QS_WORDS u32 status words
+  std::string cache_dir;
+};
+
+// wraps a C entry point: runs f(), converts exceptions to status codes + last_error
+template <class F> int guarded(qhip_ctx* c, F&& f);
+
+}  // namespace qhip
+
+struct qhip_ctx : qhip::Ctx {};
+
+namespace qhip {
+void set_global_error(const std::string& m);
+template <class F> int guarded(qhip_ctx* c, F&& f) {
+  try {
+    f();
+    return QHIP_OK;
+  } catch (const Error& e) {
+    if (c) c->last_error = e.what(); else set_global_error(e.what());
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    if (c) c->last_error = "host allocation failed"; else set_global_error("host allocation failed");
+    return QHIP_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    if (c) c->last_error = e.what(); else set_global_error(e.what());
+    return QHIP_INVALID_ARGUMENT;
+  }
+}
+}  // namespace qhip

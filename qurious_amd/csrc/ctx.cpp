@@ -1,0 +1,198 @@
+// ctx.cpp — context lifecycle, dtype helpers, device buffers.
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+#include "common.hpp"
+#include "device/qhip_status.h"
+
+namespace qhip {
+
+static std::mutex g_err_mu;
+static std::string g_err;
+void set_global_error(const std::string& m) { std::lock_guard<std::mutex> l(g_err_mu); g_err = m; }
+
+std::string dtype_name(const DType& t) {
+  switch (t.id) {
+    case QHIP_NULL: return "Null";
+    case QHIP_BOOL: return "Boolean";
+    case QHIP_INT8: return "Int8";
+    case QHIP_INT16: return "Int16";
+    case QHIP_INT32: return "Int32";
+    case QHIP_INT64: return "Int64";
+    case QHIP_UINT8: return "UInt8";
+    case QHIP_UINT16: return "UInt16";
+    case QHIP_UINT32: return "UInt32";
+    case QHIP_UINT64: return "UInt64";
+    case QHIP_FLOAT32: return "Float32";
+    case QHIP_FLOAT64: return "Float64";
+    case QHIP_DATE32: return "Date32";
+    case QHIP_DATE64: return "Date64";
+    case QHIP_DECIMAL128: return "Decimal128(" + std::to_string(t.precision) + ", " + std::to_string(t.scale) + ")";
+    case QHIP_UTF8: return "Utf8";
+  }
+  return "Unknown(" + std::to_string(t.id) + ")";
+}
+
+int dtype_width(const DType& t) {
+  switch (t.id) {
+    case QHIP_INT8: case QHIP_UINT8: return 1;
+    case QHIP_INT16: case QHIP_UINT16: return 2;
+    case QHIP_INT32: case QHIP_UINT32: case QHIP_FLOAT32: case QHIP_DATE32: return 4;
+    case QHIP_INT64: case QHIP_UINT64: case QHIP_FLOAT64: case QHIP_DATE64: return 8;
+    case QHIP_DECIMAL128: return 16;
+    default: return 0;
+  }
+}
+bool dtype_is_integer(const DType& t) { return t.id >= QHIP_INT8 && t.id <= QHIP_UINT64; }
+bool dtype_is_signed(const DType& t) { return t.id >= QHIP_INT8 && t.id <= QHIP_INT64; }
+bool dtype_is_float(const DType& t) { return t.id == QHIP_FLOAT32 || t.id == QHIP_FLOAT64; }
+
+std::string dtype_to_format(const DType& t) {
+  switch (t.id) {
+    case QHIP_NULL: return "n";
+    case QHIP_BOOL: return "b";
+    case QHIP_INT8: return "c";
+    case QHIP_UINT8: return "C";
+    case QHIP_INT16: return "s";
+    case QHIP_UINT16: return "S";
+    case QHIP_INT32: return "i";
+    case QHIP_UINT32: return "I";
+    case QHIP_INT64: return "l";
+    case QHIP_UINT64: return "L";
+    case QHIP_FLOAT32: return "f";
+    case QHIP_FLOAT64: return "g";
+    case QHIP_DATE32: return "tdD";
+    case QHIP_DATE64: return "tdm";
+    case QHIP_DECIMAL128: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
+    case QHIP_UTF8: return "u";
+  }
+  fail(QHIP_UNSUPPORTED, "no Arrow format for " + dtype_name(t));
+}
+
+DType dtype_from_format(const char* f) {
+  std::string s(f ? f : "");
+  if (s == "n") return DType(QHIP_NULL);
+  if (s == "b") return DType(QHIP_BOOL);
+  if (s == "c") return DType(QHIP_INT8);
+  if (s == "C") return DType(QHIP_UINT8);
+  if (s == "s") return DType(QHIP_INT16);
+  if (s == "S") return DType(QHIP_UINT16);
+  if (s == "i") return DType(QHIP_INT32);
+  if (s == "I") return DType(QHIP_UINT32);
+  if (s == "l") return DType(QHIP_INT64);
+  if (s == "L") return DType(QHIP_UINT64);
+  if (s == "f") return DType(QHIP_FLOAT32);
+  if (s == "g") return DType(QHIP_FLOAT64);
+  if (s == "tdD") return DType(QHIP_DATE32);
+  if (s == "tdm") return DType(QHIP_DATE64);
+  if (s == "u") return DType(QHIP_UTF8);
+  if (s.rfind("d:", 0) == 0) {
+    int p = 0, sc = 0, bits = 128;
+    int n = sscanf(s.c_str(), "d:%d,%d,%d", &p, &sc, &bits);
+    if (n >= 2 && bits == 128) return DType(QHIP_DECIMAL128, p, sc);
+  }
+  fail(QHIP_UNSUPPORTED, "Arrow format '" + s + "' is not supported by the HIP backend");
+}
+
+void DevBuf::alloc(size_t n) {
+  release();
+  size_t m = n ? n : 16;
+  hipError_t e = hipMalloc(&ptr, m);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    fail(e == hipErrorOutOfMemory ? QHIP_OUT_OF_MEMORY : QHIP_HIP_ERROR,
+         "hipMalloc(" + std::to_string(m) + "): " + hipGetErrorString(e));
+  }
+  bytes = n;
+}
+void DevBuf::release() {
+  if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+}
+
+int64_t DevColumn::resident_bytes() const {
+  int64_t b = 0;
+  if (values) b += (int64_t)values->bytes;
+  if (validity) b += (int64_t)validity->bytes;
+  if (data) b += data_bytes;
+  return b;
+}
+
+}  // namespace qhip
+
+using namespace qhip;
+
+extern "C" {
+
+const char* qhip_version(void) { return "qhip 0.1.0 (gfx950)"; }
+
+int qhip_device_available(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  return (e == hipSuccess && n > 0) ? 1 : 0;
+}
+
+int qhip_ctx_create(int device_index, qhip_ctx** out) {
+  if (!out) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(nullptr, [&] {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+      fail(QHIP_HIP_ERROR, std::string("no HIP device visible (hipGetDeviceCount: ") + hipGetErrorString(e) +
+                               "); libqhip has no CPU fallback");
+    int dev = device_index;
+    if (dev < 0) QHIP_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= n) fail(QHIP_INVALID_ARGUMENT, "device index out of range");
+    QHIP_HIP_CHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    QHIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    std::string arch = prop.gcnArchName;
+    if (arch.rfind("gfx950", 0) != 0 && !getenv("QHIP_ALLOW_ANY_ARCH"))
+      fail(QHIP_HIP_ERROR, "device " + std::to_string(dev) + " is " + arch + ", libqhip kernels are written for gfx950 (MI355X)");
+    std::unique_ptr<qhip_ctx> c(new qhip_ctx());
+    c->device = dev;
+    c->device_name = std::string(prop.name) + " (" + arch + ")";
+    c->num_cus = prop.multiProcessorCount;
+    QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
+    c->status.alloc(QS_WORDS * sizeof(uint32_t));
+    memset(&c->stats, 0, sizeof(c->stats));
+    const char* cd = getenv("QHIP_KERNEL_CACHE");
+    c->cache_dir = cd ? cd : "";
+    *out = c.release();
+  });
+}
+
+void qhip_ctx_destroy(qhip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  ctx->modules.clear();
+  ctx->status.release();
+  for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* qhip_last_error(const qhip_ctx* ctx) {
+  if (ctx) return ctx->last_error.c_str();
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> l(g_err_mu);
+  copy = g_err;
+  return copy.c_str();
+}
+
+int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
+  if (!ctx || !out) return QHIP_INVALID_ARGUMENT;
+  *out = ctx->stats;
+  return QHIP_OK;
+}
+
+int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || !buflen) return QHIP_INVALID_ARGUMENT;
+  snprintf(buf, buflen, "%s", ctx->device_name.c_str());
+  return QHIP_OK;
+}
+
+}  // extern "C"

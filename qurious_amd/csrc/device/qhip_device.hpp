@@ -1,0 +1,451 @@
+// qhip_device.hpp — hand-written gfx950 (CDNA4, wave64) device code of the qurious-hip backend.
+//
+// Everything here is plan-independent: 128-bit decimal arithmetic, wavefront
+// ballot/DPP primitives, the two-level (LDS-staged + HBM) open-addressing group
+// table, and the kernel templates. A plan (predicate, key and aggregate-argument
+// expressions) enters as a small generated policy struct `P` that codegen.cpp
+// emits from the qhip_expr tree; the kernel bodies below are instantiated with it
+// by hiprtc at operator-execute time (and by hipcc at build time for the catalog
+// in kernels_aot.hip). No MFMA anywhere: this path is integer/hash/gather work
+// bounded by HBM bandwidth.
+//
+// The header is self-contained (no #include) so that hiprtc can compile it from a
+// string; hipcc builds include <hip/hip_runtime.h> before it.
+#pragma once
+
+typedef unsigned char u8;
+typedef unsigned short u16;
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef long long i64;
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+#define QH_MAXC 24   // distinct input columns one kernel may reference
+#define QH_MAXL 24   // literal slots
+#define QH_WAVE 64
+#define QH_BLOCK 256
+
+// One input column as the kernel sees it (Arrow layout, concatenated over batches).
+struct KCol {
+  const void* v;  // fixed-width values, or int32 offsets (n+1) for Utf8, or bit-packed values for Boolean
+  const u8* n;    // validity bitmap (LSB order) or nullptr
+  const u8* d;    // Utf8 data bytes
+};
+
+struct KArgs {
+  KCol c[QH_MAXC];
+  u64 lit_lo[QH_MAXL];   // integer / date / bool literals (sign-extended), f64 bit patterns, Decimal128 low half
+  i64 lit_hi[QH_MAXL];   // Decimal128 high half
+  const u8* strlit;      // concatenated Utf8 literals
+  int stroff[QH_MAXL + 1];
+  i64 nrows;
+};
+
+// status word indices (QS_*): qhip_status.h, prepended to this file when it is embedded for hiprtc
+
+// ------------------------------------------------------------------ scalar helpers
+__device__ __forceinline__ u64 qh_mix64(u64 x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+__device__ __forceinline__ bool qh_bit(const u8* bm, i64 i) { return (bm[i >> 3] >> (i & 7)) & 1; }
+__device__ __forceinline__ int qh_lane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ i128 qh_mk128(u64 lo, i64 hi) { return (i128)(((u128)(u64)hi << 64) | (u128)lo); }
+__device__ __forceinline__ double qh_f64(u64 bits) { return __longlong_as_double((i64)bits); }
+
+// f64 <-> u64 whose unsigned order is the IEEE total order (arrow's min/max kernels compare floats that way)
+__device__ __forceinline__ u64 qh_f64_ord(double d) { u64 b = (u64)__double_as_longlong(d); return (b >> 63) ? ~b : (b | 0x8000000000000000ULL); }
+__device__ __forceinline__ double qh_ord_f64(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k; return __longlong_as_double((i64)b); }
+
+// Utf8 value of at most 7 bytes packed injectively into one key word: byte 7 = length, bytes 0..len-1 = data.
+__device__ __forceinline__ u64 qh_pack_str7(const u8* p, int len, bool* too_long) {
+  if (len > 7) { *too_long = true; len = 7; }
+  u64 w = (u64)len << 56;
+  for (int k = 0; k < len; ++k) w |= (u64)p[k] << (8 * k);
+  return w;
+}
+// bytewise compare like arrow's Utf8 ordering: <0, 0, >0
+__device__ __forceinline__ int qh_strcmp(const u8* a, int la, const u8* b, int lb) {
+  int n = la < lb ? la : lb;
+  for (int k = 0; k < n; ++k) { int d = (int)a[k] - (int)b[k]; if (d) return d; }
+  return la - lb;
+}
+__device__ __forceinline__ bool qh_streq(const u8* a, int la, const u8* b, int lb) {
+  if (la != lb) return false;
+  for (int k = 0; k < la; ++k) if (a[k] != b[k]) return false;
+  return true;
+}
+__device__ __forceinline__ i128 qh_pow10(int e) { i128 r = 1; for (int k = 0; k < e; ++k) r *= 10; return r; }
+
+// ------------------------------------------------------------------ wavefront primitives (wave64)
+__device__ __forceinline__ u64 qh_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ u32 qh_readlane32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ u64 qh_readlane64(u64 v, int lane) {
+  return ((u64)qh_readlane32((u32)(v >> 32), lane) << 32) | qh_readlane32((u32)v, lane);
+}
+__device__ __forceinline__ i128 qh_readlane128(i128 v, int lane) {
+  u128 u = (u128)v;
+  return (i128)(((u128)qh_readlane64((u64)(u >> 64), lane) << 64) | qh_readlane64((u64)u, lane));
+}
+// number of set bits of `m` below this lane (the lane's rank inside a ballot mask)
+__device__ __forceinline__ int qh_rank(u64 m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+}
+
+// DPP lane moves: out-of-row / masked-off destinations read 0, so the moves compose to a sum reduction.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 qh_dpp0(u32 v) {
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ i128 qh_dpp128(i128 x) {
+  u128 u = (u128)x;
+  u32 a0 = qh_dpp0<CTRL, ROWMASK>((u32)u), a1 = qh_dpp0<CTRL, ROWMASK>((u32)(u >> 32));
+  u32 a2 = qh_dpp0<CTRL, ROWMASK>((u32)(u >> 64)), a3 = qh_dpp0<CTRL, ROWMASK>((u32)(u >> 96));
+  return (i128)(((u128)a3 << 96) | ((u128)a2 << 64) | ((u128)a1 << 32) | (u128)a0);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u64 qh_dpp64(u64 x) {
+  return ((u64)qh_dpp0<CTRL, ROWMASK>((u32)(x >> 32)) << 32) | qh_dpp0<CTRL, ROWMASK>((u32)x);
+}
+// Wrapping 128-bit sum over the 64 lanes; every lane must be active. Result is wave-uniform.
+// row_shr:1/2/4/8 build an inclusive scan inside each 16-lane row, row_bcast:15 / row_bcast:31
+// carry the row totals upward so that lane 63 holds the wave total.
+__device__ __forceinline__ i128 qh_wave_sum_i128(i128 x) {
+  x += qh_dpp128<0x111, 0xf>(x);
+  x += qh_dpp128<0x112, 0xf>(x);
+  x += qh_dpp128<0x114, 0xf>(x);
+  x += qh_dpp128<0x118, 0xf>(x);
+  x += qh_dpp128<0x142, 0xa>(x);
+  x += qh_dpp128<0x143, 0xc>(x);
+  return qh_readlane128(x, 63);
+}
+__device__ __forceinline__ u64 qh_wave_sum_u64(u64 x) {
+  x += qh_dpp64<0x111, 0xf>(x);
+  x += qh_dpp64<0x112, 0xf>(x);
+  x += qh_dpp64<0x114, 0xf>(x);
+  x += qh_dpp64<0x118, 0xf>(x);
+  x += qh_dpp64<0x142, 0xa>(x);
+  x += qh_dpp64<0x143, 0xc>(x);
+  return qh_readlane64(x, 63);
+}
+__device__ __forceinline__ u64 qh_shfl_xor64(u64 v, int m) {
+  u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double qh_wave_sum_f64(double x) {
+  for (int m = 32; m >= 1; m >>= 1) x += __longlong_as_double((i64)qh_shfl_xor64((u64)__double_as_longlong(x), m));
+  return x;
+}
+__device__ __forceinline__ u64 qh_wave_max_u64(u64 x) { for (int m = 32; m >= 1; m >>= 1) { u64 y = qh_shfl_xor64(x, m); x = y > x ? y : x; } return x; }
+__device__ __forceinline__ u128 qh_wave_max_u128(u128 x) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    u128 y = ((u128)qh_shfl_xor64((u64)(x >> 64), m) << 64) | qh_shfl_xor64((u64)x, m);
+    x = y > x ? y : x;
+  }
+  return x;
+}
+
+// ------------------------------------------------------------------ memory policies for the group table
+// LDS level: workgroup scope, DS atomics. HBM level: agent scope; the 8 XCD L2s are not coherent with
+// each other, so every access to the shared table is an 8-byte agent-scope atomic (sc1), never a plain
+// load/store (MI355X_MICROARCH "Valid forms": 8-B agent atomics on both sides).
+struct MemLds {
+  static constexpr int SCOPE = __HIP_MEMORY_SCOPE_WORKGROUP;
+};
+struct MemHbm {
+  static constexpr int SCOPE = __HIP_MEMORY_SCOPE_AGENT;
+};
+template <class M> __device__ __forceinline__ u64 qh_ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, M::SCOPE); }
+template <class M> __device__ __forceinline__ void qh_st64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, M::SCOPE); }
+template <class M> __device__ __forceinline__ u64 qh_fadd64(u64* p, u64 v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, M::SCOPE); }
+template <class M> __device__ __forceinline__ void qh_add64(u64* p, u64 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, M::SCOPE); }
+template <class M> __device__ __forceinline__ bool qh_cas64(u64* p, u64 expect, u64 desired) {
+  return __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, M::SCOPE);
+}
+// Exact wrapping 128-bit accumulate from two 64-bit atomics: the low-half fetch-add returns the old
+// value, so each adder sees precisely whether ITS add wrapped; the wraps are then added to the high half.
+// Addition commutes, so the final (hi:lo) equals the sum mod 2^128 whatever the interleaving.
+template <class M> __device__ __forceinline__ void qh_acc_add_i128(u64* cell, i128 v) {
+  u128 u = (u128)v; u64 lo = (u64)u, hi = (u64)(u >> 64);
+  if (lo) { u64 old = qh_fadd64<M>(cell, lo); hi += ((u64)(old + lo) < old) ? 1ULL : 0ULL; }
+  if (hi) qh_add64<M>(cell + 1, hi);
+}
+template <class M> __device__ __forceinline__ void qh_acc_add_u64(u64* cell, u64 v) { if (v) qh_add64<M>(cell, v); }
+template <class M> __device__ __forceinline__ void qh_acc_add_f64(u64* cell, double v) {
+  (void)__hip_atomic_fetch_add((double*)cell, v, __ATOMIC_RELAXED, M::SCOPE);
+}
+// MIN and MAX cells both store an order-preserving unsigned image of the value (MIN stores its complement),
+// so a zero-filled cell is the identity and one atomic max serves both (codegen.cpp ord64()).
+template <class M> __device__ __forceinline__ void qh_acc_max_u64(u64* cell, u64 v) { (void)__hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, M::SCOPE); }
+// 128-bit max has no hardware atomic: the cell carries a third word used as a spin lock. The loop body
+// completes the critical section before any lane retries, so lanes of one wave contending for the same
+// cell cannot deadlock. All accesses are atomics of the table's scope (HBM level: sc1, L2-coherent).
+template <class M> __device__ __forceinline__ void qh_acc_max_u128(u64* cell, u128 v) {
+  bool done = false;
+  while (!done) {
+    if (qh_cas64<M>(cell + 2, 0ULL, 1ULL)) {
+      const u128 cur = ((u128)qh_ld64<M>(cell + 1) << 64) | (u128)qh_ld64<M>(cell);
+      if (v > cur) { qh_st64<M>(cell, (u64)v); qh_st64<M>(cell + 1, (u64)(v >> 64)); }
+      if (M::SCOPE == __HIP_MEMORY_SCOPE_AGENT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+      qh_st64<M>(cell + 2, 0ULL);
+      done = true;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ open-addressing group table
+// Slot = [state][key words W][cells]. state: 0 empty, 1 being written, 2 ready. The claim/publish
+// protocol lets multi-word keys be inserted concurrently: the claimer writes the key words and only
+// then publishes state=2; everybody else compares key words only on ready slots. A lane never spins
+// inside an iteration, so lanes of one wave racing for one slot make progress.
+enum { QH_EMPTY = 0, QH_BUSY = 1, QH_READY = 2 };
+
+template <class M, int W>
+__device__ __forceinline__ u64* qh_find_or_insert(u64* table, u32 nslots /*pow2*/, int slot_words, const u64* key, u64 h,
+                                                   int max_probe, bool* inserted) {
+  u32 s = (u32)h & (nslots - 1);
+  int probes = 0;
+  *inserted = false;
+  while (probes < max_probe) {
+    u64* slot = table + (size_t)s * slot_words;
+    u64 st = qh_ld64<M>(slot);
+    if (st == QH_READY) {
+      bool eq = true;
+#pragma unroll
+      for (int w = 0; w < W; ++w) eq &= (qh_ld64<M>(slot + 1 + w) == key[w]);
+      if (eq) return slot;
+      s = (s + 1) & (nslots - 1); ++probes;
+    } else if (st == QH_EMPTY) {
+      if (qh_cas64<M>(slot, QH_EMPTY, QH_BUSY)) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) qh_st64<M>(slot + 1 + w, key[w]);
+        // key words must be visible before the slot reads as ready
+        if (M::SCOPE == __HIP_MEMORY_SCOPE_AGENT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+        qh_st64<M>(slot, QH_READY);
+        *inserted = true;
+        return slot;
+      }
+      // lost the claim: look at the same slot again
+    }
+    // QH_BUSY: the claimer is between claim and publish; retry the same slot
+  }
+  return nullptr;
+}
+
+// ------------------------------------------------------------------ fused filter + hash-aggregate kernel
+// Replaces MemoryTable::scan's predicate + filter_record_batch (datasource/memory.rs:90-93) and
+// HashAggregate::execute / GroupAccumulator::update (physical/plan/aggregate/hash.rs:45-87,138-170)
+// in ONE pass over the referenced columns: no mask array, no compacted batch, no concat copy, no
+// per-group take — each needed input byte is read once (SURVEY §8d algorithmic bytes).
+//
+// Policy P (generated):
+//   W            key words per group (0 = NoGroupingAggregate, aggregate/no_grouping.rs:30-62)
+//   R            rows per thread per tile (all loads of a tile are issued before any is consumed)
+//   SLOT_WORDS   u64 words per slot: 1 state + W key + cells
+//   struct Row   { bool pass; u64 key[W]; <per-argument value + validity> }
+//   struct Part  per-cell partial aggregate of one (thread, key)
+//   eval(a, i, row, status)             load row i, evaluate predicate/keys/arguments
+//   part_init(p) / part_add(p, row, m)  thread-local accumulate of rows with m == true
+//   part_reduce(p)                      wavefront reduction (all lanes active)
+//   (every cell's identity is all-zero bits, so a zero-filled table needs no per-slot initialisation)
+//   slot_update<M>(slot, p)             atomically merge a partial into a slot
+//   slot_merge(gslot, lslot)            merge an LDS slot into the HBM table slot
+//
+// Structure: persistent grid (a few workgroups per CU), grid-stride over tiles of 256*R rows.
+// Per tile each wave deduplicates its keys with ballot/readlane ("peeling"): rows of the wave that
+// share the leader's key are summed in registers and reduced across the wave with DPP, then ONE lane
+// updates the workgroup's LDS-staged table. This turns low-cardinality GROUP BYs (Q1: 4 groups) and
+// skewed keys into one LDS update per (wave, key) instead of 64 contended atomics. Rows left after
+// QH_MAX_PEELS peels (high-cardinality data: few duplicates inside a wave) update the table one lane
+// each, where contention is naturally low. Keys that do not fit the LDS table go straight to the
+// HBM table; at the end every workgroup merges its LDS table into the HBM table.
+#define QH_MAX_PEELS 8
+#define QH_LDS_MAX_PROBE 8
+#define QH_HBM_MAX_PROBE 128
+
+extern __shared__ __attribute__((aligned(16))) u8 qh_dyn_lds[];
+
+struct AggLaunch {
+  u64* gtable;      // HBM table, nslots * SLOT_WORDS words, zero-initialised
+  u32 g_nslots;     // power of two
+  u32 l_nslots;     // LDS slots per workgroup (power of two, 0 = no LDS level)
+  u32* status;      // QS_WORDS words
+};
+
+template <class P, class M>
+__device__ __forceinline__ void qh_apply(u64* table, u32 nslots, int max_probe, const u64* key, const typename P::Part& part,
+                                         u64*& slot_out) {
+  bool inserted;
+  u64 h = 0;
+#pragma unroll
+  for (int w = 0; w < P::W; ++w) h = qh_mix64(h ^ key[w]);
+  u64* slot = qh_find_or_insert<M, P::W>(table, nslots, P::SLOT_WORDS, key, h, max_probe, &inserted);
+  slot_out = slot;
+  if (slot) P::template slot_update<M>(slot, part);
+}
+
+template <class P>
+__device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L, const u64* key, const typename P::Part& part) {
+  u64* slot = nullptr;
+  if (L.l_nslots) qh_apply<P, MemLds>(ltable, L.l_nslots, QH_LDS_MAX_PROBE, key, part, slot);
+  if (!slot) {
+    qh_apply<P, MemHbm>(L.gtable, L.g_nslots, QH_HBM_MAX_PROBE, key, part, slot);
+    if (!slot) atomicOr(&L.status[QS_OVERFLOW], 1u);
+    else if (L.l_nslots) atomicOr(&L.status[QS_LDS_SPILL], 1u);
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L) {
+  constexpr int W = P::W;
+  constexpr int R = P::R;
+  u64* ltable = (u64*)qh_dyn_lds;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+
+  if (W > 0) {
+    // LDS table: zero = empty slots and identity cells
+    const u32 lwords = L.l_nslots * (u32)P::SLOT_WORDS;
+    for (u32 k = tid; k < lwords; k += QH_BLOCK) ltable[k] = 0;
+    __syncthreads();
+  }
+
+  typename P::Part acc;   // W == 0: whole-kernel per-thread accumulator
+  if (W == 0) P::part_init(acc);
+
+  const i64 tile_rows = (i64)QH_BLOCK * R;
+  const i64 ntiles = (a.nrows + tile_rows - 1) / tile_rows;
+  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    typename P::Row row[R];
+    const i64 base = t * tile_rows + tid;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i64 i = base + (i64)r * QH_BLOCK;
+      row[r].pass = false;
+      if (i < a.nrows) P::eval(a, i, row[r], L.status);
+    }
+    if (W == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) P::part_add(acc, row[r], row[r].pass);
+      continue;
+    }
+    // ---- wave-level key dedup
+    u64 act[R];
+    bool pend[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { pend[r] = row[r].pass; act[r] = qh_ballot(pend[r]); }
+    int peels = 0, singles = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < R; ++r0) {
+      while (act[r0] != 0 && peels < QH_MAX_PEELS && singles < 3) {
+        const int leader = __builtin_ctzll(act[r0]);
+        u64 lk[W > 0 ? W : 1];
+#pragma unroll
+        for (int w = 0; w < W; ++w) lk[w] = qh_readlane64(row[r0].key[w], leader);
+        // who else in this wave (this slice and later ones) carries the leader's key?
+        u64 msk[R];
+        int cnt = 0;
+#pragma unroll
+        for (int r = r0; r < R; ++r) {
+          bool m = pend[r];
+#pragma unroll
+          for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == lk[w]);
+          msk[r] = qh_ballot(m);
+          cnt += __builtin_popcountll(msk[r]);
+        }
+        if (cnt <= 1) {
+          // a key nobody shares: leave the row to the per-lane path (it stays pending)
+          act[r0] &= ~(1ULL << leader);
+          ++singles;
+          continue;
+        }
+        singles = 0;
+        typename P::Part part;
+        P::part_init(part);
+#pragma unroll
+        for (int r = r0; r < R; ++r) {
+          const bool m = (msk[r] >> lane) & 1;
+          P::part_add(part, row[r], m);
+          if (m) pend[r] = false;
+          act[r] &= ~msk[r];
+        }
+        P::part_reduce(part);   // all 64 lanes active: the tile loop and the peel loop are wave-uniform
+        if (lane == leader) qh_update_group<P>(ltable, L, lk, part);
+        ++peels;
+      }
+    }
+    // ---- rows not consumed by a peel: one lane per row
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (pend[r]) {
+        typename P::Part part;
+        P::part_init(part);
+        P::part_add(part, row[r], true);
+        qh_update_group<P>(ltable, L, row[r].key, part);
+      }
+    }
+  }
+
+  if (W == 0) {
+    P::part_reduce(acc);
+    if (lane == 0) P::template slot_update<MemHbm>(L.gtable, acc);
+    return;
+  }
+  // ---- merge this workgroup's LDS table into the HBM table
+  __syncthreads();
+  for (u32 s = tid; s < L.l_nslots; s += QH_BLOCK) {
+    u64* ls = ltable + (size_t)s * P::SLOT_WORDS;
+    if (ls[0] == QH_READY) {
+      u64 key[W > 0 ? W : 1];
+      u64 h = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { key[w] = ls[1 + w]; h = qh_mix64(h ^ key[w]); }
+      bool inserted;
+      u64* gs = qh_find_or_insert<MemHbm, W>(L.gtable, L.g_nslots, P::SLOT_WORDS, key, h, QH_HBM_MAX_PROBE, &inserted);
+      if (!gs) atomicOr(&L.status[QS_OVERFLOW], 1u);
+      else P::slot_merge(gs, ls);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ predicate -> selection mask kernel
+// Filter::execute (physical/plan/filter.rs:28-44): mask word j holds the keep bits of rows 64j..64j+63
+// (wavefront ballot), wave_count[j] their popcount; the exclusive scan of wave_count gives every
+// wavefront its output offset for the column compaction kernels (selection-vector compaction).
+template <class P>
+__device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32* wave_count, u32* status) {
+  const i64 nwords = (a.nrows + 63) / 64;
+  const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (i64 j = wave_global; j < nwords; j += nwaves) {
+    const i64 i = j * 64 + lane;
+    bool keep = false;
+    if (i < a.nrows) keep = P::pred(a, i, status);
+    u64 m = qh_ballot(keep);
+    if (lane == 0) { mask[j] = m; wave_count[j] = (u32)__builtin_popcountll(m); }
+  }
+}
+
+// ------------------------------------------------------------------ expression -> key words kernel (hash join keys, partition keys)
+// Evaluates the W key words of every row into word-major arrays keys[w * nrows + i]; keyvalid bit i is
+// set when every key column of the row is non-null (NULL keys never match, hash_join.rs:191-215).
+template <class P>
+__device__ __forceinline__ void qh_eval_keys_body(const KArgs& a, u64* keys, u64* keyvalid, u32* status) {
+  const i64 nwords = (a.nrows + 63) / 64;
+  const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (i64 j = wave_global; j < nwords; j += nwaves) {
+    const i64 i = j * 64 + lane;
+    bool ok = false;
+    if (i < a.nrows) {
+      u64 k[P::W];
+      ok = P::keys(a, i, k, status);
+#pragma unroll
+      for (int w = 0; w < P::W; ++w) keys[(size_t)w * a.nrows + i] = ok ? k[w] : 0;
+    }
+    u64 m = qh_ballot(ok);
+    if (lane == 0) keyvalid[j] = m;
+  }
+}

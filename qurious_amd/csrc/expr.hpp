@@ -1,0 +1,43 @@
+// expr.hpp — typed expression IR built from the qhip_expr POD tree, with the arrow-rs 53 type
+// rules the reference relies on (physical/expr/binary.rs:31-70, cast.rs:33-37).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace qhip {
+
+struct ENode {
+  int kind = 0, op = 0, column = -1, left = -1, right = -1;
+  DType type;
+  bool nullable = false;   // can evaluate to NULL for some row
+  // literal payload
+  bool lit_null = false;
+  uint64_t lo = 0;
+  int64_t hi = 0;
+  double f = 0;
+  std::string s;
+  DType cast_to;           // CAST target
+  std::string canon;       // structural identity (for common-subexpression sharing)
+};
+
+struct InputCol {
+  DType type;
+  bool has_nulls = false;  // null_count > 0 in the table actually being executed
+};
+
+struct ExprSet {
+  std::vector<ENode> nodes;
+  // Parses and types the POD tree against `input`. Literal casts are folded on the host (the reference
+  // re-materialises and re-casts N copies of the literal per batch, literal.rs:20-22 + cast.rs:33-37).
+  void build(const qhip_expr* exprs, int n, const std::vector<InputCol>& input);
+  const ENode& at(int k) const { return nodes.at((size_t)k); }
+};
+
+// host-side scalar cast with arrow's safe=false semantics; throws QHIP_EXEC_ERROR on overflow / parse failure
+void fold_literal_cast(const ENode& src, const DType& to, ENode& out);
+int32_t parse_date32(const std::string& s);   // "YYYY-MM-DD" -> days since epoch; throws QHIP_EXEC_ERROR
+i128 pow10_i128(int e);
+
+}  // namespace qhip

@@ -1,0 +1,36 @@
+// kargs_host.hpp — host mirrors of the kernel-argument structs declared in device/qhip_device.hpp.
+// Layouts must match byte for byte (both sides are LP64 with natural alignment); static_asserts below
+// pin the sizes the device header produces.
+#pragma once
+#include <cstdint>
+
+namespace qhip {
+
+constexpr int kMaxCols = 24;   // QH_MAXC
+constexpr int kMaxLits = 24;   // QH_MAXL
+
+struct HKCol {
+  const void* v;
+  const uint8_t* n;
+  const uint8_t* d;
+};
+struct HKArgs {
+  HKCol c[kMaxCols];
+  uint64_t lit_lo[kMaxLits];
+  int64_t lit_hi[kMaxLits];
+  const uint8_t* strlit;
+  int stroff[kMaxLits + 1];
+  int64_t nrows;
+};
+static_assert(sizeof(HKCol) == 24, "KCol layout");
+static_assert(sizeof(HKArgs) == 24 * 24 + 8 * 24 + 8 * 24 + 8 + 104 + 8, "KArgs layout");
+
+struct HAggLaunch {
+  uint64_t* gtable;
+  uint32_t g_nslots;
+  uint32_t l_nslots;
+  uint32_t* status;
+};
+static_assert(sizeof(HAggLaunch) == 24, "AggLaunch layout");
+
+}  // namespace qhip

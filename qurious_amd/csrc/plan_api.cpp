@@ -1,0 +1,63 @@
+// plan_api.cpp — plan-only entry points (no GPU needed): return the kernel source libqhip would
+// instantiate for a plan. __graft_entry__.build() uses them with qhip_jit_compile_to_cache to compile
+// the benchmark/test catalog for gfx950 ahead of time; CPU tests use them to check the host logic.
+#include <cstdio>
+#include <cstdlib>
+
+#include "codegen.hpp"
+#include "common.hpp"
+
+using namespace qhip;
+
+static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_nulls, int n) {
+  std::vector<InputCol> v;
+  for (int k = 0; k < n; ++k) { InputCol c; c.type = DType(t[k]); c.has_nulls = has_nulls && has_nulls[k]; v.push_back(c); }
+  return v;
+}
+static int give(const std::string& s, char* buf, size_t buflen, size_t* needed) {
+  if (needed) *needed = s.size() + 1;
+  if (buf && buflen) snprintf(buf, buflen, "%s", s.c_str());
+  return QHIP_OK;
+}
+static thread_local std::string g_plan_err;
+
+extern "C" {
+
+const char* qhip_plan_last_error(void) { return g_plan_err.c_str(); }
+
+int qhip_plan_aggregate_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                               int32_t n_exprs, int32_t predicate_root, const int32_t* group_roots, int32_t n_groups,
+                               const qhip_agg* aggs, int32_t n_aggs, char* buf, size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    AggPlan p;
+    const char* r = getenv("QHIP_AGG_R");
+    plan_aggregate(es, in, predicate_root, group_roots, n_groups, aggs, n_aggs, r && *r ? atoi(r) : 4, p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+int qhip_plan_filter_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                            int32_t n_exprs, int32_t predicate_root, char* buf, size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    MaskPlan p;
+    plan_predicate_mask(es, in, predicate_root, p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+int qhip_plan_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                          int32_t n_exprs, const int32_t* key_roots, int32_t n_keys, char* buf, size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    KeysPlan p;
+    plan_keys(es, in, key_roots, n_keys, p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+}  // extern "C"

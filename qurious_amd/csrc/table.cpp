@@ -1,0 +1,345 @@
+// table.cpp — qhip_table: Arrow C Data Interface <-> HBM-resident columns.
+//
+// A qhip_table stands for the Vec<RecordBatch> flowing between the reference's operators
+// (physical/plan/mod.rs:27). Upload concatenates the batches of each column into one device
+// buffer (what the reference does with concat_batches, aggregate/hash.rs:150, join/hash_join.rs:154,
+// happens here for free as part of the host->HBM copy) and remembers the batch boundaries.
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace qhip {
+
+static inline bool host_bit(const uint8_t* bm, int64_t i) { return (bm[i >> 3] >> (i & 7)) & 1; }
+static inline void host_set_bit(uint8_t* bm, int64_t i) { bm[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+
+// copy `n` bits from src starting at bit `src_off` to dst starting at bit `dst_off` (dst pre-zeroed there)
+static void copy_bits(const uint8_t* src, int64_t src_off, uint8_t* dst, int64_t dst_off, int64_t n) {
+  if (((src_off | dst_off) & 7) == 0) {
+    int64_t nb = n >> 3;
+    memcpy(dst + (dst_off >> 3), src + (src_off >> 3), (size_t)nb);
+    for (int64_t i = nb << 3; i < n; ++i) if (host_bit(src, src_off + i)) host_set_bit(dst, dst_off + i);
+    return;
+  }
+  for (int64_t i = 0; i < n; ++i) if (host_bit(src, src_off + i)) host_set_bit(dst, dst_off + i);
+}
+static void set_bits(uint8_t* dst, int64_t dst_off, int64_t n) {
+  int64_t i = 0;
+  while (i < n && ((dst_off + i) & 7)) { host_set_bit(dst, dst_off + i); ++i; }
+  int64_t nb = (n - i) >> 3;
+  memset(dst + ((dst_off + i) >> 3), 0xff, (size_t)nb);
+  i += nb << 3;
+  for (; i < n; ++i) host_set_bit(dst, dst_off + i);
+}
+static int64_t count_set_bits(const uint8_t* bm, int64_t off, int64_t n) {
+  int64_t c = 0;
+  int64_t i = 0;
+  while (i < n && ((off + i) & 7)) { c += host_bit(bm, off + i); ++i; }
+  for (; i + 8 <= n; i += 8) c += __builtin_popcount(bm[(off + i) >> 3]);
+  for (; i < n; ++i) c += host_bit(bm, off + i);
+  return c;
+}
+
+static void h2d(void* dst, const void* src, size_t n, hipStream_t s) {
+  if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
+}
+static void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
+  if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
+}
+
+qhip_table* table_from_arrow(Ctx* ctx, const ArrowSchema* schema, const ArrowArray* const* batches, int64_t nb) {
+  if (!schema || !schema->format || strcmp(schema->format, "+s") != 0)
+    fail(QHIP_INVALID_ARGUMENT, "qhip_table_from_arrow: schema must be a struct ('+s') describing a RecordBatch");
+  const int64_t nc = schema->n_children;
+  std::unique_ptr<qhip_table> t(new qhip_table());
+  t->ctx = ctx;
+  t->batch_offsets.push_back(0);
+  for (int64_t b = 0; b < nb; ++b) {
+    const ArrowArray* a = batches[b];
+    if (!a || a->n_children != nc) fail(QHIP_INVALID_ARGUMENT, "batch " + std::to_string(b) + " does not match the schema");
+    if (a->null_count > 0) fail(QHIP_UNSUPPORTED, "struct-level nulls in a RecordBatch are not supported");
+    t->batch_offsets.push_back(t->batch_offsets.back() + a->length);
+  }
+  const int64_t N = t->batch_offsets.back();
+  t->num_rows = N;
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  std::vector<std::vector<uint8_t>> staging;  // host staging kept alive until the stream is drained
+  for (int64_t c = 0; c < nc; ++c) {
+    const ArrowSchema* cs = schema->children[c];
+    DevColumn col;
+    col.type = dtype_from_format(cs->format);
+    col.length = N;
+    t->names.push_back(cs->name ? cs->name : "");
+    t->nullable.push_back((cs->flags & ARROW_FLAG_NULLABLE) != 0);
+    // null count + validity
+    int64_t nulls = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      if (ca->length != batches[b]->length) fail(QHIP_INVALID_ARGUMENT, "column length differs from its batch length");
+      if (col.type.id == QHIP_NULL) { nulls += ca->length; continue; }
+      const uint8_t* bm = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
+      if (bm && ca->null_count != 0) nulls += ca->length - count_set_bits(bm, ca->offset, ca->length);
+    }
+    col.null_count = nulls;
+    if (nulls > 0 && col.type.id != QHIP_NULL) {
+      staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
+      uint8_t* dst = staging.back().data();
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        const uint8_t* bm = (const uint8_t*)ca->buffers[0];
+        if (bm && ca->null_count != 0) copy_bits(bm, ca->offset, dst, t->batch_offsets[b], ca->length);
+        else set_bits(dst, t->batch_offsets[b], ca->length);
+      }
+      col.validity = std::make_shared<DevBuf>((size_t)((N + 7) / 8 + 8));
+      h2d(col.validity->ptr, dst, col.validity->bytes, ctx->stream);
+    }
+    const int w = dtype_width(col.type);
+    if (w > 0) {
+      col.values = std::make_shared<DevBuf>((size_t)N * w);
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        if (ca->length == 0) continue;
+        if (ca->n_buffers < 2 || !ca->buffers[1]) fail(QHIP_INVALID_ARGUMENT, "missing values buffer");
+        h2d((uint8_t*)col.values->ptr + (size_t)t->batch_offsets[b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
+            (size_t)ca->length * w, ctx->stream);
+      }
+    } else if (col.type.id == QHIP_BOOL) {
+      staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
+      uint8_t* dst = staging.back().data();
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        if (ca->length) copy_bits((const uint8_t*)ca->buffers[1], ca->offset, dst, t->batch_offsets[b], ca->length);
+      }
+      col.values = std::make_shared<DevBuf>(staging.back().size());
+      h2d(col.values->ptr, dst, col.values->bytes, ctx->stream);
+    } else if (col.type.id == QHIP_UTF8) {
+      // rebase the int32 offsets of every batch onto the concatenated data buffer
+      staging.emplace_back((size_t)(N + 1) * 4, 0);
+      int32_t* off = (int32_t*)staging.back().data();
+      int64_t total = 0;
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        if (ca->length == 0) continue;
+        const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+        total += (int64_t)so[ca->length] - so[0];
+      }
+      if (total > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB (needs LargeUtf8 offsets)");
+      col.data = std::make_shared<DevBuf>((size_t)total);
+      col.data_bytes = total;
+      int64_t pos = 0;
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        if (ca->length == 0) continue;
+        const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+        const int32_t base = so[0];
+        int32_t* d = off + t->batch_offsets[b];
+        const int32_t shift = (int32_t)pos - base;
+        for (int64_t i = 0; i < ca->length; ++i) d[i] = so[i] + shift;
+        const int64_t nbytes = (int64_t)so[ca->length] - base;
+        h2d((uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes, ctx->stream);
+        pos += nbytes;
+      }
+      off[N] = (int32_t)total;
+      col.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
+      h2d(col.values->ptr, off, col.values->bytes, ctx->stream);
+    } else if (col.type.id == QHIP_NULL) {
+      col.null_count = N;
+    }
+    t->cols.push_back(std::move(col));
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return t.release();
+}
+
+// ---------------------------------------------------------------- download
+struct HostArrayPrivate {
+  std::vector<void*> buffers;       // malloc'ed
+  std::vector<const void*> buffer_ptrs;
+  std::vector<ArrowArray*> children;
+  std::vector<ArrowArray> child_storage;
+};
+static void release_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  HostArrayPrivate* p = (HostArrayPrivate*)a->private_data;
+  if (p) {
+    for (auto& ch : p->child_storage) if (ch.release) ch.release(&ch);
+    for (void* b : p->buffers) free(b);
+    delete p;
+  }
+  a->release = nullptr;
+}
+struct HostSchemaPrivate {
+  std::string format, name;
+  std::vector<ArrowSchema*> children;
+  std::vector<ArrowSchema> child_storage;
+};
+static void release_schema(ArrowSchema* s) {
+  if (!s || !s->release) return;
+  HostSchemaPrivate* p = (HostSchemaPrivate*)s->private_data;
+  if (p) {
+    for (auto& ch : p->child_storage) if (ch.release) ch.release(&ch);
+    delete p;
+  }
+  s->release = nullptr;
+}
+static void fill_schema(ArrowSchema* s, const std::string& fmt, const std::string& name, bool nullable, size_t nchildren) {
+  HostSchemaPrivate* p = new HostSchemaPrivate();
+  p->format = fmt; p->name = name;
+  p->child_storage.resize(nchildren);
+  for (auto& c : p->child_storage) { memset(&c, 0, sizeof(c)); p->children.push_back(&c); }
+  memset(s, 0, sizeof(*s));
+  s->format = p->format.c_str();
+  s->name = p->name.c_str();
+  s->metadata = nullptr;
+  s->flags = nullable ? ARROW_FLAG_NULLABLE : 0;
+  s->n_children = (int64_t)nchildren;
+  s->children = nchildren ? p->children.data() : nullptr;
+  s->release = release_schema;
+  s->private_data = p;
+}
+
+void table_schema_to_arrow(const qhip_table* t, ArrowSchema* out) {
+  fill_schema(out, "+s", "", false, t->cols.size());
+  for (size_t c = 0; c < t->cols.size(); ++c)
+    fill_schema(out->children[c], dtype_to_format(t->cols[c].type), t->names[c], t->nullable[c], 0);
+}
+
+static void* xmalloc(size_t n) {
+  void* p = nullptr;
+  if (posix_memalign(&p, 64, n ? ((n + 63) / 64) * 64 : 64) != 0) throw std::bad_alloc();
+  memset(p, 0, n ? ((n + 63) / 64) * 64 : 64);
+  return p;
+}
+
+void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* out) {
+  if (b < 0 || b >= t->num_batches()) fail(QHIP_INVALID_ARGUMENT, "batch index out of range");
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  const int64_t r0 = t->batch_offsets[b], r1 = t->batch_offsets[b + 1], n = r1 - r0;
+  std::unique_ptr<HostArrayPrivate> top(new HostArrayPrivate());
+  top->child_storage.resize(t->cols.size());
+  for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
+  struct Pending { uint8_t* raw; uint8_t* dst; int64_t bit_off; int64_t nbits; };
+  std::vector<Pending> bitfix;                       // bitmaps to realign after the copies land
+  struct OffFix { int32_t* off; int64_t n; };
+  std::vector<OffFix> offfix;
+  std::vector<std::pair<ArrowArray*, uint8_t*>> nullfix;
+  for (size_t c = 0; c < t->cols.size(); ++c) {
+    const DevColumn& col = t->cols[c];
+    ArrowArray* ca = &top->child_storage[c];
+    HostArrayPrivate* p = new HostArrayPrivate();
+    ca->private_data = p;
+    ca->release = release_array;
+    ca->length = n;
+    ca->offset = 0;
+    ca->null_count = 0;
+    uint8_t* validity = nullptr;
+    auto fetch_bits = [&](const DevBuf& src) -> uint8_t* {
+      uint8_t* dst = (uint8_t*)xmalloc((size_t)((n + 7) / 8));
+      if (n == 0) return dst;
+      const int64_t byte0 = r0 >> 3, byte1 = (r1 + 7) >> 3;
+      if ((r0 & 7) == 0) {
+        d2h(dst, (const uint8_t*)src.ptr + byte0, (size_t)((n + 7) / 8), ctx->stream);
+      } else {
+        uint8_t* raw = (uint8_t*)xmalloc((size_t)(byte1 - byte0));
+        d2h(raw, (const uint8_t*)src.ptr + byte0, (size_t)(byte1 - byte0), ctx->stream);
+        bitfix.push_back({raw, dst, r0 & 7, n});
+      }
+      return dst;
+    };
+    if (col.type.id == QHIP_NULL) {
+      ca->null_count = n;
+      ca->n_buffers = 0;
+      ca->buffers = nullptr;
+      top->children.push_back(ca);
+      continue;
+    }
+    if (col.validity && col.null_count > 0) {
+      validity = fetch_bits(*col.validity);
+      nullfix.push_back({ca, validity});
+    }
+    p->buffers.push_back(validity);
+    const int w = dtype_width(col.type);
+    if (w > 0) {
+      uint8_t* v = (uint8_t*)xmalloc((size_t)n * w);
+      d2h(v, (const uint8_t*)col.values->ptr + (size_t)r0 * w, (size_t)n * w, ctx->stream);
+      p->buffers.push_back(v);
+    } else if (col.type.id == QHIP_BOOL) {
+      p->buffers.push_back(fetch_bits(*col.values));
+    } else if (col.type.id == QHIP_UTF8) {
+      int32_t* off = (int32_t*)xmalloc((size_t)(n + 1) * 4);
+      d2h(off, (const int32_t*)col.values->ptr + r0, (size_t)(n + 1) * 4, ctx->stream);
+      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // need the offsets to size the data slice
+      const int32_t base = off[0];
+      const int64_t nbytes = (int64_t)off[n] - base;
+      uint8_t* data = (uint8_t*)xmalloc((size_t)nbytes);
+      d2h(data, (const uint8_t*)col.data->ptr + base, (size_t)nbytes, ctx->stream);
+      if (base) offfix.push_back({off, n + 1});
+      p->buffers.push_back(off);
+      p->buffers.push_back(data);
+    }
+    for (void* bp : p->buffers) p->buffer_ptrs.push_back(bp);
+    ca->n_buffers = (int64_t)p->buffer_ptrs.size();
+    ca->buffers = p->buffer_ptrs.data();
+    top->children.push_back(ca);
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (auto& f : bitfix) { copy_bits(f.raw, f.bit_off, f.dst, 0, f.nbits); free(f.raw); }
+  for (auto& f : offfix) { const int32_t base = f.off[0]; for (int64_t i = 0; i < f.n; ++i) f.off[i] -= base; }
+  for (auto& nf : nullfix) nf.first->null_count = n - count_set_bits(nf.second, 0, n);
+  memset(out, 0, sizeof(*out));
+  out->length = n;
+  out->null_count = 0;
+  out->offset = 0;
+  top->buffers.push_back(nullptr);
+  top->buffer_ptrs.push_back(nullptr);
+  out->n_buffers = 1;
+  out->buffers = top->buffer_ptrs.data();
+  out->n_children = (int64_t)top->children.size();
+  out->children = top->children.empty() ? nullptr : top->children.data();
+  out->release = release_array;
+  out->private_data = top.release();
+}
+
+}  // namespace qhip
+
+using namespace qhip;
+namespace qhip {
+qhip_table* table_from_arrow(Ctx*, const ArrowSchema*, const ArrowArray* const*, int64_t);
+void table_batch_to_arrow(Ctx*, const qhip_table*, int64_t, ArrowArray*);
+void table_schema_to_arrow(const qhip_table*, ArrowSchema*);
+}
+
+extern "C" {
+
+int qhip_table_from_arrow(qhip_ctx* ctx, const struct ArrowSchema* schema, const struct ArrowArray* const* batches,
+                          int64_t n_batches, qhip_table** out) {
+  if (!ctx || !out || n_batches < 0 || (n_batches > 0 && !batches)) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = table_from_arrow(ctx, schema, batches, n_batches); });
+}
+
+int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index, struct ArrowArray* out_array,
+                        struct ArrowSchema* out_schema) {
+  if (!ctx || !t) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] {
+    if (out_array) table_batch_to_arrow(ctx, t, batch_index, out_array);
+    if (out_schema) table_schema_to_arrow(t, out_schema);
+  });
+}
+
+int64_t qhip_table_num_batches(const qhip_table* t) { return t ? t->num_batches() : -1; }
+int64_t qhip_table_num_rows(const qhip_table* t) { return t ? t->num_rows : -1; }
+int64_t qhip_table_num_columns(const qhip_table* t) { return t ? (int64_t)t->cols.size() : -1; }
+int64_t qhip_table_column_bytes(const qhip_table* t, int64_t col) {
+  if (!t || col < 0 || col >= (int64_t)t->cols.size()) return -1;
+  return t->cols[(size_t)col].resident_bytes();
+}
+void qhip_table_destroy(qhip_table* t) {
+  if (!t) return;
+  if (t->ctx) (void)hipSetDevice(t->ctx->device);
+  delete t;
+}
+
+}  // extern "C"

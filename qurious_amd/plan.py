@@ -1,0 +1,295 @@
+"""PhysicalPlan mirrors — the host side of the drop-in boundary.
+
+Same node names, constructor arguments and error behaviour as the reference's operators
+(physical/plan/{scan,filter}.rs, aggregate/{hash,no_grouping}.rs, join/hash_join.rs and
+datasource/memory.rs), so a parity test reads like the reference's own test. ``execute()`` returns
+``list[pyarrow.RecordBatch]`` exactly like ``PhysicalPlan::execute() -> Result<Vec<RecordBatch>>``
+(physical/plan/mod.rs:25-29). All compute happens in libqhip's HIP kernels; between two HIP nodes the
+batches stay in HBM (``execute_device``) and only the root's result is downloaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import pyarrow as pa
+
+from . import _ffi
+from ._ffi import DeviceTable, get_context
+from .datatypes import JoinSide, JoinType
+from .expr import AggregateExpr, ExprArray, PhysicalExpr, int32_array
+
+FIELD_QUALIFIERS_META_KEY = "qurious.field_qualifiers"   # common/table_schema.rs:18
+
+
+class PhysicalPlan:
+    """trait PhysicalPlan (physical/plan/mod.rs:25-29)."""
+
+    def schema(self) -> pa.Schema:
+        raise NotImplementedError
+
+    def execute(self) -> List[pa.RecordBatch]:
+        t = self.execute_device()
+        batches = t.to_batches()
+        sch = self.schema()
+        # re-attach names/metadata the C side is agnostic of (SURVEY §8b "Data contract")
+        return [_with_schema(b, sch) for b in batches]
+
+    def execute_device(self) -> DeviceTable:
+        raise NotImplementedError
+
+    def children(self) -> Optional[List["PhysicalPlan"]]:
+        return None
+
+
+def _with_schema(batch: pa.RecordBatch, schema: Optional[pa.Schema]) -> pa.RecordBatch:
+    if schema is None or len(schema) != batch.num_columns:
+        return batch
+    fields = []
+    for k, f in enumerate(schema):
+        got = batch.schema.field(k)
+        if got.type != f.type:
+            raise _ffi.InternalError(_ffi.QHIP_INVALID_ARGUMENT,
+                                     f"column {k} ('{f.name}') has type {got.type} but the plan schema says {f.type}")
+        fields.append(pa.field(f.name, f.type, nullable=True if batch.column(k).null_count else f.nullable, metadata=f.metadata))
+    return pa.RecordBatch.from_arrays(batch.columns, schema=pa.schema(fields, metadata=schema.metadata))
+
+
+class MemoryTable:
+    """datasource/memory.rs:20-98 — also the universal fixture source of the reference's tests."""
+
+    def __init__(self, schema: pa.Schema, data: Sequence[pa.RecordBatch]):
+        self._schema = schema
+        self.data = list(data)
+        self._device: Optional[DeviceTable] = None
+
+    @staticmethod
+    def try_new(schema: pa.Schema, data: Sequence[pa.RecordBatch]) -> "MemoryTable":
+        return MemoryTable(schema, data)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def device_table(self) -> DeviceTable:
+        """Batches pinned in HBM (uploaded once; the reference keeps them in host memory behind an RwLock)."""
+        if self._device is None:
+            self._device = DeviceTable.from_batches(get_context(), self._schema, self.data)
+        return self._device
+
+    def scan(self, projection: Optional[List[str]], filters: Optional[PhysicalExpr]) -> List[pa.RecordBatch]:
+        """TableProvider::scan (memory.rs:69-98)."""
+        return Scan(self._schema, self, projection, filters).execute()
+
+
+class Scan(PhysicalPlan):
+    """physical/plan/scan.rs:12-47"""
+
+    def __init__(self, schema: pa.Schema, datasource: MemoryTable, projections: Optional[List[str]] = None,
+                 filter: Optional[PhysicalExpr] = None):
+        self._schema, self.datasource, self.projections, self.filter = schema, datasource, projections, filter
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def _projection_indices(self) -> Optional[List[int]]:
+        if self.projections is None:
+            return None
+        src = self.datasource.schema()
+        idx = []
+        for name in self.projections:
+            k = src.get_field_index(name)
+            if k < 0:
+                raise _ffi.ArrowError(_ffi.QHIP_INVALID_ARGUMENT, f"Schema error: Unable to get field named \"{name}\"")
+            idx.append(k)
+        return idx
+
+    def execute_device(self) -> DeviceTable:
+        base = self.datasource.device_table()
+        proj = self._projection_indices()
+        if self.filter is None and proj is None:
+            return base
+        return _filter_device(base, self.filter, proj)
+
+    def execute(self) -> List[pa.RecordBatch]:
+        if self.filter is None and self.projections is None:
+            return list(self.datasource.data)   # scan.rs:40-42 without filter: the stored batches themselves
+        return super().execute()
+
+
+def _filter_device(table: DeviceTable, predicate: Optional[PhysicalExpr], projection: Optional[List[int]]) -> DeviceTable:
+    ctx = table.ctx
+    ea = ExprArray()
+    root = -1
+    if predicate is not None:
+        if projection is not None:
+            # memory.rs:79-93: the projection is applied first, the filter then sees the projected batch
+            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "scan with both projection and filter is not used by the planner")
+        root = ea.lower(predicate)
+    arr, n = ea.c_array()
+    out = C.c_void_p()
+    pj = int32_array(projection or [])
+    ctx.check(ctx.lib.qhip_filter_execute(ctx.handle, table.handle, arr, n, root, pj if projection is not None else None,
+                                          len(projection) if projection is not None else -1, C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+class Filter(PhysicalPlan):
+    """physical/plan/filter.rs:12-48"""
+
+    def __init__(self, input: PhysicalPlan, predicate: PhysicalExpr):
+        self.input, self.predicate = input, predicate
+
+    def schema(self) -> pa.Schema:
+        return self.input.schema()
+
+    def execute_device(self) -> DeviceTable:
+        return _filter_device(self.input.execute_device(), self.predicate, None)
+
+    def children(self):
+        return [self.input]
+
+
+def _aggregate_device(table: DeviceTable, predicate: Optional[PhysicalExpr], group_exprs: Sequence[PhysicalExpr],
+                      aggregate_exprs: Sequence[AggregateExpr], names: Sequence[str]) -> DeviceTable:
+    ctx = table.ctx
+    ea = ExprArray()
+    pred = ea.lower(predicate) if predicate is not None else -1
+    groups = [ea.lower(g) for g in group_exprs]
+    aggs = (_ffi.qhip_agg * max(1, len(aggregate_exprs)))()
+    from .datatypes import to_qhip_dtype
+    for k, a in enumerate(aggregate_exprs):
+        aggs[k].kind = a.kind
+        aggs[k].expr = ea.lower(a.expression())
+        aggs[k].return_type = to_qhip_dtype(a._return_type())
+    arr, n = ea.c_array()
+    cnames = (C.c_char_p * max(1, len(names)))(*[s.encode() for s in names])
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_hash_aggregate_execute(ctx.handle, table.handle, arr, n, pred, int32_array(groups), len(groups), aggs,
+                                                  len(aggregate_exprs), cnames, C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+class HashAggregate(PhysicalPlan):
+    """physical/plan/aggregate/hash.rs:110-176. When the input is a Scan with a pushed-down filter
+    (the shape PushdownFilter produces for Q1) the predicate is fused into the aggregation
+    kernel: one pass over the referenced columns, nothing materialised in between."""
+
+    def __init__(self, schema: pa.Schema, input: PhysicalPlan, group_exprs: Sequence[PhysicalExpr],
+                 aggregate_exprs: Sequence[AggregateExpr]):
+        self._schema, self.input = schema, input
+        self.group_exprs, self.aggregate_exprs = list(group_exprs), list(aggregate_exprs)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def _source(self) -> Tuple[DeviceTable, Optional[PhysicalExpr]]:
+        node = self.input
+        if isinstance(node, Scan) and node.projections is None:
+            return node.datasource.device_table(), node.filter
+        if isinstance(node, Filter) and isinstance(node.input, Scan) and node.input.filter is None and node.input.projections is None:
+            return node.input.datasource.device_table(), node.predicate
+        return node.execute_device(), None
+
+    def execute_device(self) -> DeviceTable:
+        table, pred = self._source()
+        names = [f.name for f in self._schema] if self._schema is not None else \
+            [f"c{k}" for k in range(len(self.group_exprs) + len(self.aggregate_exprs))]
+        return _aggregate_device(table, pred, self.group_exprs, self.aggregate_exprs, names)
+
+    def children(self):
+        return [self.input]
+
+    def __str__(self):
+        return f"HashAggregateExec: groupExpr={[str(g) for g in self.group_exprs]}, aggrExpr={[str(a) for a in self.aggregate_exprs]}"
+
+
+class NoGroupingAggregate(HashAggregate):
+    """physical/plan/aggregate/no_grouping.rs:9-66"""
+
+    def __init__(self, schema: pa.Schema, input: PhysicalPlan, aggr_expr: Sequence[AggregateExpr]):
+        super().__init__(schema, input, [], aggr_expr)
+
+    def children(self):
+        return None   # no_grouping.rs:63-65
+
+
+ColumnIndex = Tuple[int, JoinSide]
+
+
+class JoinFilter:
+    """physical/plan/join/mod.rs JoinFilter { expr, schema, column_indices }"""
+
+    def __init__(self, expr: PhysicalExpr, column_indices: Sequence[ColumnIndex], schema: pa.Schema):
+        self.expr, self.column_indices, self.schema = expr, list(column_indices), schema
+
+
+def build_join_schema(left: pa.Schema, right: pa.Schema, join_type: JoinType) -> Tuple[pa.Schema, List[ColumnIndex]]:
+    """physical/plan/join/mod.rs:26-123 (field nullability by join type, merged qualifier metadata)."""
+    sep = "\x1f"
+    key = FIELD_QUALIFIERS_META_KEY.encode()
+    lmeta = dict(left.metadata or {})
+    if join_type in (JoinType.LeftSemi, JoinType.LeftAnti):
+        fields = [f for f in left]
+        return pa.schema(fields, metadata=lmeta or None), [(k, JoinSide.Left) for k in range(len(left))]
+    ln, rn = {JoinType.Left: (False, True), JoinType.Right: (True, False), JoinType.Inner: (False, False),
+              JoinType.Full: (True, True)}[join_type]
+    fields, idx = [], []
+    for k, f in enumerate(left):
+        fields.append(f.with_nullable(True) if ln else f)
+        idx.append((k, JoinSide.Left))
+    for k, f in enumerate(right):
+        fields.append(f.with_nullable(True) if rn else f)
+        idx.append((k, JoinSide.Right))
+
+    def parts(s: pa.Schema):
+        q = (s.metadata or {}).get(key)
+        q = q.decode() if q is not None else sep * max(0, len(s) - 1)
+        p = q.split(sep)
+        return p if len(p) == len(s) else [""] * len(s)
+
+    meta = dict(lmeta)
+    meta[key] = sep.join(parts(left) + parts(right)).encode()
+    return pa.schema(fields, metadata=meta), idx
+
+
+class HashJoinExec(PhysicalPlan):
+    """physical/plan/join/hash_join.rs:110-384 — build = left, probe = right."""
+
+    def __init__(self, left, right, join_type, on, filter, schema, column_indices):
+        self.left, self.right, self.join_type, self.on, self.filter = left, right, JoinType(join_type), list(on), filter
+        self._schema, self.column_indices = schema, column_indices
+
+    @staticmethod
+    def try_new(left: PhysicalPlan, right: PhysicalPlan, join_type: JoinType,
+                on: Sequence[Tuple[PhysicalExpr, PhysicalExpr]], filter: Optional[JoinFilter] = None) -> "HashJoinExec":
+        if len(on) == 0:
+            raise _ffi.InternalError(_ffi.QHIP_INVALID_ARGUMENT, "Internal error: On constraints in HashJoinExec should be non-empty")
+        schema, ci = build_join_schema(left.schema(), right.schema(), JoinType(join_type))
+        return HashJoinExec(left, right, join_type, on, filter, schema, ci)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def children(self):
+        return [self.left, self.right]
+
+    def execute_device(self) -> DeviceTable:
+        lt = self.left.execute_device()
+        rt = self.right.execute_device()
+        ctx = lt.ctx
+        le, re_, fe = ExprArray(), ExprArray(), ExprArray()
+        on_l = [le.lower(l) for l, _ in self.on]
+        on_r = [re_.lower(r) for _, r in self.on]
+        froot, fsides, fcols = -1, [], []
+        if self.filter is not None:
+            froot = fe.lower(self.filter.expr)
+            fsides = [int(s) for _, s in self.filter.column_indices]
+            fcols = [int(c) for c, _ in self.filter.column_indices]
+        la, ln = le.c_array()
+        ra, rn = re_.c_array()
+        fa, fn = fe.c_array()
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_hash_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), la, ln, ra, rn,
+                                                 int32_array(on_l), int32_array(on_r), len(self.on), fa, fn, froot,
+                                                 int32_array(fsides), int32_array(fcols), len(fcols), C.byref(out)))
+        return DeviceTable(ctx, out)
