@@ -1,0 +1,130 @@
+"""GPU parity: fused filter + hash-aggregate HIP kernel vs the CPU oracle, through the C ABI (bit-exact)."""
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import qurious_amd as q
+from qurious_amd import Operator, queries, synth
+from qurious_amd import ScalarValue as S
+
+from .helpers import col, lit_i64, rows_of, sorted_rows, table_scan
+
+pytestmark = pytest.mark.gpu
+I64 = pa.int64()
+
+
+def _same(plan, oracle):
+    got = sorted_rows(plan.execute())
+    want = sorted_rows(oracle.execute(plan))
+    assert got == want
+    return got
+
+
+def test_q1_mini_config0_matches_oracle(ctx, oracle):
+    """configs[0]: 1M-row synthetic batch, l_shipdate < 1998-09-01 GROUP BY l_returnflag, SUM(l_quantity) — bit-exact."""
+    table = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, synth.lineitem(1_000_000, 1_000_000))
+    plan = queries.q1_mini(table)
+    got = _same(plan, oracle)
+    assert len(got) == 3
+    out = plan.execute()
+    assert out[0].schema.field(1).type == pa.decimal128(15, 2)
+    st = ctx.last_stats()
+    assert st["main_kernel_name"] == "qk_filter_agg" and st["rows_in"] == 1_000_000
+
+
+def test_q1_full_matches_oracle(ctx, oracle):
+    """TPC-H Q1 aggregate list on 300k synthetic rows in 1024-row batches (the reference's COPY batch size)."""
+    table = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, synth.lineitem(300_000, 1024))
+    plan = queries.q1_full(table)
+    got = _same(plan, oracle)
+    assert len(got) == 4
+    out = plan.execute()[0]
+    assert [f.type for f in out.schema][2:] == [pa.decimal128(15, 2), pa.decimal128(15, 2), pa.decimal128(38, 4), pa.decimal128(38, 6),
+                                                 pa.decimal128(19, 6), pa.decimal128(19, 6), pa.decimal128(19, 6), pa.int64()]
+
+
+def test_group_by_int64_with_nulls_and_expr_keys(ctx, oracle):
+    rng = np.random.default_rng(3)
+    n = 20000
+    k = rng.integers(0, 37, n)
+    v = rng.integers(-10**12, 10**12, n)
+    kmask = rng.random(n) < 0.1
+    vmask = rng.random(n) < 0.1
+    schema = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+    batch = pa.RecordBatch.from_arrays([pa.array(k, type=I64, mask=kmask), pa.array(v, type=I64, mask=vmask)], schema=schema)
+    scan = table_scan(schema, [batch.slice(0, 7000), batch.slice(7000, 13000)])
+    key = q.BinaryExpr(col("k", 0), Operator.Add, lit_i64(1))
+    aggs = [q.SumAggregateExpr(col("v", 1), I64), q.CountAggregateExpr(col("v", 1)), q.CountAggregateExpr(lit_i64(1)),
+            q.MinAggregateExpr(col("v", 1), I64), q.MaxAggregateExpr(col("v", 1), I64)]
+    _same(q.HashAggregate(None, scan, [key], aggs), oracle)
+    pred = q.BinaryExpr(col("v", 1), Operator.Gt, lit_i64(0))
+    _same(q.HashAggregate(None, q.Filter(scan, pred), [col("k", 0)], aggs), oracle)
+
+
+def test_high_cardinality_group_by(ctx, oracle):
+    """more groups than the LDS-staged table holds: keys spill to the HBM table, table growth retry path"""
+    rng = np.random.default_rng(5)
+    n = 400_000
+    k = rng.integers(0, 150_000, n)
+    v = rng.integers(0, 1000, n)
+    schema = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+    scan = table_scan(schema, [pa.RecordBatch.from_arrays([pa.array(k, type=I64), pa.array(v, type=I64)], schema=schema)])
+    plan = q.HashAggregate(None, scan, [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64), q.CountAggregateExpr(lit_i64(1))])
+    got = _same(plan, oracle)
+    assert len(got) == len(np.unique(k))
+
+
+def test_decimal_i128_wraparound_sum_is_exact(ctx, oracle):
+    """values near +-2^126 so that low-half carries and 128-bit wrap-around both happen (SUM is add_wrapping, sum.rs:75-77)"""
+    t = pa.decimal128(38, 0)
+    big = (1 << 126) - 12345
+    vals = [big, big, big, -big, 7, (1 << 64) - 1, (1 << 64) - 1, -(1 << 100)] * 500
+    D = decimal.Decimal
+    ctx38 = decimal.Context(prec=60)
+    raw = np.array([[v & 0xFFFFFFFFFFFFFFFF, (v >> 64) & 0xFFFFFFFFFFFFFFFF] for v in vals], dtype=np.uint64)
+    arr = pa.Array.from_buffers(t, len(vals), [None, pa.py_buffer(raw)])
+    keys = pa.array([i % 3 for i in range(len(vals))], type=pa.int32())
+    schema = pa.schema([pa.field("k", pa.int32()), pa.field("v", t)])
+    scan = table_scan(schema, [pa.RecordBatch.from_arrays([keys, arr], schema=schema)])
+    plan = q.HashAggregate(None, scan, [col("k", 0)], [q.SumAggregateExpr(col("v", 1), t)])
+    got = plan.execute()[0]
+    want = oracle.execute(plan)[0]
+    to_raw = lambda b: sorted((b.column(0)[i].as_py(), bytes(b.column(1).buffers()[1])[16 * i:16 * i + 16]) for i in range(b.num_rows))
+    assert to_raw(got) == to_raw(want)
+
+
+def test_no_grouping_and_empty_inputs(ctx, oracle):
+    schema = pa.schema([pa.field("v1", I64), pa.field("v2", pa.float64())])
+    rows = [(1, 2.5), (2, 3.2), (None, 4.7), (4, None)]
+    scan = table_scan(schema, rows)
+    aggs = [q.SumAggregateExpr(col("v1", 0), I64), q.SumAggregateExpr(col("v2", 1), pa.float64()), q.CountAggregateExpr(col("v1", 0)),
+            q.MinAggregateExpr(col("v1", 0), I64), q.MaxAggregateExpr(col("v2", 1), pa.float64()),
+            q.AvgAggregateExpr(col("v2", 1), pa.float64(), pa.float64())]
+    got = rows_of(q.NoGroupingAggregate(None, scan, aggs).execute())
+    want = rows_of(oracle.execute(q.NoGroupingAggregate(None, scan, aggs)))
+    assert len(got) == 1 and got[0][0] == want[0][0] and got[0][2:4] == want[0][2:4]
+    for a, b in ((got[0][1], want[0][1]), (got[0][4], want[0][4]), (got[0][5], want[0][5])):
+        assert abs(a - b) <= 1e-6 * abs(b)
+    # zero batches: COUNT -> 0, SUM -> NULL; grouped: no output batches (aggregation.slt:162-169,192-195)
+    empty = q.Scan(schema, q.MemoryTable.try_new(schema, []))
+    assert rows_of(q.NoGroupingAggregate(None, empty, [q.CountAggregateExpr(lit_i64(1)), q.SumAggregateExpr(col("v1", 0), I64)]).execute()) == [(0, None)]
+    assert q.HashAggregate(None, empty, [col("v1", 0)], [q.CountAggregateExpr(lit_i64(1))]).execute() == []
+    # a filter that keeps nothing: groups = 0 rows in one batch
+    none = q.Filter(scan, q.BinaryExpr(col("v1", 0), Operator.Gt, lit_i64(100)))
+    out = q.HashAggregate(None, none, [col("v1", 0)], [q.CountAggregateExpr(lit_i64(1))]).execute()
+    assert len(out) == 1 and out[0].num_rows == 0
+
+
+def test_errors_match_reference_behaviour(ctx, oracle):
+    schema = pa.schema([pa.field("a", I64), pa.field("b", pa.int32()), pa.field("f", pa.float64())])
+    scan = table_scan(schema, [(1, 1, 1.0), (2, 0, 2.0)])
+    with pytest.raises(q.QuriousError, match="Invalid comparison operation"):
+        q.HashAggregate(None, q.Filter(scan, q.BinaryExpr(col("a", 0), Operator.Eq, col("b", 1))), [col("a", 0)], []).execute()
+    with pytest.raises(q.QuriousError, match="Unsupported data type in hasher"):
+        q.HashAggregate(None, scan, [col("f", 2)], [q.CountAggregateExpr(lit_i64(1))]).execute()
+    with pytest.raises(q.QuriousError, match="Divide by zero"):
+        q.HashAggregate(None, scan, [col("a", 0)], [q.SumAggregateExpr(q.BinaryExpr(col("a", 0), Operator.Div, q.CastExpr(col("b", 1), I64)), I64)]).execute()
+    with pytest.raises(q.QuriousError, match="Sum not supported"):
+        q.HashAggregate(None, scan, [col("a", 0)], [q.SumAggregateExpr(col("b", 1), pa.int32())]).execute()
