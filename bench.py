@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the qurious-hip backend (contract: see the task prompt / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+BASELINE.json configs[1] — SELECT l_returnflag, SUM(l_quantity) FROM lineitem WHERE l_shipdate < '1998-09-01'
+GROUP BY l_returnflag over 100M synthetic rows (2^20-row Arrow batches) — executed by the fused filter +
+hash-aggregate HIP kernel through the C ABI. With N > 1 every rank owns its own 100M-row shard (weak scaling,
+rows are independent; partial aggregates are merged once on the host for verification — no data-path collective).
+
+Prints ONE JSON line on rank 0: value = rows/s of the whole job, plus
+  roofline     — algorithmic bytes (25 B/row) / mean device time of the dominant kernel (HIP events on
+                 the library's stream) vs the 8 TB/s HBM peak; `traffic` = PMC-measured HBM bytes per launch when a
+                 profile summary for this round exists under profiles/ (else null)
+  cpu_baseline — the CPU oracle's faithful-cost restatement of the reference executor (oracle/qoracle.c, 1 thread)
+                 timed on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import qurious_amd as q  # noqa: E402  (before torch: binds the system ROCm runtime first)
+from qurious_amd import queries, synth  # noqa: E402
+
+ALGO_BYTES_PER_ROW = {"q1_mini": 25, "q1_full": 78}   # Date32 4 + Utf8 (4+1) [x2 for Q1] + Decimal128 16 [x4]
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def gen_table(first_row: int, n_rows: int, batch_rows: int) -> q.MemoryTable:
+    starts = list(range(0, n_rows, batch_rows))
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        batches = list(ex.map(lambda s: synth.lineitem_batch(first_row + s, min(batch_rows, n_rows - s)), starts))
+    return q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, batches)
+
+
+def result_key(batches):
+    rows = []
+    for b in batches:
+        rows.extend(zip(*[c.to_pylist() for c in b.columns]))
+    return sorted(rows)
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (configs[1]: 100M)")
+    ap.add_argument("--batch-rows", type=int, default=1 << 20)
+    ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full"])
+    ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("QHIP_DEVICE", str(local_rank))
+    ctx = q.get_context()   # raises without a gfx950 device: there is no CPU fallback
+    log(f"context on {ctx.device_name()}")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("torch imported")
+    # ---- synthetic input, resident in HBM before the timed region
+    t0 = time.time()
+    table = gen_table(rank * args.rows, args.rows, args.batch_rows)
+    t_gen = time.time() - t0
+    log(f"generated {args.rows} rows in {t_gen:.1f}s")
+    t0 = time.time()
+    dev = table.device_table()
+    t_upload = time.time() - t0
+    log(f"uploaded in {t_upload:.1f}s")
+    resident = sum(dev.column_bytes(c) for c in range(dev.num_columns))
+    plan = getattr(queries, args.workload)(table)
+
+    for _ in range(args.warmup):
+        plan.execute_device()
+        log(f"warmup step: kernel {ctx.last_stats()['main_kernel_ms']:.3f} ms")
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.execute_device()
+        kernel_ms.append(ctx.last_stats()["main_kernel_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    stats = ctx.last_stats()
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+
+    # ---- verification of the whole-job result (outside the timed region)
+    result = plan.execute()
+    partial = result_key(result)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, partial)
+    else:
+        gathered = [partial]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    merged = {}
+    for part in gathered:
+        for row in part:
+            nk = len(plan.group_exprs)
+            k = row[:nk]
+            if k not in merged:
+                merged[k] = list(row[nk:])
+            elif args.workload == "q1_mini":
+                merged[k] = [a + b for a, b in zip(merged[k], row[nk:])]
+
+    total_rows = args.rows * world
+    value = total_rows * args.steps / elapsed
+    mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    bpr = ALGO_BYTES_PER_ROW[args.workload]
+    achieved = args.rows * bpr / (mean_kernel_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        from oracle import qoracle
+        n = min(args.cpu_sample_rows, args.rows)
+        sample = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, table.data[: max(1, n // args.batch_rows)])
+        cplan = getattr(queries, args.workload)(sample)
+        log(f"cpu baseline: oracle over {sum(b.num_rows for b in sample.data)} rows ...")
+        cres, cdt, crows = qoracle.scan_filter_aggregate_timed(cplan)
+        log(f"cpu baseline: {crows / cdt / 1e6:.2f} Mrows/s ({cdt:.1f}s)")
+        # same rows through the HIP path must agree bit-exactly with the oracle
+        assert result_key([cres]) == result_key(cplan.execute()), "HIP result differs from the CPU oracle on the baseline sample"
+        cpu_baseline = {"value": crows / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+                        "sample": f"{crows} rows ({len(sample.data)} batches of {args.batch_rows}) of the same workload through "
+                                  f"oracle/qoracle.c qo_scan_filter_aggregate, 1 of {os.cpu_count()} host cores "
+                                  "(the reference executor is single-threaded)",
+                        "seconds": cdt}
+
+    line = {
+        "metric": "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "i128",
+        "data": "synthetic",
+        "config": {"workload": f"configs[1] {args.workload}: filter+GROUP BY, {args.rows} synthetic lineitem rows per GPU in "
+                               f"{args.batch_rows}-row Arrow batches, HBM-resident",
+                   "rows_per_gpu": args.rows, "batch_rows": args.batch_rows, "groups": len(merged),
+                   "resident_bytes_per_gpu": resident, "parallelism": f"replicated-shards x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "kernel": stats["main_kernel_name"], "kernel_ms": mean_kernel_ms,
+                     "algorithmic_bytes_per_row": bpr},
+        "cpu_baseline": cpu_baseline,
+        "device": ctx.device_name(),
+        "setup_s": {"generate": t_gen, "upload_h2d": t_upload, "h2d_GBps": resident / t_upload / 1e9},
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -946,3 +946,121 @@ void qo_agg_result_free(qo_agg_result* r) {
   free(r->agg_cols);
   memset(r, 0, sizeof *r);
 }
+
+/* ================================================================ whole-pipeline restatement (timed CPU baseline)
+ * Scan(filter) -> HashAggregate exactly as the reference runs it for Q1-shaped plans:
+ *   per stored batch: evaluate the predicate (literal broadcast + cast + compare, memory.rs:90-91),
+ *                     filter_record_batch over EVERY column (memory.rs:92; no projection pushdown, planner/mod.rs:251-256)
+ *   concat_batches of all filtered batches (hash.rs:150)
+ *   evaluate group and aggregate-argument expressions over the concatenated batch (hash.rs:152-162)
+ *   GroupAccumulator::update + output (hash.rs:45-107)
+ * batches[b * ncols + c] is column c of batch b. pred_root < 0: no filter. */
+static void gather_col(const qo_col* in, const int64_t* sel, int64_t m, qo_col* out) {
+  memset(out, 0, sizeof *out);
+  out->type = in->type; out->n = m; out->owned = 1;
+  int w = type_width(in->type.id);
+  if (in->valid) { out->valid = (uint8_t*)malloc((size_t)(m > 0 ? m : 1)); for (int64_t k = 0; k < m; ++k) out->valid[k] = in->valid[sel[k]]; }
+  if (in->type.id == QHIP_UTF8) {
+    out->offsets = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    int64_t total = 0;
+    for (int64_t k = 0; k < m; ++k) total += in->offsets[sel[k] + 1] - in->offsets[sel[k]];
+    out->data = (uint8_t*)malloc((size_t)(total > 0 ? total : 1));
+    int32_t pos = 0;
+    for (int64_t k = 0; k < m; ++k) {
+      int32_t b = in->offsets[sel[k]], len = in->offsets[sel[k] + 1] - b;
+      out->offsets[k] = pos;
+      memcpy(out->data + pos, in->data + b, (size_t)len);
+      pos += len;
+    }
+    out->offsets[m] = pos;
+  } else if (w) {
+    out->values = malloc((size_t)(m > 0 ? m : 1) * (size_t)w);
+    const uint8_t* src = (const uint8_t*)in->values;
+    uint8_t* dst = (uint8_t*)out->values;
+    switch (w) {
+      case 4: for (int64_t k = 0; k < m; ++k) ((uint32_t*)dst)[k] = ((const uint32_t*)src)[sel[k]]; break;
+      case 8: for (int64_t k = 0; k < m; ++k) ((uint64_t*)dst)[k] = ((const uint64_t*)src)[sel[k]]; break;
+      case 16: for (int64_t k = 0; k < m; ++k) ((u128*)dst)[k] = ((const u128*)src)[sel[k]]; break;
+      default: for (int64_t k = 0; k < m; ++k) memcpy(dst + (size_t)k * w, src + (size_t)sel[k] * w, (size_t)w);
+    }
+  }
+}
+
+static void concat_cols(const qo_col* parts, int64_t nparts, int stride, qo_col* out) {
+  /* parts[k * stride] for k in 0..nparts */
+  memset(out, 0, sizeof *out);
+  if (nparts == 0) return;
+  out->type = parts[0].type; out->owned = 1;
+  int64_t n = 0, bytes = 0;
+  int any_valid = 0;
+  for (int64_t k = 0; k < nparts; ++k) {
+    const qo_col* p = &parts[k * stride];
+    n += p->n;
+    if (p->valid) any_valid = 1;
+    if (p->type.id == QHIP_UTF8) bytes += p->offsets[p->n] - p->offsets[0];
+  }
+  out->n = n;
+  int w = type_width(out->type.id);
+  if (any_valid) out->valid = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+  if (out->type.id == QHIP_UTF8) { out->offsets = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1)); out->data = (uint8_t*)malloc((size_t)(bytes > 0 ? bytes : 1)); }
+  else if (w) out->values = malloc((size_t)(n > 0 ? n : 1) * (size_t)w);
+  int64_t pos = 0; int32_t bpos = 0;
+  for (int64_t k = 0; k < nparts; ++k) {
+    const qo_col* p = &parts[k * stride];
+    if (any_valid) { if (p->valid) memcpy(out->valid + pos, p->valid, (size_t)p->n); else memset(out->valid + pos, 1, (size_t)p->n); }
+    if (out->type.id == QHIP_UTF8) {
+      int32_t base = p->offsets[0];
+      for (int64_t i = 0; i < p->n; ++i) out->offsets[pos + i] = p->offsets[i] - base + bpos;
+      memcpy(out->data + bpos, p->data + base, (size_t)(p->offsets[p->n] - base));
+      bpos += p->offsets[p->n] - base;
+    } else if (w) memcpy((uint8_t*)out->values + (size_t)pos * w, p->values, (size_t)p->n * w);
+    pos += p->n;
+  }
+  if (out->type.id == QHIP_UTF8) out->offsets[n] = bpos;
+}
+
+int qo_scan_filter_aggregate(const qo_col* batches, int64_t nbatches, int ncols, const int64_t* batch_rows, const qhip_expr* exprs,
+                             int n_exprs, int pred_root, const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs,
+                             qo_agg_result* out, qo_col* out_keys /* n_groups result key columns, caller frees */, int64_t* rows_after_filter) {
+  int rc = 0;
+  qo_col* filtered = (qo_col*)calloc((size_t)(nbatches * ncols > 0 ? nbatches * ncols : 1), sizeof(qo_col));
+  int64_t total = 0;
+  for (int64_t b = 0; b < nbatches && !rc; ++b) {
+    const qo_col* bc = &batches[b * ncols];
+    const int64_t n = batch_rows[b];
+    if (pred_root >= 0) {
+      qo_col mask;
+      rc = eval_node(exprs, n_exprs, pred_root, bc, ncols, n, &mask);
+      if (rc) break;
+      int64_t* sel = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * 8);
+      int64_t m = qo_filter_indices(&mask, sel);
+      qo_col_free(&mask);
+      if (m < 0) { free(sel); rc = QHIP_INVALID_ARGUMENT; break; }
+      for (int c = 0; c < ncols; ++c) gather_col(&bc[c], sel, m, &filtered[b * ncols + c]);
+      free(sel);
+      total += m;
+    } else {
+      for (int c = 0; c < ncols; ++c) { filtered[b * ncols + c] = bc[c]; filtered[b * ncols + c].owned = 0; filtered[b * ncols + c].n = n; }
+      total += n;
+    }
+  }
+  qo_col* cat = (qo_col*)calloc((size_t)(ncols > 0 ? ncols : 1), sizeof(qo_col));
+  if (!rc) for (int c = 0; c < ncols; ++c) concat_cols(&filtered[c], nbatches, ncols, &cat[c]);
+  for (int64_t k = 0; k < nbatches * ncols; ++k) qo_col_free(&filtered[k]);
+  free(filtered);
+  if (rows_after_filter) *rows_after_filter = total;
+  qo_col* keys = (qo_col*)calloc((size_t)(n_groups > 0 ? n_groups : 1), sizeof(qo_col));
+  qo_col* args = (qo_col*)calloc((size_t)(n_aggs > 0 ? n_aggs : 1), sizeof(qo_col));
+  for (int k = 0; k < n_groups && !rc; ++k) rc = eval_node(exprs, n_exprs, group_roots[k], cat, ncols, total, &keys[k]);
+  for (int a = 0; a < n_aggs && !rc; ++a) rc = eval_node(exprs, n_exprs, aggs[a].expr, cat, ncols, total, &args[a]);
+  if (!rc) {
+    int64_t offs[2] = {0, total};
+    rc = qo_hash_aggregate(keys, n_groups, args, aggs, n_aggs, total, offs, nbatches > 0 ? 1 : 0, out);
+  }
+  if (!rc && out_keys) for (int k = 0; k < n_groups; ++k) gather_col(&keys[k], out->first_row, out->n_groups, &out_keys[k]);
+  for (int k = 0; k < n_groups; ++k) qo_col_free(&keys[k]);
+  for (int a = 0; a < n_aggs; ++a) qo_col_free(&args[a]);
+  for (int c = 0; c < ncols; ++c) qo_col_free(&cat[c]);
+  free(keys); free(args); free(cat);
+  return rc;
+}

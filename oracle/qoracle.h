@@ -107,15 +107,11 @@ int qo_hash_aggregate(const qo_col* keys, int n_keys, const qo_col* args, const 
                       const int64_t* batch_offsets, int64_t n_batches, qo_agg_result* out);
 void qo_agg_result_free(qo_agg_result* r);
 
-/* ---- faithful-cost end-to-end baseline used by bench.py (cpu_baseline): config 0/1 and Q1 over
- * synthetic lineitem batches of `batch_rows` rows generated by the caller. See qoracle.c. */
-typedef struct qo_lineitem_batch {
-  int64_t n;
-  const int32_t* l_shipdate;
-  const int32_t* rf_offsets; const uint8_t* rf_data;
-  const int32_t* ls_offsets; const uint8_t* ls_data;
-  const void* l_quantity; const void* l_extendedprice; const void* l_discount; const void* l_tax; /* i128 LE */
-} qo_lineitem_batch;
+/* ---- faithful-cost whole pipeline Scan(filter) -> HashAggregate, timed by bench.py as cpu_baseline.
+ * batches[b * ncols + c] = column c of stored batch b. See qoracle.c for the steps mirrored. */
+int qo_scan_filter_aggregate(const qo_col* batches, int64_t nbatches, int ncols, const int64_t* batch_rows, const qhip_expr* exprs,
+                             int n_exprs, int pred_root, const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs,
+                             qo_agg_result* out, qo_col* out_keys, int64_t* rows_after_filter);
 
 #ifdef __cplusplus
 }

@@ -454,3 +454,49 @@ def execute(node) -> List[pa.RecordBatch]:
     if isinstance(node, P.Filter):
         return [filter_batch(b, node.predicate) for b in execute(node.input)]       # filter.rs:29-43
     raise OracleError(2, f"oracle: unsupported plan node {type(node).__name__}")
+
+
+# ---------------------------------------------------------------- timed whole-pipeline baseline (bench.py cpu_baseline)
+def scan_filter_aggregate_timed(plan: "P.HashAggregate"):
+    """Run HashAggregate(Scan(filter)) entirely inside the C restatement (qo_scan_filter_aggregate) and return
+    (result RecordBatch, seconds of the C call, rows scanned). Single-threaded like the reference executor."""
+    import time
+    L = lib()
+    L.qo_scan_filter_aggregate.argtypes = [C.POINTER(qo_col), C.c_int64, C.c_int, C.c_void_p, C.POINTER(_pffi.qhip_expr), C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int, C.POINTER(_pffi.qhip_agg), C.c_int, C.POINTER(qo_agg_result),
+                                           C.POINTER(qo_col), C.POINTER(C.c_int64)]
+    scan = plan.input
+    assert isinstance(scan, P.Scan) and scan.projections is None
+    data = scan.datasource.data
+    ncols = len(scan.datasource.schema())
+    cols = [Col(b.column(c)) for b in data for c in range(ncols)]
+    carr = _col_array(cols)
+    rows = np.asarray([b.num_rows for b in data], dtype=np.int64)
+    ea = ExprArray()
+    pred = ea.lower(scan.filter) if scan.filter is not None else -1
+    groups = np.asarray([ea.lower(g) for g in plan.group_exprs], dtype=np.int32)
+    aggs = (_pffi.qhip_agg * max(1, len(plan.aggregate_exprs)))()
+    for k, a in enumerate(plan.aggregate_exprs):
+        aggs[k].kind = a.kind
+        aggs[k].expr = ea.lower(a.expression())
+        aggs[k].return_type = to_qhip_dtype(a._return_type())
+    arr, n = ea.c_array()
+    res = qo_agg_result()
+    okeys = (qo_col * max(1, len(groups)))()
+    kept = C.c_int64(0)
+    t0 = time.perf_counter()
+    rc = L.qo_scan_filter_aggregate(carr, len(data), ncols, rows.ctypes.data if rows.size else None, arr, n, pred,
+                                    groups.ctypes.data if groups.size else None, len(groups), aggs, len(plan.aggregate_exprs),
+                                    C.byref(res), okeys, C.byref(kept))
+    dt = time.perf_counter() - t0
+    _check(rc)
+    try:
+        out_cols = [col_to_arrow(okeys[k], _result_type(None, okeys[k])) for k in range(len(groups))]
+        for a, ae in enumerate(plan.aggregate_exprs):
+            out_cols.append(col_to_arrow(res.agg_cols[a], ae._return_type()))
+    finally:
+        for k in range(len(groups)):
+            L.qo_col_free(C.byref(okeys[k]))
+        L.qo_agg_result_free(C.byref(res))
+    batch = pa.RecordBatch.from_arrays(out_cols, names=[f"c{k}" for k in range(len(out_cols))])
+    return batch, dt, int(rows.sum())

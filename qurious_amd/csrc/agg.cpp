@@ -172,7 +172,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", 4);
   unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
 
-  uint32_t cap = plan.W == 0 ? 1 : std::max<uint32_t>(1024, std::min<uint32_t>(pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2), 1u << 22));
+  // start small: clearing and compacting the table costs time proportional to its size, and a GROUP BY with few
+  // groups (Q1: 4) should not pay for a table sized for the row count. Overflow -> kernel bails out early -> x16.
+  uint32_t cap = plan.W == 0 ? 1 : std::max<uint32_t>(1024, std::min<uint32_t>(pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2),
+                                                                               (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 1 << 16)));
   const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
   DevBuf gtable;
   uint32_t status[QS_WORDS];
@@ -200,7 +203,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;
     if (cap >= cap_max) fail(QHIP_HIP_ERROR, "group table overflow at maximum capacity (internal error)");
-    cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 8, cap_max);
+    cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 16, cap_max);
     ++retries;
   }
 

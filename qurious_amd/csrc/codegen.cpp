@@ -237,10 +237,10 @@ void ExprGen::emit(int k, std::string& out) {
             // arrow `div`/`rem` are checked: DivideByZero, and MIN / -1 overflows (evaluated on valid rows only)
             o << "    " << T << " " << v << " = 0;\n";
             o << "    if (" << (n.nullable ? nn : std::string("true")) << ") {\n";
-            o << "      if (" << rv << " == 0) atomicOr(&status[" << QS_DIV_ZERO << "], 1u);\n";
+            o << "      if (" << rv << " == 0) err |= " << (1u << QS_DIV_ZERO) << "u;\n";
             if (signed_intlike(n.type)) {
               if (n.op == QHIP_OP_DIV)
-                o << "      else if (" << lv << " == " << int_min(n.type) << " && " << rv << " == -1) atomicOr(&status[" << QS_ARITH_OVERFLOW << "], 1u);\n";
+                o << "      else if (" << lv << " == " << int_min(n.type) << " && " << rv << " == -1) err |= " << (1u << QS_ARITH_OVERFLOW) << "u;\n";
               else
                 o << "      else if (" << rv << " == -1) " << v << " = 0;\n";
             }
@@ -261,7 +261,7 @@ void ExprGen::emit(int k, std::string& out) {
       if (n.nullable) o << "    const bool " << nn << " = " << co << ";\n";
       const std::string live = n.nullable ? nn : std::string("true");
       auto flag = [&](const std::string& cond) {
-        o << "    if (" << live << " && (" << cond << ")) atomicOr(&status[" << QS_CAST_OVERFLOW << "], 1u);\n";
+        o << "    if (" << live << " && (" << cond << ")) err |= " << (1u << QS_CAST_OVERFLOW) << "u;\n";
       };
       if (from == to) {
         o << "    const " << T << " " << v << " = " << cv << ";\n";
@@ -386,8 +386,8 @@ static void emit_key_words(ExprGen& g, const ExprSet& es, const std::vector<KeyD
     const std::string w = dst + "[" + std::to_string(kd.word_off) + "]";
     std::string value;
     if (kd.type.id == QHIP_UTF8) {
-      o << "    bool tl" << k << " = false; const u64 ks" << k << " = qh_pack_str7(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ", &tl" << k << ");\n";
-      o << "    if (" << okx << " && tl" << k << ") atomicOr(&status[" << QS_KEY_TOO_LONG << "], 1u);\n";
+      o << "    const u64 ks" << k << " = qh_pack_str7(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ");\n";
+      o << "    if (" << okx << " && " << g.len(kd.root) << " > 7) err |= " << (1u << QS_KEY_TOO_LONG) << "u;\n";
       value = "ks" + std::to_string(k);
     } else if (kd.type.id == QHIP_DECIMAL128) {
       value = "(u64)(u128)" + g.val(kd.root);
@@ -523,7 +523,9 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   }
   s << "  };\n";
   // eval
-  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 i, Row& r, u32* status) {\n";
+  // straight-line code: every load of the row is issued unconditionally so that the loads of all R rows of a
+  // tile are in flight together (a branch on the predicate would serialise the memory latencies)
+  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 i, Row& r, u32& err) {\n";
   std::string code;
   if (predicate_root >= 0) {
     g.emit(predicate_root, code);
@@ -532,7 +534,6 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   } else {
     s << "    r.pass = true;\n";
   }
-  s << "    if (r.pass) {\n";
   code.clear();
   emit_key_words(g, es, P.keys, P.null_mask_word, "r.key", code, nullptr);
   s << code;
@@ -545,7 +546,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (value_needed) s << "    r.a" << a << " = " << g.val(P.args[a].root) << ";\n";
     if (P.args[a].nullable) s << "    r.h" << a << " = " << g.ok(P.args[a].root) << ";\n";
   }
-  s << "    }\n  }\n";
+  s << "  }\n";
   // part_init
   s << "  __device__ static __forceinline__ void part_init(Part& p) {\n";
   for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";
@@ -636,7 +637,7 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
   std::string code;
   g.emit(root, code);
   std::ostringstream s;
-  s << "struct P {\n  __device__ static __forceinline__ bool pred(const KArgs& a, const i64 i, u32* status) {\n" << code;
+  s << "struct P {\n  __device__ static __forceinline__ bool pred(const KArgs& a, const i64 i, u32& err) {\n" << code;
   s << "    return " << g.ok(root) << " && " << g.val(root) << ";\n  }\n};\n";
   s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_pred_mask(KArgs a, u64* mask, u32* wave_count, u32* status) { "
        "qh_pred_mask_body<P>(a, mask, wave_count, status); }\n";
@@ -654,7 +655,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   emit_key_words(g, es, out.keys, false, "k", code, &all);
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
-  s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32* status) {\n" << code;
+  s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
   s << "    return " << all << ";\n  }\n};\n";
   s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
        "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";

@@ -98,7 +98,9 @@ DType dtype_from_format(const char* f) {
 
 void DevBuf::alloc(size_t n) {
   release();
-  size_t m = n ? n : 16;
+  // 64 bytes of slack: kernels read Utf8 values with one unaligned 8-byte load (qh_pack_str7) and never fault
+  // on the last value of a buffer; n == 0 still yields a valid pointer
+  size_t m = n + 64;
   hipError_t e = hipMalloc(&ptr, m);
   if (e != hipSuccess) {
     ptr = nullptr;

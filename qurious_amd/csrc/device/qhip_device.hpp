@@ -58,11 +58,17 @@ __device__ __forceinline__ u64 qh_f64_ord(double d) { u64 b = (u64)__double_as_l
 __device__ __forceinline__ double qh_ord_f64(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k; return __longlong_as_double((i64)b); }
 
 // Utf8 value of at most 7 bytes packed injectively into one key word: byte 7 = length, bytes 0..len-1 = data.
-__device__ __forceinline__ u64 qh_pack_str7(const u8* p, int len, bool* too_long) {
-  if (len > 7) { *too_long = true; len = 7; }
-  u64 w = (u64)len << 56;
-  for (int k = 0; k < len; ++k) w |= (u64)p[k] << (8 * k);
-  return w;
+// Branch-free: one unaligned 8-byte load (every Utf8 data buffer is allocated with >= 8 bytes of slack), masked to
+// the value's length; a loop of byte loads would put control flow between the loads of a tile's rows.
+typedef u64 __attribute__((aligned(1))) qh_u64_unaligned;
+__device__ __forceinline__ u64 qh_pack_str7(const u8* p, int len) {
+  const u64 raw = *(const qh_u64_unaligned*)p;
+  const int l = len > 7 ? 7 : len;
+  const u64 mask = l ? (~0ULL >> (64 - 8 * l)) : 0ULL;
+  return (raw & mask) | ((u64)l << 56);
+}
+__device__ __forceinline__ void qh_report(u32* status, u32 err) {
+  if (err) for (int b = 0; b < QS_WORDS; ++b) if ((err >> b) & 1u) atomicOr(&status[b], 1u);
 }
 // bytewise compare like arrow's Utf8 ordering: <0, 0, >0
 __device__ __forceinline__ int qh_strcmp(const u8* a, int la, const u8* b, int lb) {
@@ -244,7 +250,7 @@ __device__ __forceinline__ u64* qh_find_or_insert(u64* table, u32 nslots /*pow2*
 //   SLOT_WORDS   u64 words per slot: 1 state + W key + cells
 //   struct Row   { bool pass; u64 key[W]; <per-argument value + validity> }
 //   struct Part  per-cell partial aggregate of one (thread, key)
-//   eval(a, i, row, status)             load row i, evaluate predicate/keys/arguments
+//   eval(a, i, row, err)                load row i (branch-free), evaluate predicate/keys/arguments; status bits into err
 //   part_init(p) / part_add(p, row, m)  thread-local accumulate of rows with m == true
 //   part_reduce(p)                      wavefront reduction (all lanes active)
 //   (every cell's identity is all-zero bits, so a zero-filled table needs no per-slot initialisation)
@@ -312,17 +318,25 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
 
   typename P::Part acc;   // W == 0: whole-kernel per-thread accumulator
   if (W == 0) P::part_init(acc);
+  u32 err = 0;            // QS_* bits raised by this thread, reported once at the end
 
   const i64 tile_rows = (i64)QH_BLOCK * R;
   const i64 ntiles = (a.nrows + tile_rows - 1) / tile_rows;
   for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (the load is
+    // issued with the tile's loads and consumed at the end of the iteration, wave-uniform)
+    const u32 overflowed = W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     typename P::Row row[R];
     const i64 base = t * tile_rows + tid;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+      // out-of-range lanes re-read the last row (no branch around the loads) and are masked out afterwards
       const i64 i = base + (i64)r * QH_BLOCK;
-      row[r].pass = false;
-      if (i < a.nrows) P::eval(a, i, row[r], L.status);
+      const bool inb = i < a.nrows;
+      u32 e = 0;
+      P::eval(a, inb ? i : a.nrows - 1, row[r], e);
+      row[r].pass = row[r].pass && inb;
+      err |= inb ? e : 0u;
     }
     if (W == 0) {
 #pragma unroll
@@ -384,8 +398,10 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
         qh_update_group<P>(ltable, L, row[r].key, part);
       }
     }
+    if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
   }
 
+  qh_report(L.status, err);
   if (W == 0) {
     P::part_reduce(acc);
     if (lane == 0) P::template slot_update<MemHbm>(L.gtable, acc);
@@ -418,13 +434,17 @@ __device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32
   const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
   const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
   const int lane = qh_lane();
+  u32 err = 0;
   for (i64 j = wave_global; j < nwords; j += nwaves) {
     const i64 i = j * 64 + lane;
-    bool keep = false;
-    if (i < a.nrows) keep = P::pred(a, i, status);
+    const bool inb = i < a.nrows;
+    u32 e = 0;
+    const bool keep = P::pred(a, inb ? i : a.nrows - 1, e) && inb;
+    err |= inb ? e : 0u;
     u64 m = qh_ballot(keep);
     if (lane == 0) { mask[j] = m; wave_count[j] = (u32)__builtin_popcountll(m); }
   }
+  qh_report(status, err);
 }
 
 // ------------------------------------------------------------------ expression -> key words kernel (hash join keys, partition keys)
@@ -436,16 +456,20 @@ __device__ __forceinline__ void qh_eval_keys_body(const KArgs& a, u64* keys, u64
   const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
   const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
   const int lane = qh_lane();
+  u32 err = 0;
   for (i64 j = wave_global; j < nwords; j += nwaves) {
     const i64 i = j * 64 + lane;
-    bool ok = false;
-    if (i < a.nrows) {
-      u64 k[P::W];
-      ok = P::keys(a, i, k, status);
+    const bool inb = i < a.nrows;
+    u64 k[P::W];
+    u32 e = 0;
+    const bool ok = P::keys(a, inb ? i : a.nrows - 1, k, e) && inb;
+    err |= inb ? e : 0u;
+    if (inb) {
 #pragma unroll
       for (int w = 0; w < P::W; ++w) keys[(size_t)w * a.nrows + i] = ok ? k[w] : 0;
     }
     u64 m = qh_ballot(ok);
     if (lane == 0) keyvalid[j] = m;
   }
+  qh_report(status, err);
 }
