@@ -1,7 +1,80 @@
-// filter.cpp — placeholder, replaced below in this round
+// filter.cpp — qhip_filter_execute: Filter::execute (physical/plan/filter.rs:28-44) and MemoryTable::scan with a
+// pushed-down filter / projection (datasource/memory.rs:69-98).
+//   predicate -> keep mask (JIT kernel, wavefront ballot)  ->  exclusive scan of the per-wave popcounts
+//   -> selection vector (rank inside the ballot mask)      ->  every column gathered by the selection vector.
+// One output batch per input batch, possibly empty, row order preserved.
+#include <hip/hip_runtime_api.h>
+
 #include "common.hpp"
+#include "kernels.hpp"
+#include "relops.hpp"
+
 using namespace qhip;
-extern "C" int qhip_filter_execute(qhip_ctx* ctx, const qhip_table*, const qhip_expr*, int32_t, int32_t, const int32_t*, int32_t, qhip_table** out) {
-  if (out) *out = nullptr;
-  return guarded(ctx, [&] { fail(QHIP_UNSUPPORTED, "qhip_filter_execute: not built yet"); });
+
+static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, int root, const int32_t* projection,
+                                  int n_projection) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  std::vector<int> cols;
+  if (projection && n_projection >= 0) {
+    for (int k = 0; k < n_projection; ++k) {
+      if (projection[k] < 0 || projection[k] >= (int)in->cols.size()) fail(QHIP_INVALID_ARGUMENT, "projection index out of range");
+      cols.push_back(projection[k]);
+    }
+  } else {
+    for (size_t c = 0; c < in->cols.size(); ++c) cols.push_back((int)c);
+  }
+  std::unique_ptr<qhip_table> out(new qhip_table());
+  out->ctx = ctx;
+  for (int c : cols) { out->names.push_back(in->names[(size_t)c]); out->nullable.push_back(in->nullable[(size_t)c]); }
+  if (root < 0) {
+    // projection only: the column buffers are shared, nothing is copied (RecordBatch::project, memory.rs:79-88)
+    for (int c : cols) out->cols.push_back(in->cols[(size_t)c]);
+    out->num_rows = in->num_rows;
+    out->batch_offsets = in->batch_offsets;
+    return out.release();
+  }
+  if (root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "predicate index out of range");
+  if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+  std::vector<InputCol> icols = input_cols_of(in);
+  ExprSet es;
+  es.build(exprs, n_exprs, icols);
+  DevBuf mask, wave, sel;
+  hipEventRecord(ctx->ev[0], ctx->stream);
+  run_pred_mask(ctx, in, es, icols, root, mask, wave);
+  const uint32_t m = select_from_mask(ctx, mask, wave, in->num_rows, sel);
+  for (int c : cols) out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
+  hipEventRecord(ctx->ev[1], ctx->stream);
+  // output batch boundaries = kept rows before each input batch start
+  const size_t nb1 = in->batch_offsets.size();
+  out->num_rows = m;
+  if (in->num_rows == 0) {
+    out->batch_offsets.assign(nb1, 0);
+  } else {
+    std::vector<uint64_t> rows(in->batch_offsets.begin(), in->batch_offsets.end());
+    DevBuf drows(nb1 * 8), dpos(nb1 * 4);
+    QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_mask_prefix_at(mask.as<uint64_t>(), wave.as<uint32_t>(), drows.as<uint64_t>(), (uint32_t)nb1, (uint64_t)in->num_rows, m,
+                          dpos.as<uint32_t>(), ctx->stream);
+    std::vector<uint32_t> pos(nb1);
+    QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out->batch_offsets.assign(pos.begin(), pos.end());
+  }
+  float ms = 0;
+  hipEventSynchronize(ctx->ev[1]);
+  hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+  ctx->stats.total_device_ms = ms;
+  ctx->stats.main_kernel_ms = ms;
+  ctx->stats.rows_in = in->num_rows;
+  ctx->stats.rows_out = m;
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_pred_mask+gather");
+  return out.release();
+}
+
+extern "C" int qhip_filter_execute(qhip_ctx* ctx, const qhip_table* input, const qhip_expr* exprs, int32_t n_exprs, int32_t predicate_root,
+                                   const int32_t* projection, int32_t n_projection, qhip_table** out) {
+  if (!ctx || !input || !out) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = filter_execute(ctx, input, exprs, n_exprs, predicate_root, projection, n_projection); });
 }

@@ -1,9 +1,252 @@
-// join.cpp — placeholder, replaced below in this round
+// join.cpp — qhip_hash_join_execute: HashJoinExec::execute (physical/plan/join/hash_join.rs:354-384).
+//
+//   build (left, hash_join.rs:148-175)    key words (JIT) -> open-addressing table of distinct keys -> rows grouped by slot
+//                                          with a stable radix sort (ascending build row inside a key, the order the
+//                                          reference's reverse-built chains yield) -> CSR start/count per slot
+//   probe (right, hash_join.rs:218-275)   key words (JIT) -> pass 1 matches per probe row -> scan -> pass 2 (build, probe) pairs
+//                                          [-> residual JoinFilter on an intermediate batch, join/mod.rs:125-154]
+//                                          -> visited bitmap -> Right/Full NULL padding (join/mod.rs:176-207)
+//   output (utils/batch.rs:18-61)         every column gathered by the index vectors; one batch per non-empty probe batch,
+//                                          then the unmatched-build / semi tail batch (hash_join.rs:277-343, 374-381)
+// All probe batches are probed in one launch; batch boundaries are recovered from the scanned offsets.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+
 #include "common.hpp"
+#include "device/qhip_status.h"
+#include "kernels.hpp"
+#include "relops.hpp"
+
 using namespace qhip;
-extern "C" int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table*, const qhip_table*, int32_t, const qhip_expr*, int32_t, const qhip_expr*, int32_t,
-                                      const int32_t*, const int32_t*, int32_t, const qhip_expr*, int32_t, int32_t, const int32_t*, const int32_t*, int32_t,
-                                      qhip_table** out) {
-  if (out) *out = nullptr;
-  return guarded(ctx, [&] { fail(QHIP_UNSUPPORTED, "qhip_hash_join_execute: not built yet"); });
+
+namespace {
+
+uint32_t pow2_ceil32(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return (uint32_t)std::min<uint64_t>(p, 1ULL << 31);
+}
+int log2u(uint32_t x) { int b = 0; while ((1u << b) < x) ++b; return b; }
+
+uint32_t read_u32(const void* dev) {
+  uint32_t v = 0;
+  QHIP_HIP_CHECK(hipMemcpy(&v, dev, 4, hipMemcpyDeviceToHost));
+  return v;
+}
+
+qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int join_type, const qhip_expr* lex, int nlex, const qhip_expr* rex,
+                      int nrex, const int32_t* on_l, const int32_t* on_r, int n_on, const qhip_expr* fex, int nfex, int froot,
+                      const int32_t* fsides, const int32_t* fcols, int nfcols) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if (n_on <= 0) fail(QHIP_INVALID_ARGUMENT, "Internal error: On constraints in HashJoinExec should be non-empty");
+  if (join_type < QHIP_JOIN_LEFT || join_type > QHIP_JOIN_LEFT_ANTI) fail(QHIP_INVALID_ARGUMENT, "unknown join type");
+  if (L->num_rows >= (int64_t)kNullIdx - 1 || R->num_rows >= (int64_t)kNullIdx - 1)
+    fail(QHIP_UNSUPPORTED, "join inputs of 2^32 - 2 rows or more are not supported");
+  hipStream_t s = ctx->stream;
+  const uint64_t B = (uint64_t)L->num_rows, P = (uint64_t)R->num_rows;
+  const bool semi_anti = join_type == QHIP_JOIN_LEFT_SEMI || join_type == QHIP_JOIN_LEFT_ANTI;
+  const bool pad_right = join_type == QHIP_JOIN_RIGHT || join_type == QHIP_JOIN_FULL;
+
+  // ---- key words of both sides
+  std::vector<InputCol> lcols = input_cols_of(L), rcols = input_cols_of(R);
+  ExprSet les, res;
+  les.build(lex, nlex, lcols);
+  res.build(rex, nrex, rcols);
+  KeysPlan lkp, rkp;
+  DevBuf lkeys, lvalid, rkeys, rvalid;
+  hipEventRecord(ctx->ev[0], s);
+  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid);
+  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid);
+  for (int k = 0; k < n_on; ++k)
+    if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
+      fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
+                                      " == " + dtype_name(rkp.keys[(size_t)k].type));
+  const int W = lkp.W;
+
+  // ---- build: distinct-key table + CSR of build rows per key
+  const uint32_t nslots = std::max<uint32_t>(16, pow2_ceil32(B * 2));
+  DevBuf table((size_t)nslots * (1 + W) * 8), count((size_t)(nslots + 1) * 4), start((size_t)(nslots + 1) * 4), row_slot((B + 1) * 4);
+  DevBuf sorted_slot((B + 1) * 4), sorted_rows((B + 1) * 4), iota((B + 1) * 4);
+  QHIP_HIP_CHECK(hipMemsetAsync(table.ptr, 0, table.bytes, s));
+  QHIP_HIP_CHECK(hipMemsetAsync(count.ptr, 0, count.bytes, s));
+  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
+  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table.as<uint64_t>(), nslots, row_slot.as<uint32_t>(),
+                           count.as<uint32_t>(), ctx->status.as<uint32_t>(), s);
+  launch_iota_u32(iota.as<uint32_t>(), B, s);
+  stable_sort_pairs_u32(row_slot.as<uint32_t>(), sorted_slot.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), B,
+                        log2u(nslots) + 1, s);
+  exclusive_scan_u32(count.as<uint32_t>(), start.as<uint32_t>(), nslots, nullptr, s);
+  {
+    uint32_t st[QS_WORDS];
+    QHIP_HIP_CHECK(hipMemcpy(st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost));
+    if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
+  }
+
+  // ---- probe pass 1 + 2
+  DevBuf slot_of((P + 1) * 4), cnt((P + 1) * 4), pair_off((P + 1) * 4), total(4);
+  hipEventRecord(ctx->ev[2], s);
+  launch_join_probe_count(W, rkeys.as<uint64_t>(), rvalid.as<uint64_t>(), P, table.as<uint64_t>(), nslots, count.as<uint32_t>(),
+                          slot_of.as<uint32_t>(), cnt.as<uint32_t>(), s);
+  exclusive_scan_u32(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), P, total.as<uint32_t>(), s);
+  uint64_t M = P ? read_u32(total.ptr) : 0;
+  DevBuf b_idx((M + 1) * 4), p_idx((M + 1) * 4);
+  launch_join_probe_write(slot_of.as<uint32_t>(), pair_off.as<uint32_t>(), start.as<uint32_t>(), sorted_rows.as<uint32_t>(), cnt.as<uint32_t>(), P,
+                          b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), s);
+  hipEventRecord(ctx->ev[3], s);
+
+  // ---- residual JoinFilter (join/mod.rs:125-154): evaluate over an intermediate batch of the filter's columns, keep true rows
+  bool filtered = false;
+  if (froot >= 0 && M > 0) {
+    qhip_table inter;
+    inter.ctx = ctx;
+    for (int k = 0; k < nfcols; ++k) {
+      const qhip_table* src = fsides[k] == 0 ? L : R;
+      if (fcols[k] < 0 || fcols[k] >= (int)src->cols.size()) fail(QHIP_INVALID_ARGUMENT, "join filter column index out of range");
+      inter.cols.push_back(gather_column(ctx, src->cols[(size_t)fcols[k]], fsides[k] == 0 ? b_idx.as<uint32_t>() : p_idx.as<uint32_t>(), M, false));
+      inter.names.push_back(src->names[(size_t)fcols[k]]);
+      inter.nullable.push_back(true);
+    }
+    inter.num_rows = (int64_t)M;
+    inter.batch_offsets = {0, (int64_t)M};
+    std::vector<InputCol> fic = input_cols_of(&inter);
+    ExprSet fes;
+    fes.build(fex, nfex, fic);
+    DevBuf mask, wave, sel;
+    run_pred_mask(ctx, &inter, fes, fic, froot, mask, wave);
+    const uint32_t m2 = select_from_mask(ctx, mask, wave, (int64_t)M, sel);
+    DevBuf b2(((uint64_t)m2 + 1) * 4), p2(((uint64_t)m2 + 1) * 4);
+    launch_gather_fixed(b_idx.ptr, sel.as<uint32_t>(), b2.ptr, m2, 4, s);
+    launch_gather_fixed(p_idx.ptr, sel.as<uint32_t>(), p2.ptr, m2, 4, s);
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    b_idx = std::move(b2);
+    p_idx = std::move(p2);
+    M = m2;
+    filtered = true;
+  }
+
+  // ---- visited bitmap; per-probe-row surviving counts when they changed or are needed
+  const uint64_t vwords = ((B + 63) / 64) * 2 + 2;
+  DevBuf visited(vwords * 4);
+  QHIP_HIP_CHECK(hipMemsetAsync(visited.ptr, 0, visited.bytes, s));
+  DevBuf cnt2;
+  if (filtered) {
+    cnt2.alloc((P + 1) * 4);
+    QHIP_HIP_CHECK(hipMemsetAsync(cnt2.ptr, 0, cnt2.bytes, s));
+  }
+  launch_join_mark(b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), M, visited.as<uint32_t>(), filtered ? cnt2.as<uint32_t>() : nullptr, s);
+  const uint32_t* final_cnt = filtered ? cnt2.as<uint32_t>() : cnt.as<uint32_t>();
+  DevBuf off2;                                  // exclusive scan of final_cnt (position of a probe row's first pair)
+  const uint32_t* final_off = pair_off.as<uint32_t>();
+  if (filtered) {
+    off2.alloc((P + 1) * 4);
+    exclusive_scan_u32(final_cnt, off2.as<uint32_t>(), P, nullptr, s);
+    final_off = off2.as<uint32_t>();
+  }
+
+  // ---- Right / Full: probe rows without a surviving pair appear once with a NULL build index, in probe order
+  DevBuf out_off;
+  if (pad_right) {
+    DevBuf out_cnt((P + 1) * 4), tot(4);
+    out_off.alloc((P + 1) * 4);
+    launch_join_out_counts(final_cnt, P, out_cnt.as<uint32_t>(), s);
+    exclusive_scan_u32(out_cnt.as<uint32_t>(), out_off.as<uint32_t>(), P, tot.as<uint32_t>(), s);
+    const uint64_t M2 = P ? read_u32(tot.ptr) : 0;
+    DevBuf b3((M2 + 1) * 4), p3((M2 + 1) * 4);
+    launch_join_adjust_right(b_idx.as<uint32_t>(), final_cnt, final_off, out_off.as<uint32_t>(), P, b3.as<uint32_t>(), p3.as<uint32_t>(), s);
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    b_idx = std::move(b3);
+    p_idx = std::move(p3);
+    M = M2;
+    final_off = out_off.as<uint32_t>();
+  }
+  if (semi_anti) M = 0;   // hash_join.rs:260-262: nothing is emitted while probing
+
+  // ---- tail: unmatched build rows (Left / Full / LeftAnti) or matched ones (LeftSemi), ascending build index
+  const bool has_tail = join_type == QHIP_JOIN_LEFT || join_type == QHIP_JOIN_FULL || semi_anti;
+  uint64_t T = 0;
+  DevBuf tail_sel;
+  if (has_tail && B > 0) {
+    DevBuf tmask(((B + 63) / 64) * 8 + 8), twave((((B + 63) / 64) + 1) * 4);
+    launch_mask_from_bits(visited.as<uint32_t>(), B, join_type == QHIP_JOIN_LEFT_SEMI ? 1 : 0, tmask.as<uint64_t>(), twave.as<uint32_t>(), s);
+    T = select_from_mask(ctx, tmask, twave, (int64_t)B, tail_sel);
+  }
+  const uint64_t total_rows = M + T;
+  if (total_rows >= kNullIdx) fail(QHIP_UNSUPPORTED, "join output of 2^32 - 1 rows or more is not supported");
+
+  // ---- index vectors of the whole output: [pairs | tail]
+  DevBuf b_all((total_rows + 1) * 4), p_all((total_rows + 1) * 4);
+  if (M) {
+    QHIP_HIP_CHECK(hipMemcpyAsync(b_all.ptr, b_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+    QHIP_HIP_CHECK(hipMemcpyAsync(p_all.ptr, p_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (T) {
+    QHIP_HIP_CHECK(hipMemcpyAsync(b_all.as<uint32_t>() + M, tail_sel.ptr, T * 4, hipMemcpyDeviceToDevice, s));
+    launch_fill_u32(p_all.as<uint32_t>() + M, T, kNullIdx, s);
+  }
+
+  // ---- gather output columns (build_batch_from_indices, utils/batch.rs:18-61)
+  std::unique_ptr<qhip_table> out(new qhip_table());
+  out->ctx = ctx;
+  const bool left_nullable = pad_right;
+  const bool right_nullable = has_tail;
+  for (size_t c = 0; c < L->cols.size(); ++c) {
+    out->cols.push_back(gather_column(ctx, L->cols[c], b_all.as<uint32_t>(), total_rows, left_nullable));
+    out->names.push_back(L->names[c]);
+    out->nullable.push_back(L->nullable[c] || left_nullable);
+  }
+  if (!semi_anti) {
+    for (size_t c = 0; c < R->cols.size(); ++c) {
+      out->cols.push_back(gather_column(ctx, R->cols[c], p_all.as<uint32_t>(), total_rows, right_nullable));
+      out->names.push_back(R->names[c]);
+      out->nullable.push_back(R->nullable[c] || right_nullable);
+    }
+  }
+  out->num_rows = (int64_t)total_rows;
+
+  // ---- output batches: one per non-empty probe batch (hash_join.rs:363-372), then the tail batch
+  out->batch_offsets.clear();
+  out->batch_offsets.push_back(0);
+  if (!semi_anti && R->num_batches() > 0 && M > 0) {
+    const size_t nb1 = R->batch_offsets.size();
+    std::vector<uint64_t> rows(R->batch_offsets.begin(), R->batch_offsets.end());
+    DevBuf drows(nb1 * 8), dpos(nb1 * 4);
+    QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, s));
+    launch_lookup_u32(final_off, drows.as<uint64_t>(), (uint32_t)nb1, P, (uint32_t)M, dpos.as<uint32_t>(), s);
+    std::vector<uint32_t> pos(nb1);
+    QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, s));
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t b = 1; b < nb1; ++b)
+      if (pos[b] > (uint32_t)out->batch_offsets.back()) out->batch_offsets.push_back(pos[b]);
+  }
+  if (has_tail) out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
+  hipEventRecord(ctx->ev[1], s);
+  hipEventSynchronize(ctx->ev[1]);
+  float all_ms = 0, probe_ms = 0;
+  hipEventElapsedTime(&all_ms, ctx->ev[0], ctx->ev[1]);
+  hipEventElapsedTime(&probe_ms, ctx->ev[2], ctx->ev[3]);
+  ctx->stats.total_device_ms = all_ms;
+  ctx->stats.main_kernel_ms = probe_ms;
+  ctx->stats.rows_in = (int64_t)P;
+  ctx->stats.rows_out = (int64_t)total_rows;
+  ctx->stats.groups = (int64_t)M;
+  ctx->stats.table_capacity = nslots;
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "k_join_probe_count+write");
+  return out.release();
+}
+
+}  // namespace
+
+extern "C" int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right, int32_t join_type,
+                                      const qhip_expr* left_exprs, int32_t n_left_exprs, const qhip_expr* right_exprs, int32_t n_right_exprs,
+                                      const int32_t* on_left, const int32_t* on_right, int32_t n_on, const qhip_expr* filter_exprs,
+                                      int32_t n_filter_exprs, int32_t filter_root, const int32_t* filter_sides, const int32_t* filter_cols,
+                                      int32_t n_filter_cols, qhip_table** out) {
+  if (!ctx || !left || !right || !out) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    *out = hash_join(ctx, left, right, join_type, left_exprs, n_left_exprs, right_exprs, n_right_exprs, on_left, on_right, n_on, filter_exprs,
+                     n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols);
+  });
 }

@@ -1,13 +1,46 @@
-// kernels.hpp — host launchers of the plan-independent (ahead-of-time compiled) kernels in kernels.hip.
+// kernels.hpp — host launchers of the plan-independent (ahead-of-time compiled) kernels in kernels.hip / kernels_rel.hip.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <cstdint>
 
 namespace qhip {
 
-// group table -> dense slot array
+constexpr uint32_t kNullIdx = 0xFFFFFFFFu;   // NULL row index in u32 index vectors (tables hold < 2^32 - 1 rows)
+
+// group table -> dense slot array (kernels.hip)
 void launch_count_ready(const uint64_t* table, uint32_t nslots, int slot_words, uint32_t* counter, hipStream_t s);
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
                           uint32_t out_capacity, hipStream_t s);
+
+// scan / selection / gather (kernels_rel.hip)
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, hipStream_t s);
+void launch_select_indices(const uint64_t* mask, const uint32_t* wave_offset, uint64_t nrows, uint32_t* sel, hipStream_t s);
+void launch_mask_prefix_at(const uint64_t* mask, const uint32_t* wave_offset, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total,
+                           uint32_t* out, hipStream_t s);
+void launch_mask_from_bits(const uint32_t* bits, uint64_t nrows, int want_set, uint64_t* mask, uint32_t* wave_count, hipStream_t s);
+void launch_gather_fixed(const void* in, const uint32_t* idx, void* out, uint64_t m, int width, hipStream_t s);
+void launch_gather_bits(const uint8_t* bitmap, const uint32_t* idx, uint64_t m, uint64_t* out_words, uint32_t* set_count, hipStream_t s);
+void launch_gather_utf8_lengths(const int32_t* offsets, const uint32_t* idx, uint64_t m, uint32_t* out_len, hipStream_t s);
+void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const uint32_t* idx, uint64_t m, const uint32_t* out_off,
+                              uint8_t* out_data, hipStream_t s);
+void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s);
+void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s);
+void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s);
+void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total, uint32_t* out, hipStream_t s);
+
+// hash join (kernels_rel.hip)
+void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
+                              uint32_t* row_slot, uint32_t* count, uint32_t* status, hipStream_t s);
+void launch_join_probe_count(int W, const uint64_t* pkeys, const uint64_t* pvalid, uint64_t np, const uint64_t* table, uint32_t nslots,
+                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, hipStream_t s);
+void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* pair_off, const uint32_t* start, const uint32_t* sorted_rows,
+                             const uint32_t* cnt, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s);
+void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s);
+void launch_join_out_counts(const uint32_t* cnt, uint64_t np, uint32_t* out_cnt, hipStream_t s);
+void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const uint32_t* in_off, const uint32_t* out_off, uint64_t np,
+                              uint32_t* b_out, uint32_t* p_out, hipStream_t s);
+void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s);
+void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
+                           hipStream_t s);
 
 }  // namespace qhip

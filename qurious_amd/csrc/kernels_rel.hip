@@ -1,0 +1,442 @@
+// kernels_rel.hip — plan-independent relational kernels (gfx950, wave64), compiled ahead of time:
+//   exclusive scan, selection-vector compaction (ballot + popcount rank), row gather ("take") for every
+//   Arrow layout on the path, and the hash-join build / probe kernels.
+// Reference operators they replace are cited per kernel (paths relative to /root/reference/qurious/src).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device/qhip_status.h"
+#include "device/qhip_device.hpp"
+#include "kernels.hpp"
+
+namespace qhip {
+
+#define QH_NULL_IDX 0xFFFFFFFFu
+
+static inline unsigned grid_for(uint64_t n, unsigned per_block = QH_BLOCK, unsigned cap = 4096) {
+  uint64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+// ================================================================ exclusive scan (u32)
+// Three-phase scan: per-chunk sums -> scan of the sums (recursive) -> per-chunk scan + chunk offset. A chunk is
+// 2048 elements (256 threads x 8); inside a chunk each wave scans with shuffles, waves are combined through LDS.
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (QH_BLOCK * SCAN_ITEMS)
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
+  const int lane = qh_lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 t = (u32)__shfl_up((int)v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(QH_BLOCK) void k_scan_chunk_sums(const u32* in, u64 n, u32* sums) {
+  __shared__ u32 wsum[4];
+  const u64 base = (u64)blockIdx.x * SCAN_CHUNK;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const u64 i = base + (u64)k * QH_BLOCK + threadIdx.x;
+    s += i < n ? in[i] : 0u;
+  }
+  const u32 w = (u32)qh_wave_sum_u64(s);
+  if (qh_lane() == 0) wsum[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(QH_BLOCK) void k_scan_chunk_apply(const u32* in, u32* out, u64 n, const u32* chunk_offsets) {
+  __shared__ u32 wtot[4];
+  const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const u64 i = base + k;
+    v[k] = i < n ? in[i] : 0u;
+    s += v[k];
+  }
+  const u32 incl = wave_incl_scan_u32(s);
+  const int wave = threadIdx.x >> 6;
+  if (qh_lane() == 63) wtot[wave] = incl;
+  __syncthreads();
+  u32 off = chunk_offsets ? chunk_offsets[blockIdx.x] : 0u;
+  for (int w = 0; w < wave; ++w) off += wtot[w];
+  u32 run = off + incl - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const u64 i = base + k;
+    if (i < n) out[i] = run;
+    run += v[k];
+  }
+}
+
+// out[i] = sum(in[0..i)); out may alias in. *total (device) receives the grand total when non-null.
+void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, hipStream_t s) {
+  if (n == 0) {
+    if (total_dev) hipMemsetAsync(total_dev, 0, 4, s);
+    return;
+  }
+  const uint64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  uint32_t* sums = nullptr;
+  hipMalloc(&sums, (nchunks + 1) * sizeof(uint32_t));
+  hipLaunchKernelGGL(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u64)n, (u32*)sums);
+  if (nchunks == 1) {
+    // one chunk: its sum is the total and its offset is zero
+    hipMemcpyAsync(sums + 1, sums, 4, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_scan_chunk_apply, dim3(1), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)nullptr);
+  } else {
+    // scan the chunk sums in place (recursion depth <= 3 for n < 2^32)
+    exclusive_scan_u32(sums, sums, nchunks, sums + nchunks, s);
+    hipLaunchKernelGGL(k_scan_chunk_apply, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)sums);
+  }
+  if (total_dev) hipMemcpyAsync(total_dev, sums + nchunks, 4, hipMemcpyDeviceToDevice, s);
+  hipStreamSynchronize(s);
+  hipFree(sums);
+}
+
+// ================================================================ selection vector from a keep-mask
+// filter_record_batch (physical/plan/filter.rs:34, datasource/memory.rs:92): the rank of a kept row inside its
+// wavefront's 64-bit ballot mask (v_mbcnt) plus the scanned per-wave offset is its output position.
+__global__ __launch_bounds__(QH_BLOCK) void k_select_indices(const u64* mask, const u32* wave_offset, u64 nrows, u32* sel) {
+  const u64 nwords = (nrows + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 m = mask[j];
+    if ((m >> lane) & 1) sel[wave_offset[j] + (u32)qh_rank(m)] = (u32)(j * 64 + lane);
+  }
+}
+
+// number of kept rows before each boundary row (batch starts): one output batch per input batch (filter.rs:29-43)
+__global__ void k_mask_prefix_at(const u64* mask, const u32* wave_offset, const u64* rows, u32 n, u64 nrows, u32 total, u32* out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const u64 r = rows[k];
+  if (r >= nrows) { out[k] = total; return; }
+  const u64 j = r >> 6;
+  const u64 below = (r & 63) ? (mask[j] & ((1ULL << (r & 63)) - 1)) : 0ULL;
+  out[k] = wave_offset[j] + (u32)__builtin_popcountll(below);
+}
+
+// keep-mask from a bitmap of "visited" build rows (hash_join.rs:277-343): want_set selects visited / unvisited
+__global__ __launch_bounds__(QH_BLOCK) void k_mask_from_bits(const u32* bits, u64 nrows, int want_set, u64* mask, u32* wave_count) {
+  const u64 nwords = (nrows + 63) / 64;
+  for (u64 j = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; j < nwords; j += (u64)gridDim.x * QH_BLOCK) {
+    u64 m = (u64)bits[2 * j] | ((u64)bits[2 * j + 1] << 32);
+    if (!want_set) m = ~m;
+    const u64 rem = nrows - j * 64;
+    if (rem < 64) m &= (1ULL << rem) - 1;
+    mask[j] = m;
+    wave_count[j] = (u32)__builtin_popcountll(m);
+  }
+}
+
+// ================================================================ gather ("take") kernels
+// compute::take (hash.rs:65,79; hash_join.rs:192-199; utils/batch.rs:46,53): out[k] = in[idx[k]], NULL index -> NULL.
+template <class T>
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_fixed(const T* in, const u32* idx, T* out, u64 m) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    T v;
+    if (i == QH_NULL_IDX) memset(&v, 0, sizeof(T)); else v = in[i];
+    out[k] = v;
+  }
+}
+// validity (or Boolean values) of the gathered rows as one ballot word per 64 output rows, plus the set count
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_bits(const u8* bitmap /* null = all set */, const u32* idx, u64 m, u64* out_words,
+                                                         u32* set_count) {
+  const u64 nwords = (m + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  u32 local = 0;
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 k = j * 64 + lane;
+    bool bit = false;
+    if (k < m) {
+      const u32 i = idx[k];
+      bit = i != QH_NULL_IDX && (!bitmap || qh_bit(bitmap, i));
+    }
+    const u64 w = qh_ballot(bit);
+    if (lane == 0) { out_words[j] = w; local += (u32)__builtin_popcountll(w); }
+  }
+  if (lane == 0 && local) atomicAdd(set_count, local);
+}
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_utf8_lengths(const int* offsets, const u32* idx, u64 m, u32* out_len) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    out_len[k] = i == QH_NULL_IDX ? 0u : (u32)(offsets[i + 1] - offsets[i]);
+  }
+}
+// one wavefront per 64 output rows; every row's bytes are copied by its own lane (short strings: TPC-H flags,
+// segments), rows longer than 64 bytes are copied cooperatively by the whole wavefront afterwards
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_utf8_bytes(const int* offsets, const u8* data, const u32* idx, u64 m, const u32* out_off,
+                                                               u8* out_data) {
+  const u64 nwords = (m + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 k = j * 64 + lane;
+    u32 len = 0, src = 0, dst = 0;
+    if (k < m) {
+      const u32 i = idx[k];
+      if (i != QH_NULL_IDX) { src = (u32)offsets[i]; len = (u32)offsets[i + 1] - src; dst = out_off[k]; }
+    }
+    if (len <= 64) for (u32 b = 0; b < len; ++b) out_data[dst + b] = data[src + b];
+    u64 big = qh_ballot(len > 64);
+    while (big) {
+      const int l = __builtin_ctzll(big);
+      big &= big - 1;
+      const u32 s2 = qh_readlane32(src, l), d2 = qh_readlane32(dst, l), n2 = qh_readlane32(len, l);
+      for (u32 b = lane; b < n2; b += 64) out_data[d2 + b] = data[s2 + b];
+    }
+  }
+}
+__global__ void k_store_u32(u32* p, u32 v) { *p = v; }
+
+// ================================================================ hash join
+// JoinHashMap (physical/plan/join/hash_join.rs:39-107) keeps `hash -> last row + 1` and a `next` chain, built in
+// reverse so that chains ascend. Here: an open-addressing table keyed by the REAL key words (so there is no
+// candidate re-check, hash_join.rs:191-215) maps every distinct build key to a slot; rows are then grouped by slot
+// (stable radix sort => ascending row order inside a group, the order the reverse-built chains produce) into a
+// CSR layout (start/count per slot). NULL keys are never inserted and never probe (eq of NULL is NULL).
+template <int W>
+__global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys, const u64* keyvalid, u64 n, u64* table, u32 nslots,
+                                                               u32* row_slot, u32* count, u32* status) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    u32 sid = nslots;   // NULL key: sorts behind every real slot, never probed
+    if ((keyvalid[i >> 6] >> (i & 63)) & 1) {
+      u64 k[W];
+      u64 h = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { k[w] = keys[(size_t)w * n + i]; h = qh_mix64(h ^ k[w]); }
+      bool inserted;
+      u64* slot = qh_find_or_insert<MemHbm, W>(table, nslots, 1 + W, k, h, (int)nslots, &inserted);
+      if (!slot) atomicOr(&status[QS_OVERFLOW], 1u);
+      else {
+        sid = (u32)((slot - table) / (1 + W));
+        atomicAdd(&count[sid], 1u);
+      }
+    }
+    row_slot[i] = sid;
+  }
+}
+
+// read-only lookup after the build kernel has completed (plain cached loads)
+template <int W>
+__device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const u64* k) {
+  u64 h = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) h = qh_mix64(h ^ k[w]);
+  u32 s = (u32)h & (nslots - 1);
+  for (u32 probes = 0; probes < nslots; ++probes) {
+    const u64* slot = table + (size_t)s * (1 + W);
+    if (slot[0] != QH_READY) return QH_NULL_IDX;
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) eq &= slot[1 + w] == k[w];
+    if (eq) return s;
+    s = (s + 1) & (nslots - 1);
+  }
+  return QH_NULL_IDX;
+}
+
+// probe pass 1 (get_matches_indices + key equality, hash_join.rs:70-107,177-216): matches per probe row
+template <int W>
+__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_count(const u64* pkeys, const u64* pvalid, u64 np, const u64* table, u32 nslots,
+                                                              const u32* count, u32* out_slot, u32* out_cnt) {
+  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) {
+    u32 sid = QH_NULL_IDX, c = 0;
+    if ((pvalid[p >> 6] >> (p & 63)) & 1) {
+      u64 k[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) k[w] = pkeys[(size_t)w * np + p];
+      sid = qh_join_find<W>(table, nslots, k);
+      if (sid != QH_NULL_IDX) c = count[sid];
+    }
+    out_slot[p] = sid;
+    out_cnt[p] = c;
+  }
+}
+// probe pass 2: emit (build row, probe row) pairs — probe-row major, build rows ascending (hash_join.rs:475-512 pins it)
+__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_write(const u32* slot_of, const u32* pair_off, const u32* start, const u32* sorted_rows,
+                                                              const u32* cnt, u64 np, u32* b_idx, u32* p_idx) {
+  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) {
+    const u32 c = cnt[p];
+    if (!c) continue;
+    const u32 s0 = start[slot_of[p]], o = pair_off[p];
+    for (u32 k = 0; k < c; ++k) { b_idx[o + k] = sorted_rows[s0 + k]; p_idx[o + k] = (u32)p; }
+  }
+}
+// visited bitmap (hash_join.rs:166-167,253-255) and surviving-pair count per probe row
+__global__ __launch_bounds__(QH_BLOCK) void k_join_mark(const u32* b_idx, const u32* p_idx, u64 m, u32* visited_bits, u32* cnt_per_probe) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 b = b_idx[k];
+    if (b != QH_NULL_IDX) atomicOr(&visited_bits[b >> 5], 1u << (b & 31));
+    if (cnt_per_probe) atomicAdd(&cnt_per_probe[p_idx[k]], 1u);
+  }
+}
+// adjust_right_indices (join/mod.rs:176-207): probe rows without a surviving pair are emitted once with a NULL build index
+__global__ __launch_bounds__(QH_BLOCK) void k_join_out_counts(const u32* cnt, u64 np, u32* out_cnt) {
+  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) out_cnt[p] = cnt[p] ? cnt[p] : 1u;
+}
+__global__ __launch_bounds__(QH_BLOCK) void k_join_adjust_right(const u32* b_in, const u32* cnt, const u32* in_off, const u32* out_off, u64 np,
+                                                               u32* b_out, u32* p_out) {
+  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) {
+    const u32 c = cnt[p], o = out_off[p];
+    if (!c) { b_out[o] = QH_NULL_IDX; p_out[o] = (u32)p; continue; }
+    const u32 i0 = in_off[p];
+    for (u32 k = 0; k < c; ++k) { b_out[o + k] = b_in[i0 + k]; p_out[o + k] = (u32)p; }
+  }
+}
+__global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (u32)i;
+}
+__global__ __launch_bounds__(QH_BLOCK) void k_fill_u32(u32* out, u64 n, u32 v) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = v;
+}
+// out[k] = off[rows[k]] for boundary rows (batch starts), rows[k] == n -> total
+__global__ void k_lookup_u32(const u32* off, const u64* rows, u32 n, u64 nrows, u32 total, u32* out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = rows[k] >= nrows ? total : off[rows[k]];
+}
+// partition id per row from its key words (exchange): mix64 of the key, top bits -> [0, nparts)
+template <int W>
+__global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64 n, u32 nparts, u32* part, u32* hist) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    u64 h = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) h = qh_mix64(h ^ keys[(size_t)w * n + i]);
+    const u32 pid = (u32)(((h >> 32) * (u64)nparts) >> 32);
+    part[i] = pid;
+    atomicAdd(&hist[pid], 1u);
+  }
+}
+
+// ================================================================ host launchers
+void launch_select_indices(const uint64_t* mask, const uint32_t* wave_offset, uint64_t nrows, uint32_t* sel, hipStream_t s) {
+  if (!nrows) return;
+  hipLaunchKernelGGL(k_select_indices, dim3(grid_for((nrows + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u64*)mask, (const u32*)wave_offset,
+                     (u64)nrows, (u32*)sel);
+}
+void launch_mask_prefix_at(const uint64_t* mask, const uint32_t* wave_offset, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total,
+                           uint32_t* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_mask_prefix_at, dim3((n + 255) / 256), dim3(256), 0, s, (const u64*)mask, (const u32*)wave_offset, (const u64*)rows, n,
+                     (u64)nrows, total, (u32*)out);
+}
+void launch_mask_from_bits(const uint32_t* bits, uint64_t nrows, int want_set, uint64_t* mask, uint32_t* wave_count, hipStream_t s) {
+  if (!nrows) return;
+  hipLaunchKernelGGL(k_mask_from_bits, dim3(grid_for((nrows + 63) / 64)), dim3(QH_BLOCK), 0, s, (const u32*)bits, (u64)nrows, want_set, (u64*)mask,
+                     (u32*)wave_count);
+}
+void launch_gather_fixed(const void* in, const uint32_t* idx, void* out, uint64_t m, int width, hipStream_t s) {
+  if (!m) return;
+  const dim3 g(grid_for(m)), b(QH_BLOCK);
+  switch (width) {
+    case 1: hipLaunchKernelGGL(k_gather_fixed<u8>, g, b, 0, s, (const u8*)in, (const u32*)idx, (u8*)out, (u64)m); break;
+    case 2: hipLaunchKernelGGL(k_gather_fixed<u16>, g, b, 0, s, (const u16*)in, (const u32*)idx, (u16*)out, (u64)m); break;
+    case 4: hipLaunchKernelGGL(k_gather_fixed<u32>, g, b, 0, s, (const u32*)in, (const u32*)idx, (u32*)out, (u64)m); break;
+    case 8: hipLaunchKernelGGL(k_gather_fixed<u64>, g, b, 0, s, (const u64*)in, (const u32*)idx, (u64*)out, (u64)m); break;
+    default: hipLaunchKernelGGL(k_gather_fixed<u128>, g, b, 0, s, (const u128*)in, (const u32*)idx, (u128*)out, (u64)m); break;
+  }
+}
+void launch_gather_bits(const uint8_t* bitmap, const uint32_t* idx, uint64_t m, uint64_t* out_words, uint32_t* set_count, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(k_gather_bits, dim3(grid_for((m + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u8*)bitmap, (const u32*)idx, (u64)m,
+                     (u64*)out_words, (u32*)set_count);
+}
+void launch_gather_utf8_lengths(const int32_t* offsets, const uint32_t* idx, uint64_t m, uint32_t* out_len, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(k_gather_utf8_lengths, dim3(grid_for(m)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (const u32*)idx, (u64)m, (u32*)out_len);
+}
+void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const uint32_t* idx, uint64_t m, const uint32_t* out_off,
+                              uint8_t* out_data, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(k_gather_utf8_bytes, dim3(grid_for((m + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (const u8*)data,
+                     (const u32*)idx, (u64)m, (const u32*)out_off, (u8*)out_data);
+}
+void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, (u32*)p, v); }
+void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n);
+}
+void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, v);
+}
+void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total, uint32_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_lookup_u32, dim3((n + 255) / 256), dim3(256), 0, s, (const u32*)off, (const u64*)rows, n, (u64)nrows, total, (u32*)out);
+}
+
+#define DISPATCH_W(W, CALL)                \
+  switch (W) {                             \
+    case 1: { constexpr int KW = 1; CALL; } break; \
+    case 2: { constexpr int KW = 2; CALL; } break; \
+    case 3: { constexpr int KW = 3; CALL; } break; \
+    case 4: { constexpr int KW = 4; CALL; } break; \
+    case 5: { constexpr int KW = 5; CALL; } break; \
+    case 6: { constexpr int KW = 6; CALL; } break; \
+    case 7: { constexpr int KW = 7; CALL; } break; \
+    default: { constexpr int KW = 8; CALL; } break; \
+  }
+
+void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
+                              uint32_t* row_slot, uint32_t* count, uint32_t* status, hipStream_t s) {
+  if (!n) return;
+  DISPATCH_W(W, hipLaunchKernelGGL(k_join_build_insert<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (const u64*)keyvalid, (u64)n,
+                                   (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)status));
+}
+void launch_join_probe_count(int W, const uint64_t* pkeys, const uint64_t* pvalid, uint64_t np, const uint64_t* table, uint32_t nslots,
+                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, hipStream_t s) {
+  if (!np) return;
+  DISPATCH_W(W, hipLaunchKernelGGL(k_join_probe_count<KW>, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u64*)pkeys, (const u64*)pvalid, (u64)np,
+                                   (const u64*)table, nslots, (const u32*)count, (u32*)out_slot, (u32*)out_cnt));
+}
+void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* pair_off, const uint32_t* start, const uint32_t* sorted_rows,
+                             const uint32_t* cnt, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s) {
+  if (!np) return;
+  hipLaunchKernelGGL(k_join_probe_write, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)pair_off, (const u32*)start,
+                     (const u32*)sorted_rows, (const u32*)cnt, (u64)np, (u32*)b_idx, (u32*)p_idx);
+}
+void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(k_join_mark, dim3(grid_for(m)), dim3(QH_BLOCK), 0, s, (const u32*)b_idx, (const u32*)p_idx, (u64)m, (u32*)visited_bits,
+                     (u32*)cnt_per_probe);
+}
+void launch_join_out_counts(const uint32_t* cnt, uint64_t np, uint32_t* out_cnt, hipStream_t s) {
+  if (np) hipLaunchKernelGGL(k_join_out_counts, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)cnt, (u64)np, (u32*)out_cnt);
+}
+void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const uint32_t* in_off, const uint32_t* out_off, uint64_t np,
+                              uint32_t* b_out, uint32_t* p_out, hipStream_t s) {
+  if (np) hipLaunchKernelGGL(k_join_adjust_right, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)b_in, (const u32*)cnt, (const u32*)in_off,
+                             (const u32*)out_off, (u64)np, (u32*)b_out, (u32*)p_out);
+}
+void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s) {
+  if (!n) return;
+  DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
+}
+
+// stable sort of (key, value) pairs on the low `bits` bits of the key (rocPRIM LSD radix sort): groups build rows by
+// hash-table slot / rows by partition id while keeping ascending row order inside a group
+void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
+                           hipStream_t s) {
+  if (!n) return;
+  size_t tmp_bytes = 0;
+  rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
+  void* tmp = nullptr;
+  hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
+  hipStreamSynchronize(s);
+  hipFree(tmp);
+}
+
+}  // namespace qhip

@@ -1,0 +1,119 @@
+// relops.cpp — host-side building blocks shared by Filter, HashJoinExec and the exchange: predicate -> keep mask
+// (JIT), mask -> selection vector (scan + ballot rank), row gather of whole columns, key-word evaluation (JIT).
+#include "relops.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include "device/qhip_status.h"
+#include "jit.hpp"
+#include "kernels.hpp"
+
+namespace qhip {
+
+void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, int root, DevBuf& mask,
+                   DevBuf& wave_count) {
+  const int64_t N = t->num_rows;
+  const uint64_t nwords = (uint64_t)(N + 63) / 64;
+  mask.alloc(nwords * 8);
+  wave_count.alloc((nwords + 1) * 4);
+  if (N == 0) return;
+  MaskPlan mp;
+  plan_predicate_mask(es, icols, root, mp);
+  std::shared_ptr<Module> mod = get_module(ctx, mp.source, mp.kernel_name);
+  HKArgs ka;
+  DevBuf strlit;
+  fill_kargs(ctx, t, mp.bind, ka, strlit);
+  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+  void* mptr = mask.ptr;
+  void* wptr = wave_count.ptr;
+  void* sptr = ctx->status.ptr;
+  void* args[] = {&ka, &mptr, &wptr, &sptr};
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
+  QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  uint32_t status[QS_WORDS];
+  QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  check_status_words(status);
+}
+
+uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel) {
+  const uint64_t nwords = (uint64_t)(nrows + 63) / 64;
+  if (nrows == 0) { sel.alloc(0); return 0; }
+  DevBuf total(4);
+  exclusive_scan_u32(wave_count.as<uint32_t>(), wave_count.as<uint32_t>(), nwords, total.as<uint32_t>(), ctx->stream);
+  uint32_t m = 0;
+  QHIP_HIP_CHECK(hipMemcpy(&m, total.ptr, 4, hipMemcpyDeviceToHost));
+  sel.alloc((size_t)m * 4);
+  launch_select_indices(mask.as<uint64_t>(), wave_count.as<uint32_t>(), (uint64_t)nrows, sel.as<uint32_t>(), ctx->stream);
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return m;
+}
+
+DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null) {
+  DevColumn out;
+  out.type = col.type;
+  out.length = (int64_t)m;
+  if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return out; }
+  DevBuf counter(4);
+  if (col.null_count > 0 || idx_may_be_null) {
+    auto words = std::make_shared<DevBuf>(((m + 63) / 64) * 8 + 8);
+    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 4, ctx->stream));
+    launch_gather_bits(col.validity ? col.validity->as<uint8_t>() : nullptr, idx, m, words->as<uint64_t>(), counter.as<uint32_t>(), ctx->stream);
+    uint32_t set = 0;
+    QHIP_HIP_CHECK(hipMemcpyAsync(&set, counter.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    out.null_count = (int64_t)m - (int64_t)set;
+    if (out.null_count > 0) out.validity = words;
+  }
+  const int w = dtype_width(col.type);
+  if (w > 0) {
+    out.values = std::make_shared<DevBuf>((size_t)m * w);
+    launch_gather_fixed(col.values->ptr, idx, out.values->ptr, m, w, ctx->stream);
+  } else if (col.type.id == QHIP_BOOL) {
+    out.values = std::make_shared<DevBuf>(((m + 63) / 64) * 8 + 8);
+    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 4, ctx->stream));
+    launch_gather_bits(col.values->as<uint8_t>(), idx, m, out.values->as<uint64_t>(), counter.as<uint32_t>(), ctx->stream);
+  } else if (col.type.id == QHIP_UTF8) {
+    out.values = std::make_shared<DevBuf>((size_t)(m + 1) * 4);
+    uint32_t* off = out.values->as<uint32_t>();
+    launch_gather_utf8_lengths(col.values->as<int32_t>(), idx, m, off, ctx->stream);
+    DevBuf total(4);
+    exclusive_scan_u32(off, off, m, total.as<uint32_t>(), ctx->stream);
+    uint32_t nbytes = 0;
+    QHIP_HIP_CHECK(hipMemcpy(&nbytes, total.ptr, 4, hipMemcpyDeviceToHost));
+    if (nbytes > 0x7fffffffu) fail(QHIP_UNSUPPORTED, "gathered Utf8 column exceeds 2 GiB");
+    QHIP_HIP_CHECK(hipMemcpyAsync(off + m, total.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    out.data = std::make_shared<DevBuf>((size_t)nbytes);
+    out.data_bytes = nbytes;
+    launch_gather_utf8_bytes(col.values->as<int32_t>(), col.data->as<uint8_t>(), idx, m, off, out.data->as<uint8_t>(), ctx->stream);
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return out;
+}
+
+void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid) {
+  plan_keys(es, icols, roots, n, kp);
+  const int64_t N = t->num_rows;
+  const uint64_t nwords = (uint64_t)(N + 63) / 64;
+  keys.alloc((size_t)kp.W * (size_t)N * 8);
+  keyvalid.alloc(nwords * 8 + 8);
+  if (N == 0) return;
+  std::shared_ptr<Module> mod = get_module(ctx, kp.source, kp.kernel_name);
+  HKArgs ka;
+  DevBuf strlit;
+  fill_kargs(ctx, t, kp.bind, ka, strlit);
+  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+  void* kptr = keys.ptr;
+  void* vptr = keyvalid.ptr;
+  void* sptr = ctx->status.ptr;
+  void* args[] = {&ka, &kptr, &vptr, &sptr};
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
+  QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  uint32_t status[QS_WORDS];
+  QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  check_status_words(status);
+}
+
+}  // namespace qhip

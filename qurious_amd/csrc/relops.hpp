@@ -1,0 +1,28 @@
+// relops.hpp — shared host-side building blocks (see relops.cpp) + helpers defined in agg.cpp.
+#pragma once
+#include <vector>
+
+#include "codegen.hpp"
+#include "common.hpp"
+#include "kargs_host.hpp"
+
+namespace qhip {
+
+// agg.cpp
+std::vector<InputCol> input_cols_of(const qhip_table* t);
+void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& a, DevBuf& strlit_dev);
+void check_status_words(const uint32_t* st);
+
+// relops.cpp
+// keep-mask of `root` over every row of t: mask word j = ballot of rows 64j..64j+63, wave_count[j] = its popcount
+void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, int root, DevBuf& mask,
+                   DevBuf& wave_count);
+// wave_count is scanned in place into per-wave output offsets; sel receives the kept row indices; returns their number
+uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel);
+// out[k] = col[idx[k]] (device u32 indices, kNullIdx -> NULL when idx_may_be_null)
+DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null);
+// key words [W][N] + validity bitmap of the key expressions `roots`
+void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid);
+
+}  // namespace qhip
