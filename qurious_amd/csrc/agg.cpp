@@ -133,7 +133,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   ExprSet es;
   es.build(exprs, n_exprs, icols);
   AggPlan plan;
-  plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, env_int("QHIP_AGG_R", 4), plan);
+  plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, env_int("QHIP_AGG_R", 0), plan);
 
   // output schema: keys then aggregates (hash.rs:166-169)
   std::vector<std::string> names;

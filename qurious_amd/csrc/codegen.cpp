@@ -497,6 +497,19 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   int off = 0;
   for (auto& c : P.cells) { c.off = off; off += c.words; }
   P.slot_words = 1 + P.W + off;
+  if (P.R <= 0) {
+    // rows per thread per tile: as many as the register file takes comfortably. The per-tile cost of the wave-level
+    // key dedup is independent of R, so larger tiles amortise it (measured on MI355X, q1_mini: R=4 3.7 TB/s, R=8 4.7 TB/s;
+    // q1_full spills at R=8). Estimate: one Row costs 1 + 2 W + (argument dwords) VGPRs.
+    int row_regs = 1 + 2 * P.W;
+    for (size_t a = 0; a < P.args.size(); ++a) {
+      bool value_needed = false;
+      for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
+      if (value_needed) row_regs += std::max(1, dtype_width(P.args[a].type) / 4);
+      if (P.args[a].nullable) row_regs += 1;
+    }
+    P.R = row_regs <= 10 ? 8 : row_regs <= 28 ? 4 : row_regs <= 56 ? 2 : 1;
+  }
 
   // ---- source
   ExprGen g(es, input);

@@ -33,7 +33,7 @@ int qhip_plan_aggregate_source(const qhip_dtype* col_types, const int32_t* col_h
     ExprSet es; es.build(exprs, n_exprs, in);
     AggPlan p;
     const char* r = getenv("QHIP_AGG_R");
-    plan_aggregate(es, in, predicate_root, group_roots, n_groups, aggs, n_aggs, r && *r ? atoi(r) : 4, p);
+    plan_aggregate(es, in, predicate_root, group_roots, n_groups, aggs, n_aggs, r && *r ? atoi(r) : 0, p);
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }

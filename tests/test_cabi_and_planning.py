@@ -1,0 +1,111 @@
+"""CPU-only checks of the drop-in boundary and the host logic: the C ABI exports every symbol include/qhip.h declares,
+the library refuses to run without a GPU (no fallback), plans are typed like arrow-rs types them, generated kernel
+source is literal-independent and compiles for gfx950 (hiprtc cross-compiles without a GPU)."""
+import ctypes
+import os
+import re
+
+import pyarrow as pa
+import pytest
+
+import qurious_amd as q
+from qurious_amd import Operator, planning, queries, synth
+from qurious_amd import ScalarValue as S
+
+from .helpers import col, lit_i64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "qhip.h")).read()
+    names = set(re.findall(r"^(?:int64_t|int|void|const char\*)\s+(qhip_[a-z0-9_]+)\s*\(", header, re.M))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(os.path.join(ROOT, "qurious_amd", "libqhip.so"))
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/qhip.h but not exported by libqhip.so: {missing}"
+
+
+def test_no_cpu_fallback_without_device():
+    lib = q.load_library()
+    if lib.qhip_device_available():
+        pytest.skip("a HIP device is visible: the loud-failure path cannot be exercised here")
+    with pytest.raises(q.HipError, match="no CPU fallback"):
+        q.Context(0)
+
+
+def test_product_never_touches_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "qurious_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "qoracle" not in text and "liboracle" not in text, f"{f} references the oracle"
+
+
+def test_q1_plan_shapes():
+    table = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, [])
+    mini = queries.q1_mini(table)
+    src = planning.aggregate_source(synth.LINEITEM_SCHEMA, mini.input.filter, mini.group_exprs, mini.aggregate_exprs)
+    assert "static constexpr int W = 1;" in src and "qk_filter_agg" in src
+    assert "10470" not in src                     # the literal travels in KArgs.lit_lo, not in the kernel text
+    full = queries.q1_full(table)
+    src = planning.aggregate_source(synth.LINEITEM_SCHEMA, full.input.filter, full.group_exprs, full.aggregate_exprs)
+    assert "static constexpr int W = 2;" in src
+    # SUM(qty)/AVG(qty) and SUM(price)/AVG(price) share cells; COUNT(1) uses the row counter: 5 i128 sums + rows
+    assert src.count("qh_wave_sum_i128") == 5 and "static constexpr int SLOT_WORDS = 14;" in src
+
+
+def test_kernel_source_is_literal_independent():
+    pred = lambda day: q.BinaryExpr(q.Column("l_shipdate", 0), Operator.Lt, q.CastExpr(q.Literal(S.Utf8(day)), pa.date32()))
+    a = planning.filter_source(synth.LINEITEM_SCHEMA, pred("1998-09-01"))
+    b = planning.filter_source(synth.LINEITEM_SCHEMA, pred("1995-03-15"))
+    assert a == b
+
+
+def test_type_rules_and_errors_at_plan_time():
+    schema = pa.schema([pa.field("a", pa.int64()), pa.field("b", pa.int32()), pa.field("d", pa.decimal128(15, 2)), pa.field("s", pa.string())])
+    with pytest.raises(q.QuriousError, match="Invalid comparison operation: Int64 == Int32"):
+        planning.filter_source(schema, q.BinaryExpr(col("a", 0), Operator.Eq, col("b", 1)))
+    with pytest.raises(q.QuriousError, match="Invalid arithmetic operation"):
+        planning.filter_source(schema, q.BinaryExpr(q.BinaryExpr(col("a", 0), Operator.Add, col("b", 1)), Operator.Gt, lit_i64(0)))
+    with pytest.raises(q.QuriousError, match="must be Boolean"):
+        planning.filter_source(schema, q.BinaryExpr(col("a", 0), Operator.Add, lit_i64(1)))
+    with pytest.raises(q.QuriousError, match="Cannot cast string 'not-a-date'"):
+        planning.filter_source(schema, q.BinaryExpr(q.CastExpr(col("b", 1), pa.date32()), Operator.Lt,
+                                                    q.CastExpr(q.Literal(S.Utf8("not-a-date")), pa.date32())))
+    with pytest.raises(q.QuriousError, match="Unsupported data type in hasher: Float64"):
+        planning.keys_source(pa.schema([pa.field("f", pa.float64())]), [col("f", 0)])
+    with pytest.raises(q.QuriousError, match="column at index 9"):
+        planning.filter_source(schema, q.BinaryExpr(col("zz", 9), Operator.Gt, lit_i64(0)))
+    # Decimal128 result types of arrow-rs: (20,0)-(15,2) -> (23,2); (15,2)*(23,2) -> (38,4)
+    one = q.CastExpr(q.Literal(S.Int64(1)), pa.decimal128(20, 0))
+    e = q.BinaryExpr(col("d", 2), Operator.Mul, q.BinaryExpr(one, Operator.Sub, col("d", 2)))
+    src = planning.aggregate_source(schema, None, [col("a", 0)], [q.SumAggregateExpr(e, pa.decimal128(38, 4))])
+    assert "qh_acc_add_i128" in src
+    with pytest.raises(q.QuriousError, match="does not match return type"):
+        planning.aggregate_source(schema, None, [col("a", 0)], [q.SumAggregateExpr(e, pa.decimal128(15, 2).__class__ and pa.int64())])
+
+
+def test_generated_kernels_compile_for_gfx950(tmp_path):
+    schema = pa.schema([pa.field("k", pa.int64()), pa.field("v", pa.float64()), pa.field("s", pa.string())])
+    pred = q.BinaryExpr(q.BinaryExpr(col("s", 2), Operator.NotEq, q.Literal(S.Utf8("x"))), Operator.And,
+                        q.BinaryExpr(col("v", 1), Operator.GtEq, q.Literal(S.Float64(0.0))))
+    aggs = [q.SumAggregateExpr(col("v", 1), pa.float64()), q.MinAggregateExpr(col("k", 0), pa.int64()),
+            q.AvgAggregateExpr(col("v", 1), pa.float64(), pa.float64()), q.CountAggregateExpr(col("s", 2))]
+    for nulls in (None, [True, True, True]):
+        src = planning.aggregate_source(schema, pred, [col("k", 0)], aggs, has_nulls=nulls)
+        planning.compile_to_cache(src, str(tmp_path))
+    planning.compile_to_cache(planning.keys_source(schema, [col("k", 0), col("s", 2)], has_nulls=[True, False, True]), str(tmp_path))
+    assert len(os.listdir(tmp_path)) == 3
+
+
+def test_synthetic_lineitem_is_counter_based():
+    a = synth.lineitem_batch(0, 3000)
+    b = pa.concat_batches([synth.lineitem_batch(0, 1000), synth.lineitem_batch(1000, 2000)])
+    assert a.equals(b)
+    flags = set(a.column("l_returnflag").to_pylist())
+    assert flags == {"A", "N", "R"}
+    d = a.column("l_shipdate").cast(pa.int32()).to_pylist()
+    assert min(d) >= 8036 and max(d) <= 8036 + 2525
+    qty = a.column("l_quantity").to_pylist()
+    assert all(1 <= x <= 50 for x in qty)
