@@ -287,6 +287,14 @@ int qhip_synth_lineitem(int64_t first_row, int64_t n_rows,
                         int32_t* l_shipdate, int32_t* l_returnflag_offsets, uint8_t* l_returnflag_data,
                         int32_t* l_linestatus_offsets, uint8_t* l_linestatus_data,
                         void* l_quantity /* i128[] */, void* l_extendedprice, void* l_discount, void* l_tax);
+/* Q3 tables: customers first_key.. (c_custkey 1-based; seg_data holds 10*n bytes), orders with ordinal first_k.. (TPC-H's
+ * sparse o_orderkey, o_custkey uniform over 1..n_customers), and the 1..7 lineitems of those orders in order. */
+int qhip_synth_customer(int64_t first_key, int64_t n, int64_t* c_custkey, int32_t* seg_offsets, uint8_t* seg_data);
+int qhip_synth_orders(int64_t first_k, int64_t n, int64_t n_customers, int64_t* o_orderkey, int64_t* o_custkey,
+                      int32_t* o_orderdate, int64_t* o_shippriority);
+int64_t qhip_synth_q3_lineitem_count(int64_t first_k, int64_t n_orders);
+int qhip_synth_q3_lineitem(int64_t first_k, int64_t n_orders, int64_t* l_orderkey, int32_t* l_shipdate,
+                           void* l_extendedprice, void* l_discount);
 
 #ifdef __cplusplus
 }

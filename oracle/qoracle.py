@@ -500,3 +500,51 @@ def scan_filter_aggregate_timed(plan: "P.HashAggregate"):
         L.qo_agg_result_free(C.byref(res))
     batch = pa.RecordBatch.from_arrays(out_cols, names=[f"c{k}" for k in range(len(out_cols))])
     return batch, dt, int(rows.sum())
+
+
+# ---------------------------------------------------------------- exchange mirror (tests of the multi-GPU path on CPUs)
+def _mix64(x: np.ndarray) -> np.ndarray:
+    x = x.copy()
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xff51afd7ed558ccd)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xc4ceb9fe1a85ec53)
+    x ^= x >> np.uint64(33)
+    return x
+
+
+def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
+    """numpy restatement of qhip_partition_by_key's row -> part mapping (csrc/kernels_rel.hip k_partition_ids over the key
+    words of csrc/codegen.cpp emit_key_words): ints/dates sign-extended to 64 bits, Decimal128 as (lo, hi), Utf8 <= 7 bytes
+    packed (bytes | len << 56); a row with any NULL key has all its key words zeroed."""
+    n = len(key_arrays[0])
+    words = []
+    valid = np.ones(n, dtype=bool)
+    for a in key_arrays:
+        if isinstance(a, pa.ChunkedArray):
+            a = a.combine_chunks()
+        if a.null_count:
+            valid &= np.array(a.is_valid())
+        t = a.type
+        if pa.types.is_string(t):
+            w = np.zeros(n, dtype=np.uint64)
+            for i, s in enumerate(a.to_pylist()):
+                if s is None:
+                    continue
+                b = s.encode()
+                assert len(b) <= 7
+                w[i] = int.from_bytes(b, "little") | (len(b) << 56)
+            words.append(w)
+        elif pa.types.is_decimal128(t):
+            raw = np.frombuffer(a.buffers()[1], dtype=np.uint64).reshape(-1, 2)[a.offset:a.offset + n]
+            words.append(raw[:, 0].copy())
+            words.append(raw[:, 1].copy())
+        else:
+            v = np.array(a.cast(pa.int64() if not pa.types.is_date32(t) else pa.int32()).fill_null(0)).astype(np.int64)
+            words.append(v.view(np.uint64).copy())
+    h = np.zeros(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for w in words:
+            h = _mix64(h ^ np.where(valid, w, np.uint64(0)))
+        pid = ((h >> np.uint64(32)) * np.uint64(n_parts)) >> np.uint64(32)
+    return pid.astype(np.int64)

@@ -138,6 +138,10 @@ def load_library() -> C.CDLL:
             "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
             "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),
             "qhip_synth_lineitem": (C.c_int, [i64, i64] + [vp] * 9),
+            "qhip_synth_customer": (C.c_int, [i64, i64, vp, vp, vp]),
+            "qhip_synth_orders": (C.c_int, [i64, i64, i64, vp, vp, vp, vp]),
+            "qhip_synth_q3_lineitem_count": (i64, [i64, i64]),
+            "qhip_synth_q3_lineitem": (C.c_int, [i64, i64, vp, vp, vp, vp]),
             "qhip_jit_compile_to_cache": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
         }
         for name, (res, args) in sigs.items():

@@ -47,3 +47,73 @@ extern "C" int qhip_synth_lineitem(int64_t first_row, int64_t n_rows, int32_t* l
   if (l_linestatus_offsets) l_linestatus_offsets[n_rows] = (int32_t)n_rows;
   return QHIP_OK;
 }
+
+// ---------------------------------------------------------------- Q3 tables: customer, orders, lineitem-of-orders
+namespace {
+const char* const kSegments[5] = {"AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"};
+inline int64_t sparse_orderkey(int64_t k) { return ((k - 1) / 8) * 32 + (k - 1) % 8 + 1; }   // TPC-H's sparse o_orderkey
+inline int lines_of(int64_t k) { return 1 + (int)(u((uint64_t)k, 11) % 7); }
+inline int32_t orderdate_of(int64_t k) { return 8035 + (int32_t)(u((uint64_t)k, 10) % 2406); }
+}  // namespace
+
+extern "C" {
+
+// customers first_key .. first_key + n - 1 (c_custkey is 1-based); seg_data must hold 10 * n bytes
+int qhip_synth_customer(int64_t first_key, int64_t n, int64_t* c_custkey, int32_t* seg_offsets, uint8_t* seg_data) {
+  if (first_key < 1 || n < 0) return QHIP_INVALID_ARGUMENT;
+  int32_t pos = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t key = first_key + i;
+    c_custkey[i] = key;
+    const char* s = kSegments[u((uint64_t)key, 8) % 5];
+    seg_offsets[i] = pos;
+    const size_t len = strlen(s);
+    memcpy(seg_data + pos, s, len);
+    pos += (int32_t)len;
+  }
+  seg_offsets[n] = pos;
+  return QHIP_OK;
+}
+
+// orders with ordinal first_k .. first_k + n - 1 (1-based); o_custkey uniform over 1..n_customers
+int qhip_synth_orders(int64_t first_k, int64_t n, int64_t n_customers, int64_t* o_orderkey, int64_t* o_custkey, int32_t* o_orderdate,
+                      int64_t* o_shippriority) {
+  if (first_k < 1 || n < 0 || n_customers < 1) return QHIP_INVALID_ARGUMENT;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t k = first_k + i;
+    o_orderkey[i] = sparse_orderkey(k);
+    o_custkey[i] = 1 + (int64_t)(u((uint64_t)k, 9) % (uint64_t)n_customers);
+    o_orderdate[i] = orderdate_of(k);
+    o_shippriority[i] = 0;
+  }
+  return QHIP_OK;
+}
+
+int64_t qhip_synth_q3_lineitem_count(int64_t first_k, int64_t n_orders) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < n_orders; ++i) c += lines_of(first_k + i);
+  return c;
+}
+
+// the 1..7 lineitems of orders first_k .. first_k + n_orders - 1, in order; buffers sized by qhip_synth_q3_lineitem_count
+int qhip_synth_q3_lineitem(int64_t first_k, int64_t n_orders, int64_t* l_orderkey, int32_t* l_shipdate, void* l_extendedprice,
+                           void* l_discount) {
+  if (first_k < 1 || n_orders < 0) return QHIP_INVALID_ARGUMENT;
+  int64_t r = 0;
+  for (int64_t i = 0; i < n_orders; ++i) {
+    const int64_t k = first_k + i;
+    const int nl = lines_of(k);
+    const int64_t okey = sparse_orderkey(k);
+    const int32_t od = orderdate_of(k);
+    for (int l = 0; l < nl; ++l, ++r) {
+      const uint64_t id = (uint64_t)k * 8 + (uint64_t)l;
+      l_orderkey[r] = okey;
+      l_shipdate[r] = od + 1 + (int32_t)(u(id, 12) % 121);
+      put_i128(l_extendedprice, r, 90100 + (int64_t)(u(id, 13) % 10404900));
+      put_i128(l_discount, r, (int64_t)(u(id, 14) % 11));
+    }
+  }
+  return QHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""Multi-GPU hash-join exchange: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI; "gloo" on CPUs for tests) moves the bytes, libqhip does everything else on the device.
+
+The reference has no exchange operator (it is a single process); this is the only place the path is partitioned:
+
+    local slice of each join input --qhip_partition_by_key--> world parts (equal keys -> same part on every rank)
+        --grouped send/recv (all-to-all; xGMI is point-to-point, so all 7 links of a GPU carry one peer each)-->
+    parts received from every peer --qhip_table_from_device + qhip_table_concat--> local join input
+        --qhip_hash_join_execute--> local slice of the join result
+
+No collective is used for the aggregate after Q3's joins: its GROUP BY contains the join key, so groups are disjoint
+across ranks and the result is the union of the ranks' results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+from . import _ffi
+from ._ffi import DeviceTable
+from .datatypes import JoinType, to_qhip_dtype
+from .expr import ExprArray, PhysicalExpr, int32_array
+from .plan import HashJoinExec, PhysicalPlan
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None) -> List["torch.Tensor"]:
+    """Variable-size all-to-all of uint8 tensors: send[r] goes to rank r, the result's entry r came from rank r.
+    Built from grouped point-to-point sends/receives (``batch_isend_irecv``: one ncclGroup of ncclSend/ncclRecv on RCCL,
+    plain pairs on gloo), sizes first. Works for CPU tensors over gloo and GPU tensors over RCCL alike."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(send) == world
+    dev = send[0].device
+    sizes_out = [torch.tensor([s.numel()], dtype=torch.int64, device=dev) for s in send]
+    sizes_in = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    ops = []
+    for r in range(world):
+        if r == rank:
+            sizes_in[r].copy_(sizes_out[r])
+            continue
+        ops.append(dist.P2POp(dist.isend, sizes_out[r], r, group))
+        ops.append(dist.P2POp(dist.irecv, sizes_in[r], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    recv = [torch.empty(int(sizes_in[r].item()), dtype=torch.uint8, device=dev) for r in range(world)]
+    ops = []
+    for r in range(world):
+        if r == rank:
+            recv[r].copy_(send[r])
+            continue
+        if send[r].numel():
+            ops.append(dist.P2POp(dist.isend, send[r], r, group))
+        if recv[r].numel():
+            ops.append(dist.P2POp(dist.irecv, recv[r], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return recv
+
+
+class _DevMem:
+    """Zero-copy view of device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _column_buffers(t: DeviceTable, col: int):
+    """[(device pointer, bytes)] for values/offsets, validity, utf8 data of column `col`."""
+    out = []
+    for which in range(3):
+        p, n = C.c_void_p(), C.c_int64()
+        t.ctx.check(t.ctx.lib.qhip_table_column_buffer(t.handle, col, which, C.byref(p), C.byref(n)))
+        out.append((p.value or 0, n.value))
+    return out
+
+
+class qhip_device_column(C.Structure):
+    _fields_ = [("dtype", _ffi.qhip_dtype), ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                ("validity", C.c_void_p), ("data", C.c_void_p), ("data_bytes", C.c_int64)]
+
+
+def partition_by_key(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts: int) -> List[DeviceTable]:
+    ctx = table.ctx
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    arr, n = ea.c_array()
+    outs = (C.c_void_p * n_parts)()
+    ctx.check(ctx.lib.qhip_partition_by_key(ctx.handle, table.handle, arr, n, int32_array(roots), len(roots), n_parts, outs))
+    return [DeviceTable(ctx, C.c_void_p(outs[p])) for p in range(n_parts)]
+
+
+def concat_tables(tables: Sequence[DeviceTable]) -> DeviceTable:
+    ctx = tables[0].ctx
+    hs = (C.c_void_p * len(tables))(*[t.handle for t in tables])
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_table_concat(ctx.handle, hs, len(tables), C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+def _table_from_buffers(ctx, schema, rows: int, meta, bufs) -> DeviceTable:
+    """meta[c] = (null_count, data_bytes); bufs[c] = [values, validity, data] uint8 device tensors"""
+    ncols = len(schema)
+    cols = (qhip_device_column * max(1, ncols))()
+    names = (C.c_char_p * max(1, ncols))(*[f.name.encode() for f in schema])
+    for c, f in enumerate(schema):
+        cols[c].dtype = to_qhip_dtype(f.type)
+        cols[c].length = rows
+        cols[c].null_count = meta[c][0]
+        cols[c].data_bytes = meta[c][1]
+        v, n, d = bufs[c]
+        cols[c].values = v.data_ptr() if v.numel() else None
+        cols[c].validity = n.data_ptr() if n.numel() else None
+        cols[c].data = d.data_ptr() if d.numel() else None
+    out = C.c_void_p()
+    fn = ctx.lib.qhip_table_from_device
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(qhip_device_column), C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]
+    ctx.check(fn(ctx.handle, names, cols, ncols, rows, C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> DeviceTable:
+    """parts[r] is sent to rank r; returns the concatenation (in rank order) of what every rank sent to this one."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    assert len(parts) == world
+    ctx = parts[0].ctx
+    ncols = len(schema)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    # metadata: rows, then per column (null_count, data_bytes)
+    metas = []
+    for p in parts:
+        m = [p.num_rows]
+        for c in range(ncols):
+            n_null = C.c_int64(0)
+            # null counts are not exported separately: validity buffer present <=> nulls may exist; count recomputed by the receiver
+            bufs = _column_buffers(p, c)
+            m += [1 if bufs[1][1] else 0, bufs[2][1]]
+        metas.append(torch.tensor(m, dtype=torch.int64, device=dev).view(torch.uint8))
+    metas_in = [t.view(torch.int64).tolist() for t in all_to_all_bytes(metas, group)]
+    recv_bufs = [[[None, None, None] for _ in range(ncols)] for _ in range(world)]
+    for c in range(ncols):
+        for which in range(3):
+            send = []
+            for p in parts:
+                ptr, nb = _column_buffers(p, c)[which]
+                send.append(torch.as_tensor(_DevMem(ptr, nb), device=dev) if nb else torch.empty(0, dtype=torch.uint8, device=dev))
+            got = all_to_all_bytes(send, group)
+            for r in range(world):
+                recv_bufs[r][c][which] = got[r]
+    tables = []
+    for r in range(world):
+        rows = metas_in[r][0]
+        meta = [(rows if metas_in[r][1 + 2 * c] else 0, metas_in[r][2 + 2 * c]) for c in range(ncols)]
+        tables.append(_table_from_buffers(ctx, schema, rows, meta, recv_bufs[r]))
+    return concat_tables(tables)
+
+
+class DeviceSource(PhysicalPlan):
+    """A plan leaf over an already device-resident table (used to feed exchanged tables to HashJoinExec)."""
+
+    def __init__(self, schema, table: DeviceTable):
+        self._schema, self.table = schema, table
+
+    def schema(self):
+        return self._schema
+
+    def execute_device(self) -> DeviceTable:
+        return self.table
+
+
+class DistributedHashJoinExec(HashJoinExec):
+    """HashJoinExec whose inputs are this rank's slices: both sides are repartitioned by the join key across the ranks of
+    ``torch.distributed``'s default group, then joined locally. Row order across ranks is not the single-process order
+    (the north star asks for row-SET equality); inside a rank the reference's order holds."""
+
+    def execute_device(self) -> DeviceTable:
+        dist = _dist()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        lt = self.left.execute_device()
+        rt = self.right.execute_device()
+        if world > 1:
+            lparts = partition_by_key(lt, [l for l, _ in self.on], world)
+            rparts = partition_by_key(rt, [r for _, r in self.on], world)
+            lt = exchange_device_tables(lparts, self.left.schema())
+            rt = exchange_device_tables(rparts, self.right.schema())
+        local = HashJoinExec(DeviceSource(self.left.schema(), lt), DeviceSource(self.right.schema(), rt), self.join_type, self.on,
+                             self.filter, self._schema, self.column_indices)
+        return HashJoinExec.execute_device(local)
+
+    @staticmethod
+    def try_new(left, right, join_type, on, filter=None) -> "DistributedHashJoinExec":
+        base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
+        return DistributedHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)

@@ -42,3 +42,28 @@ def q1_full(table: MemoryTable) -> HashAggregate:
     types = [pa.string(), pa.string(), DEC, DEC, t4, t6] + [avg_return_type(DEC)] * 3 + [pa.int64()]
     schema = pa.schema([pa.field(n, t) for n, t in zip(names, types)])
     return HashAggregate(schema, scan, [Column("l_returnflag", 1), Column("l_linestatus", 2)], aggs)
+
+
+def q3(customer, orders, lineitem, join_cls=None):
+    """configs[3]: TPC-H Q3 (tests/tpch/q3.slt:2-24) up to the HashAggregate output, in the plan shape the reference's
+    optimizer produces: filters pushed into the scans, build side = left child, no side swapping.
+    customer / orders / lineitem are MemoryTables over synth.{CUSTOMER,ORDERS,LINEITEM_Q3}_SCHEMA."""
+    from .datatypes import JoinType
+    from .plan import HashJoinExec
+    from .synth import CUSTOMER_SCHEMA, LINEITEM_Q3_SCHEMA, ORDERS_SCHEMA
+    join_cls = join_cls or HashJoinExec
+    day = _date("1995-03-15")
+    c_scan = Scan(CUSTOMER_SCHEMA, customer, None, BinaryExpr(Column("c_mktsegment", 1), Operator.Eq, Literal(ScalarValue.Utf8("BUILDING"))))
+    o_scan = Scan(ORDERS_SCHEMA, orders, None, BinaryExpr(Column("o_orderdate", 2), Operator.Lt, day))
+    l_scan = Scan(LINEITEM_Q3_SCHEMA, lineitem, None, BinaryExpr(Column("l_shipdate", 1), Operator.Gt, day))
+    j1 = join_cls.try_new(c_scan, o_scan, JoinType.Inner, [(Column("c_custkey", 0), Column("o_custkey", 1))], None)
+    # j1 schema: c_custkey c_mktsegment | o_orderkey o_custkey o_orderdate o_shippriority
+    j2 = join_cls.try_new(j1, l_scan, JoinType.Inner, [(Column("o_orderkey", 2), Column("l_orderkey", 0))], None)
+    # j2 schema: j1 (6) | l_orderkey l_shipdate l_extendedprice l_discount
+    one = CastExpr(Literal(ScalarValue.Int64(1)), pa.decimal128(20, 0))
+    revenue = BinaryExpr(Column("l_extendedprice", 8), Operator.Mul, BinaryExpr(one, Operator.Sub, Column("l_discount", 9)))
+    t4 = pa.decimal128(38, 4)
+    schema = pa.schema([pa.field("l_orderkey", pa.int64()), pa.field("o_orderdate", pa.date32()), pa.field("o_shippriority", pa.int64()),
+                        pa.field("revenue", t4)])
+    return HashAggregate(schema, j2, [Column("l_orderkey", 6), Column("o_orderdate", 4), Column("o_shippriority", 5)],
+                         [SumAggregateExpr(revenue, t4)])
