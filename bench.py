@@ -53,6 +53,79 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+Q3_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}   # SURVEY §8(d) algorithmic bytes per row
+
+
+def bench_q3(args, ctx, rank, world, barrier, dist, torch):
+    """configs[3]: TPC-H Q3 (customer |><| orders |><| lineitem -> GROUP BY) at --sf, tables sliced over the ranks, both
+    joins repartitioned by key with the RCCL exchange (qurious_amd/exchange.py) when world > 1."""
+    from qurious_amd import exchange
+    t0 = time.time()
+    c, o, l = synth.q3_tables(args.sf, rank, world)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    rows = [sum(b.num_rows for b in t.data) for t in tabs]
+    log(f"generated SF{args.sf} slice {rows} rows in {time.time() - t0:.1f}s")
+    for t in tabs:
+        t.device_table()
+    plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if world > 1 else None)
+    for _ in range(args.warmup):
+        out = plan.execute_device()
+        log(f"warmup step: {out.num_rows} groups")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = plan.execute_device()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor(rows + [out.num_rows], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        rows_all = tot.tolist()
+    else:
+        rows_all = rows + [out.num_rows]
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    algo_bytes = rows_all[0] * Q3_BYTES["customer"] + rows_all[1] * Q3_BYTES["orders"] + rows_all[2] * Q3_BYTES["lineitem"]
+    ms = elapsed / args.steps * 1e3
+    achieved = algo_bytes / (ms * 1e-3) / 1e9 / world
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        from oracle import qoracle
+        sf_small = min(args.sf, 0.05)
+        cs, os_, ls = synth.q3_tables(sf_small)
+        small = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, cs), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, os_),
+                 q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, ls))
+        splan = queries.q3(*small)
+        t0 = time.perf_counter()
+        want = qoracle.execute(splan)
+        cdt = time.perf_counter() - t0
+        assert result_key(want) == result_key(splan.execute()), "HIP Q3 result differs from the CPU oracle"
+        nl = sum(b.num_rows for b in ls)
+        cpu_baseline = {"value": nl / cdt, "unit": "rows/s", "cores": 1, "kind": "port", "seconds": cdt,
+                        "sample": f"Q3 at SF{sf_small} ({nl} lineitem rows) through oracle/qoracle.py + qoracle.c, 1 of {os.cpu_count()} host cores"}
+    line = {
+        "metric": "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X",
+        "value": rows_all[2] * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i128", "data": "synthetic",
+        "config": {"workload": f"configs[3] q3: TPC-H Q3 SF{args.sf} customer|><|orders|><|lineitem + GROUP BY, HBM-resident, "
+                               f"lineitem rows/s", "rows": {"customer": rows_all[0], "orders": rows_all[1], "lineitem": rows_all[2]},
+                   "groups": rows_all[3], "parallelism": f"hash-partitioned joins x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "q3 pipeline (all kernels of one query, per GPU)", "kernel_ms": ms,
+                     "algorithmic_bytes": algo_bytes},
+        "cpu_baseline": cpu_baseline, "device": ctx.device_name(),
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (configs[1]: 100M)")
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
-    ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full"])
+    ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full", "q3"])
+    ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of the q3 workload (whole job, sliced over the ranks)")
     ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -84,6 +158,8 @@ def main():
         torch.cuda.synchronize()
 
     log("torch imported")
+    if args.workload == "q3":
+        return bench_q3(args, ctx, rank, world, barrier, dist, torch)
     # ---- synthetic input, resident in HBM before the timed region
     t0 = time.time()
     table = gen_table(rank * args.rows, args.rows, args.batch_rows)

@@ -207,25 +207,29 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ++retries;
   }
 
-  // ---- dense slots -> host
+  // ---- dense slots -> host: one compaction launch into a buffer sized for the common case (few groups); a second
+  //      launch with the exact size only when there are more groups than that
   uint32_t G = 0;
   std::vector<uint64_t> slots;
   if (plan.W == 0) {
     G = 1;
     slots.resize((size_t)plan.slot_words);
-    QHIP_HIP_CHECK(hipMemcpy(slots.data(), gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost));
+    copy_sync(ctx->stream, slots.data(), gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost);
   } else {
-    DevBuf counter(8);
-    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, ctx->stream));
-    launch_count_ready(gtable.as<uint64_t>(), cap, plan.slot_words, counter.as<uint32_t>(), ctx->stream);
-    QHIP_HIP_CHECK(hipMemcpyAsync(&G, counter.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    DevBuf dense((size_t)G * slot_bytes);
-    QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, ctx->stream));
-    launch_compact_slots(gtable.as<uint64_t>(), cap, plan.slot_words, dense.as<uint64_t>(), counter.as<uint32_t>(), G, ctx->stream);
-    slots.resize((size_t)G * plan.slot_words);
-    if (G) QHIP_HIP_CHECK(hipMemcpyAsync(slots.data(), dense.ptr, (size_t)G * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uint32_t guess = std::min<uint32_t>(cap, 4096);
+    for (int pass = 0; pass < 2; ++pass) {
+      DevBuf dense((size_t)guess * slot_bytes + 8);   // [counter | slots]
+      QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
+      launch_compact_slots(gtable.as<uint64_t>(), cap, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
+      QHIP_HIP_CHECK(hipMemcpyAsync(&G, dense.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (G <= guess) {
+        slots.resize((size_t)G * plan.slot_words);
+        if (G) copy_sync(ctx->stream, slots.data(), dense.as<uint64_t>() + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
+        break;
+      }
+      guess = G;
+    }
   }
 
   // ---- assemble the output columns (GroupAccumulator::output, hash.rs:89-107; accumulator evaluate())

@@ -59,13 +59,15 @@ struct Ctx;
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
+  size_t cap = 0;     // size class actually allocated (caching allocator, ctx.cpp)
+  int device = 0;
   DevBuf() {}
   explicit DevBuf(size_t n) { alloc(n); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes), cap(o.cap), device(o.device) { o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; cap = o.cap; device = o.device; o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
@@ -73,6 +75,13 @@ struct DevBuf {
   void release();
   template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
+
+// Copy ordered after everything queued on `s` (the context's stream is non-blocking: a plain hipMemcpy on the null stream
+// would NOT wait for it), and complete on return.
+inline void copy_sync(hipStream_t s, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+  if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, kind, s));
+  QHIP_HIP_CHECK(hipStreamSynchronize(s));
+}
 
 // One column of a device table, concatenated over all batches, Arrow layout.
 struct DevColumn {

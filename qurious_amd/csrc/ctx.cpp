@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "common.hpp"
 #include "device/qhip_status.h"
@@ -96,21 +98,79 @@ DType dtype_from_format(const char* f) {
   fail(QHIP_UNSUPPORTED, "Arrow format '" + s + "' is not supported by the HIP backend");
 }
 
+// ---------------------------------------------------------------- caching device allocator
+// hipMalloc / hipFree cost 10^2 us each and hipFree synchronises the device; an operator call allocates a dozen
+// temporaries. Freed blocks are kept per (device, size class) and reused; size classes are 1/8-octave steps (<= 12.5 %
+// slack), so the steady state of a repeated query performs no driver allocation at all. 288 GB of HBM per GPU make the
+// cache cap (QHIP_POOL_MAX_GB, default 64 GB) a non-issue.
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::unordered_map<size_t, std::vector<void*>> free_blocks;
+  size_t cached = 0;
+};
+Pool g_pools[32];
+size_t pool_cap_bytes() {
+  static size_t cap = [] { const char* v = getenv("QHIP_POOL_MAX_GB"); return (size_t)(v && *v ? atof(v) : 64.0) * (1ULL << 30); }();
+  return cap;
+}
+size_t size_class(size_t n) {
+  if (n <= 4096) return 4096;
+  int lg = 63 - __builtin_clzll((unsigned long long)n);
+  size_t step = (size_t)1 << (lg - 3);
+  return (n + step - 1) / step * step;
+}
+}  // namespace
+
 void DevBuf::alloc(size_t n) {
   release();
   // 64 bytes of slack: kernels read Utf8 values with one unaligned 8-byte load (qh_pack_str7) and never fault
   // on the last value of a buffer; n == 0 still yields a valid pointer
-  size_t m = n + 64;
-  hipError_t e = hipMalloc(&ptr, m);
-  if (e != hipSuccess) {
-    ptr = nullptr;
-    fail(e == hipErrorOutOfMemory ? QHIP_OUT_OF_MEMORY : QHIP_HIP_ERROR,
-         "hipMalloc(" + std::to_string(m) + "): " + hipGetErrorString(e));
+  const size_t m = size_class(n + 64);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Pool& pool = g_pools[dev & 31];
+  {
+    std::lock_guard<std::mutex> l(pool.mu);
+    auto it = pool.free_blocks.find(m);
+    if (it != pool.free_blocks.end() && !it->second.empty()) {
+      ptr = it->second.back();
+      it->second.pop_back();
+      pool.cached -= m;
+    }
+  }
+  if (!ptr) {
+    hipError_t e = hipMalloc(&ptr, m);
+    if (e == hipErrorOutOfMemory) {
+      // give the cache back to the driver and retry once
+      std::lock_guard<std::mutex> l(pool.mu);
+      for (auto& kv : pool.free_blocks) { for (void* p : kv.second) (void)hipFree(p); kv.second.clear(); }
+      pool.cached = 0;
+      e = hipMalloc(&ptr, m);
+    }
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      fail(e == hipErrorOutOfMemory ? QHIP_OUT_OF_MEMORY : QHIP_HIP_ERROR, "hipMalloc(" + std::to_string(m) + "): " + hipGetErrorString(e));
+    }
   }
   bytes = n;
+  cap = m;
+  device = dev;
 }
 void DevBuf::release() {
-  if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+  if (!ptr) return;
+  Pool& pool = g_pools[device & 31];
+  bool kept = false;
+  {
+    std::lock_guard<std::mutex> l(pool.mu);
+    if (pool.cached + cap <= pool_cap_bytes()) {
+      pool.free_blocks[cap].push_back(ptr);
+      pool.cached += cap;
+      kept = true;
+    }
+  }
+  if (!kept) (void)hipFree(ptr);
+  ptr = nullptr; bytes = 0; cap = 0;
 }
 
 int64_t DevColumn::resident_bytes() const {

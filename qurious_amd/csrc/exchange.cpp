@@ -37,7 +37,7 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   stable_sort_pairs_u32(part.as<uint32_t>(), sorted_part.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), N,
                         std::max(1, log2u((uint32_t)n_parts)), s);
   std::vector<uint32_t> h((size_t)n_parts);
-  QHIP_HIP_CHECK(hipMemcpy(h.data(), hist.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost));
+  copy_sync(s, h.data(), hist.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost);
   uint64_t pos = 0;
   for (int p = 0; p < n_parts; ++p) {
     std::unique_ptr<qhip_table> t(new qhip_table());
@@ -103,13 +103,13 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
         const DevColumn& sc = ts[k]->cols[c];
         const std::shared_ptr<DevBuf>& src = values ? sc.values : sc.validity;
         std::vector<uint8_t> tmp((size_t)((sc.length + 7) / 8 + 8), values ? 0 : 0xff);
-        if (src && sc.length) QHIP_HIP_CHECK(hipMemcpy(tmp.data(), src->ptr, (size_t)((sc.length + 7) / 8), hipMemcpyDeviceToHost));
+        if (src && sc.length) copy_sync(s, tmp.data(), src->ptr, (size_t)((sc.length + 7) / 8), hipMemcpyDeviceToHost);
         for (int64_t i = 0; i < sc.length; ++i)
           if ((tmp[(size_t)(i >> 3)] >> (i & 7)) & 1) host[(size_t)((pos + i) >> 3)] |= (uint8_t)(1u << ((pos + i) & 7));
         pos += sc.length;
       }
       auto b = std::make_shared<DevBuf>(host.size());
-      QHIP_HIP_CHECK(hipMemcpy(b->ptr, host.data(), host.size(), hipMemcpyHostToDevice));
+      copy_sync(s, b->ptr, host.data(), host.size(), hipMemcpyHostToDevice);
       return b;
     };
     if (nulls > 0) oc.validity = concat_bits(false);
@@ -124,7 +124,7 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
         const DevColumn& sc = ts[k]->cols[c];
         if (!sc.length) continue;
         std::vector<int32_t> so((size_t)sc.length + 1);
-        QHIP_HIP_CHECK(hipMemcpy(so.data(), sc.values->ptr, so.size() * 4, hipMemcpyDeviceToHost));
+        copy_sync(s, so.data(), sc.values->ptr, so.size() * 4, hipMemcpyDeviceToHost);
         for (int64_t i = 0; i < sc.length; ++i) off[(size_t)(pos + i)] = so[(size_t)i] - so[0] + (int32_t)bpos;
         const int64_t nb = so[(size_t)sc.length] - so[0];
         if (nb) QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)oc.data->ptr + bpos, (const uint8_t*)sc.data->ptr + so[0], (size_t)nb, hipMemcpyDeviceToDevice, s));
@@ -133,7 +133,7 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
       }
       off[(size_t)N] = (int32_t)bpos;
       oc.values = std::make_shared<DevBuf>(off.size() * 4);
-      QHIP_HIP_CHECK(hipMemcpy(oc.values->ptr, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+      copy_sync(s, oc.values->ptr, off.data(), off.size() * 4, hipMemcpyHostToDevice);
     }
     out->cols.push_back(std::move(oc));
   }

@@ -29,9 +29,9 @@ uint32_t pow2_ceil32(uint64_t x) {
 }
 int log2u(uint32_t x) { int b = 0; while ((1u << b) < x) ++b; return b; }
 
-uint32_t read_u32(const void* dev) {
+uint32_t read_u32(hipStream_t s, const void* dev) {
   uint32_t v = 0;
-  QHIP_HIP_CHECK(hipMemcpy(&v, dev, 4, hipMemcpyDeviceToHost));
+  copy_sync(s, &v, dev, 4, hipMemcpyDeviceToHost);
   return v;
 }
 
@@ -80,7 +80,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   exclusive_scan_u32(count.as<uint32_t>(), start.as<uint32_t>(), nslots, nullptr, s);
   {
     uint32_t st[QS_WORDS];
-    QHIP_HIP_CHECK(hipMemcpy(st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost));
+    copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);
     if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
   }
 
@@ -90,7 +90,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   launch_join_probe_count(W, rkeys.as<uint64_t>(), rvalid.as<uint64_t>(), P, table.as<uint64_t>(), nslots, count.as<uint32_t>(),
                           slot_of.as<uint32_t>(), cnt.as<uint32_t>(), s);
   exclusive_scan_u32(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), P, total.as<uint32_t>(), s);
-  uint64_t M = P ? read_u32(total.ptr) : 0;
+  uint64_t M = P ? read_u32(s, total.ptr) : 0;
   DevBuf b_idx((M + 1) * 4), p_idx((M + 1) * 4);
   launch_join_probe_write(slot_of.as<uint32_t>(), pair_off.as<uint32_t>(), start.as<uint32_t>(), sorted_rows.as<uint32_t>(), cnt.as<uint32_t>(), P,
                           b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), s);
@@ -152,7 +152,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     out_off.alloc((P + 1) * 4);
     launch_join_out_counts(final_cnt, P, out_cnt.as<uint32_t>(), s);
     exclusive_scan_u32(out_cnt.as<uint32_t>(), out_off.as<uint32_t>(), P, tot.as<uint32_t>(), s);
-    const uint64_t M2 = P ? read_u32(tot.ptr) : 0;
+    const uint64_t M2 = P ? read_u32(s, tot.ptr) : 0;
     DevBuf b3((M2 + 1) * 4), p3((M2 + 1) * 4);
     launch_join_adjust_right(b_idx.as<uint32_t>(), final_cnt, final_off, out_off.as<uint32_t>(), P, b3.as<uint32_t>(), p3.as<uint32_t>(), s);
     QHIP_HIP_CHECK(hipStreamSynchronize(s));

@@ -8,6 +8,7 @@
 
 #include "device/qhip_status.h"
 #include "device/qhip_device.hpp"
+#include "common.hpp"
 #include "kernels.hpp"
 
 namespace qhip {
@@ -85,8 +86,8 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*
     return;
   }
   const uint64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  uint32_t* sums = nullptr;
-  hipMalloc(&sums, (nchunks + 1) * sizeof(uint32_t));
+  DevBuf sums_buf((nchunks + 1) * sizeof(uint32_t));   // pooled; reuse is stream-ordered (single stream per context)
+  uint32_t* sums = sums_buf.as<uint32_t>();
   hipLaunchKernelGGL(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u64)n, (u32*)sums);
   if (nchunks == 1) {
     // one chunk: its sum is the total and its offset is zero
@@ -98,8 +99,6 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*
     hipLaunchKernelGGL(k_scan_chunk_apply, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)sums);
   }
   if (total_dev) hipMemcpyAsync(total_dev, sums + nchunks, 4, hipMemcpyDeviceToDevice, s);
-  hipStreamSynchronize(s);
-  hipFree(sums);
 }
 
 // ================================================================ selection vector from a keep-mask
@@ -432,11 +431,8 @@ void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const ui
   if (!n) return;
   size_t tmp_bytes = 0;
   rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
-  void* tmp = nullptr;
-  hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
-  rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
-  hipStreamSynchronize(s);
-  hipFree(tmp);
+  DevBuf tmp(tmp_bytes);
+  rocprim::radix_sort_pairs(tmp.ptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
 }
 
 }  // namespace qhip

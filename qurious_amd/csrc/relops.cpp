@@ -42,7 +42,7 @@ uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int6
   DevBuf total(4);
   exclusive_scan_u32(wave_count.as<uint32_t>(), wave_count.as<uint32_t>(), nwords, total.as<uint32_t>(), ctx->stream);
   uint32_t m = 0;
-  QHIP_HIP_CHECK(hipMemcpy(&m, total.ptr, 4, hipMemcpyDeviceToHost));
+  copy_sync(ctx->stream, &m, total.ptr, 4, hipMemcpyDeviceToHost);
   sel.alloc((size_t)m * 4);
   launch_select_indices(mask.as<uint64_t>(), wave_count.as<uint32_t>(), (uint64_t)nrows, sel.as<uint32_t>(), ctx->stream);
   QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -80,7 +80,7 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uin
     DevBuf total(4);
     exclusive_scan_u32(off, off, m, total.as<uint32_t>(), ctx->stream);
     uint32_t nbytes = 0;
-    QHIP_HIP_CHECK(hipMemcpy(&nbytes, total.ptr, 4, hipMemcpyDeviceToHost));
+    copy_sync(ctx->stream, &nbytes, total.ptr, 4, hipMemcpyDeviceToHost);
     if (nbytes > 0x7fffffffu) fail(QHIP_UNSUPPORTED, "gathered Utf8 column exceeds 2 GiB");
     QHIP_HIP_CHECK(hipMemcpyAsync(off + m, total.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
     out.data = std::make_shared<DevBuf>((size_t)nbytes);
