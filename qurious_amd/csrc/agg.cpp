@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 
 #include "codegen.hpp"
 #include "common.hpp"
@@ -172,38 +173,43 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", 4);
   unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
 
-  // start small: clearing and compacting the table costs time proportional to its size, and a GROUP BY with few
-  // groups (Q1: 4) should not pay for a table sized for the row count. Overflow -> kernel bails out early -> x16.
-  uint32_t cap = plan.W == 0 ? 1 : std::max<uint32_t>(1024, std::min<uint32_t>(pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2),
-                                                                               (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 1 << 16)));
+  // First attempt: a SMALL table (4096 slots) replicated 32 times, workgroup b merging into replica b % 32. Clearing and
+  // compacting cost time proportional to the table size, and with few groups (Q1: 4) the ~1000 workgroups would
+  // otherwise all merge into the same handful of slots at the end of the kernel (measured: ~45 us of a 470 us kernel).
+  // The host merges the replicas (<= 32 x G slots). More groups than the small table holds -> the kernel bails out
+  // early on the overflow flag -> one un-replicated table sized for the row count, x16 until it fits.
   const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
+  uint32_t cap = plan.W == 0 ? 1 : std::min<uint32_t>(cap_max, (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 4096));
+  uint32_t replicas = plan.W == 0 ? 1 : (uint32_t)std::max(1, env_int("QHIP_AGG_REPLICAS", 32));
   DevBuf gtable;
   uint32_t status[QS_WORDS];
   int retries = 0;
   float main_ms = 0;
   for (;;) {
-    gtable.alloc((size_t)cap * slot_bytes);
-    QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, (size_t)cap * slot_bytes, ctx->stream));
+    const size_t table_bytes = (size_t)cap * replicas * slot_bytes;
+    gtable.alloc(table_bytes);
+    QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, table_bytes, ctx->stream));
     QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
     HAggLaunch L;
     L.gtable = gtable.as<uint64_t>();
     L.g_nslots = cap;
     L.l_nslots = l_nslots;
     L.status = ctx->status.as<uint32_t>();
+    L.replicas = replicas;
+    L.pad = 0;
     void* args[] = {&ka, &L};
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (N > 0 || plan.W == 0) {
-      if (N > 0)
-        QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
-    }
+    if (N > 0)
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;
-    if (cap >= cap_max) fail(QHIP_HIP_ERROR, "group table overflow at maximum capacity (internal error)");
-    cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 16, cap_max);
+    if (replicas == 1 && cap >= cap_max) fail(QHIP_HIP_ERROR, "group table overflow at maximum capacity (internal error)");
+    cap = replicas > 1 ? std::min<uint32_t>(cap_max, std::max<uint32_t>(cap * 16, 1u << 18)) : (uint32_t)std::min<uint64_t>((uint64_t)cap * 16, cap_max);
+    replicas = 1;
     ++retries;
   }
 
@@ -216,11 +222,12 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     slots.resize((size_t)plan.slot_words);
     copy_sync(ctx->stream, slots.data(), gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost);
   } else {
-    uint32_t guess = std::min<uint32_t>(cap, 4096);
+    const uint32_t total_slots = cap * replicas;
+    uint32_t guess = std::min<uint32_t>(total_slots, 8192);
     for (int pass = 0; pass < 2; ++pass) {
       DevBuf dense((size_t)guess * slot_bytes + 8);   // [counter | slots]
       QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
-      launch_compact_slots(gtable.as<uint64_t>(), cap, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
+      launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
       QHIP_HIP_CHECK(hipMemcpyAsync(&G, dense.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
       if (G <= guess) {
@@ -229,6 +236,43 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         break;
       }
       guess = G;
+    }
+    if (replicas > 1 && G > 1) {
+      // merge the replicas: same key words -> one slot; every cell is a commutative monoid (wrapping adds, max)
+      std::map<std::vector<uint64_t>, uint32_t> seen;
+      uint32_t out = 0;
+      for (uint32_t g = 0; g < G; ++g) {
+        uint64_t* src = &slots[(size_t)g * plan.slot_words];
+        std::vector<uint64_t> key(src + 1, src + 1 + plan.W);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+          seen.emplace(std::move(key), out);
+          if (out != g) memcpy(&slots[(size_t)out * plan.slot_words], src, (size_t)slot_bytes);
+          ++out;
+          continue;
+        }
+        uint64_t* dst = &slots[(size_t)it->second * plan.slot_words] + 1 + plan.W;
+        const uint64_t* sc = src + 1 + plan.W;
+        for (auto& cd : plan.cells) {
+          switch (cd.kind) {
+            case CELL_ROWS: case CELL_CNT: case CELL_SUM_U64: dst[cd.off] += sc[cd.off]; break;
+            case CELL_SUM_I128: {
+              const u128 a = ((u128)dst[cd.off + 1] << 64) | dst[cd.off], b2 = ((u128)sc[cd.off + 1] << 64) | sc[cd.off], r = a + b2;
+              dst[cd.off] = (uint64_t)r; dst[cd.off + 1] = (uint64_t)(r >> 64);
+              break;
+            }
+            case CELL_SUM_F64: { double x, y; memcpy(&x, &dst[cd.off], 8); memcpy(&y, &sc[cd.off], 8); x += y; memcpy(&dst[cd.off], &x, 8); break; }
+            case CELL_MAXORD64: dst[cd.off] = std::max(dst[cd.off], sc[cd.off]); break;
+            case CELL_MAXORD128: {
+              const u128 a = ((u128)dst[cd.off + 1] << 64) | dst[cd.off], b2 = ((u128)sc[cd.off + 1] << 64) | sc[cd.off];
+              if (b2 > a) { dst[cd.off] = sc[cd.off]; dst[cd.off + 1] = sc[cd.off + 1]; }
+              break;
+            }
+          }
+        }
+      }
+      G = out;
+      slots.resize((size_t)G * plan.slot_words);
     }
   }
 

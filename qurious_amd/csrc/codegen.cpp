@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 
@@ -119,18 +120,18 @@ void ExprGen::emit(int k, std::string& out) {
       const int s = col_slot(n.column);
       const std::string S = std::to_string(s);
       if (n.type.id == QHIP_UTF8) {
-        o << "    const int* o" << K << " = (const int*)a.c[" << S << "].v; const int b" << K << " = o" << K << "[i];\n";
-        o << "    const int l" << K << " = o" << K << "[i + 1] - b" << K << "; const u8* p" << K << " = a.c[" << S << "].d + b" << K << ";\n";
+        o << "    const int* o" << K << " = (const int*)a.c[" << S << "].v" << base_ << "; const int b" << K << " = o" << K << "[" << idx_ << "];\n";
+        o << "    const int l" << K << " = o" << K << "[" << idx_ << " + 1] - b" << K << "; const u8* p" << K << " = a.c[" << S << "].d + b" << K << ";\n";
       } else if (n.type.id == QHIP_BOOL) {
-        o << "    const bool " << v << " = qh_bit((const u8*)a.c[" << S << "].v, i);\n";
+        o << "    const bool " << v << " = qh_bit((const u8*)a.c[" << S << "].v, " << row_ << ");\n";
       } else if (n.type.id == QHIP_NULL) {
         o << "    const int " << v << " = 0;\n";
       } else {
-        o << "    const " << ctype(n.type) << " " << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v)[i];\n";
+        o << "    const " << ctype(n.type) << " " << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
       }
       if (n.nullable) {
         if (n.type.id == QHIP_NULL) o << "    const bool " << nn << " = false;\n";
-        else o << "    const bool " << nn << " = qh_bit(a.c[" << S << "].n, i);\n";
+        else o << "    const bool " << nn << " = qh_bit(a.c[" << S << "].n, " << row_ << ");\n";
       }
       break;
     }
@@ -497,10 +498,15 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   int off = 0;
   for (auto& c : P.cells) { c.off = off; off += c.words; }
   P.slot_words = 1 + P.W + off;
+  // hot-key cache size: lane-private accumulators for KC keys must fit the register file next to R rows
+  int part_regs = 0;
+  for (auto& c : P.cells) if (c.kind != CELL_ROWS) part_regs += 2 * c.words - (c.kind == CELL_MAXORD128 ? 2 : 0);
+  P.KC = P.W == 0 ? 0 : (part_regs * 4 <= 96 ? 4 : part_regs * 2 <= 96 ? 2 : 0);
+  if (const char* kc = getenv("QHIP_AGG_KC")) { if (*kc && P.W > 0) P.KC = atoi(kc); }   // tuning experiments only
   if (P.R <= 0) {
-    // rows per thread per tile: as many as the register file takes comfortably. The per-tile cost of the wave-level
-    // key dedup is independent of R, so larger tiles amortise it (measured on MI355X, q1_mini: R=4 3.7 TB/s, R=8 4.7 TB/s;
-    // q1_full spills at R=8). Estimate: one Row costs 1 + 2 W + (argument dwords) VGPRs.
+    // rows per thread per tile: all loads of a tile are in flight together, so more rows = more memory-level
+    // parallelism, until registers cut the occupancy. One Row costs 1 + 2 W + (argument dwords) VGPRs, the cache
+    // KC x part_regs. Measured on MI355X: q1_mini (7 regs/row) best at R = 4, Q1 (25 regs/row, 80 cache regs) at R = 2.
     int row_regs = 1 + 2 * P.W;
     for (size_t a = 0; a < P.args.size(); ++a) {
       bool value_needed = false;
@@ -508,15 +514,20 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
       if (value_needed) row_regs += std::max(1, dtype_width(P.args[a].type) / 4);
       if (P.args[a].nullable) row_regs += 1;
     }
-    P.R = row_regs <= 10 ? 8 : row_regs <= 28 ? 4 : row_regs <= 56 ? 2 : 1;
+    P.R = std::max(1, std::min(4, (144 - P.KC * part_regs) / row_regs));
   }
 
   // ---- source
   ExprGen g(es, input);
+  // tile-relative addressing: uniform 64-bit tile base (SGPRs) + 32-bit lane offset, so that a load needs one VALU
+  // instruction for its address instead of a 64-bit multiply-add chain per column
+  g.set_indexing(" + tb", "o", "(tb + (i64)o)");
   std::ostringstream s;
   const int KW = P.W > 0 ? P.W : 1;
   s << "struct P {\n";
+  const int KC = P.KC;
   s << "  static constexpr int W = " << P.W << ";\n  static constexpr int R = " << P.R << ";\n  static constexpr int SLOT_WORDS = " << P.slot_words << ";\n";
+  s << "  static constexpr int KC = " << KC << ";\n";
   s << "  struct Row {\n    bool pass;\n    u64 key[" << KW << "];\n";
   for (size_t a = 0; a < P.args.size(); ++a) {
     const ArgDesc& ad = P.args[a];
@@ -538,7 +549,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   // eval
   // straight-line code: every load of the row is issued unconditionally so that the loads of all R rows of a
   // tile are in flight together (a branch on the predicate would serialise the memory latencies)
-  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 i, Row& r, u32& err) {\n";
+  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 tb, const u32 o, Row& r, u32& err) {\n";
   std::string code;
   if (predicate_root >= 0) {
     g.emit(predicate_root, code);
@@ -565,18 +576,21 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";
   s << "  }\n";
   // part_add
-  s << "  __device__ static __forceinline__ void part_add(Part& p, const Row& r, const bool m) {\n";
+  // ROWS = false: the caller knows the row count from ballot popcounts (part_set_rows) and saves the per-lane adds.
+  // Sums are written as `if (take) acc += v` so that the compiler can run the adds under the EXEC mask instead of
+  // paying a v_cndmask per dword on top of every add.
+  s << "  template <bool ROWS> __device__ static __forceinline__ void part_add(Part& p, const Row& r, const bool m) {\n";
   for (size_t c = 0; c < P.cells.size(); ++c) {
     const CellDesc& cd = P.cells[c];
     const std::string C = "p.c" + std::to_string(c);
-    if (cd.kind == CELL_ROWS) { s << "    " << C << " += m ? 1ULL : 0ULL;\n"; continue; }
+    if (cd.kind == CELL_ROWS) { s << "    if (ROWS) " << C << " += m ? 1ULL : 0ULL;\n"; continue; }
     const ArgDesc& ad = P.args[(size_t)cd.arg];
     const std::string A = "r.a" + std::to_string(cd.arg);
     const std::string take = ad.nullable ? "(m && r.h" + std::to_string(cd.arg) + ")" : std::string("m");
     switch (cd.kind) {
-      case CELL_SUM_I128: s << "    " << C << " = (i128)((u128)" << C << " + (u128)(" << take << " ? " << A << " : (i128)0));\n"; break;
-      case CELL_SUM_U64: s << "    " << C << " += " << take << " ? (u64)" << A << " : 0ULL;\n"; break;
-      case CELL_SUM_F64: s << "    " << C << " += " << take << " ? (double)" << A << " : 0.0;\n"; break;
+      case CELL_SUM_I128: s << "    if (" << take << ") " << C << " = (i128)((u128)" << C << " + (u128)" << A << ");\n"; break;
+      case CELL_SUM_U64: s << "    if (" << take << ") " << C << " += (u64)" << A << ";\n"; break;
+      case CELL_SUM_F64: s << "    if (" << take << ") " << C << " += (double)" << A << ";\n"; break;
       case CELL_CNT: s << "    " << C << " += " << take << " ? 1ULL : 0ULL;\n"; break;
       case CELL_MAXORD64: {
         const std::string o = std::string(cd.is_min ? "~" : "") + ord64(ad.type, A);
@@ -592,11 +606,13 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   }
   s << "  }\n";
   // part_reduce
-  s << "  __device__ static __forceinline__ void part_reduce(Part& p) {\n";
+  s << "  __device__ static __forceinline__ void part_set_rows(Part& p, const u64 n) { p.c0 = n; }\n";
+  s << "  template <bool ROWS> __device__ static __forceinline__ void part_reduce(Part& p) {\n";
   for (size_t c = 0; c < P.cells.size(); ++c) {
     const std::string C = "p.c" + std::to_string(c);
     switch (P.cells[c].kind) {
-      case CELL_ROWS: case CELL_CNT: case CELL_SUM_U64: s << "    " << C << " = qh_wave_sum_u64(" << C << ");\n"; break;
+      case CELL_ROWS: s << "    if (ROWS) " << C << " = qh_wave_sum_u64(" << C << ");\n"; break;
+      case CELL_CNT: case CELL_SUM_U64: s << "    " << C << " = qh_wave_sum_u64(" << C << ");\n"; break;
       case CELL_SUM_I128: s << "    " << C << " = qh_wave_sum_i128(" << C << ");\n"; break;
       case CELL_SUM_F64: s << "    " << C << " = qh_wave_sum_f64(" << C << ");\n"; break;
       case CELL_MAXORD64: s << "    " << C << " = qh_wave_max_u64(" << C << ");\n"; break;

@@ -27,6 +27,8 @@ class ExprGen {
   std::string ptr(int k) const { return "p" + std::to_string(k); }
   std::string len(int k) const { return "l" + std::to_string(k); }
   KernelBindings bind;
+  // how a column element is addressed in the generated code: ((T*)col + base)[idx]; `row` is the absolute row (bitmaps)
+  void set_indexing(const std::string& base, const std::string& idx, const std::string& row) { base_ = base; idx_ = idx; row_ = row; }
   static std::string ctype(const DType& t);
   static std::string i128_const(i128 v);
 
@@ -36,6 +38,7 @@ class ExprGen {
   const ExprSet& es_;
   const std::vector<InputCol>& in_;
   std::vector<bool> done_;
+  std::string base_ = "", idx_ = "i", row_ = "i";
 };
 
 // ---------------------------------------------------------------- aggregate plan
@@ -62,6 +65,7 @@ struct AggPlan {
   int W = 0;                   // key words (incl. null-mask word)
   bool null_mask_word = false;
   int R = 4;
+  int KC = 0;                  // wave-resident hot keys
   int slot_words = 0;          // 1 + W + cell words
   std::vector<KeyDesc> keys;
   std::vector<ArgDesc> args;

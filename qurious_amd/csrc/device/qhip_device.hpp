@@ -251,20 +251,23 @@ __device__ __forceinline__ u64* qh_find_or_insert(u64* table, u32 nslots /*pow2*
 //   struct Row   { bool pass; u64 key[W]; <per-argument value + validity> }
 //   struct Part  per-cell partial aggregate of one (thread, key)
 //   eval(a, i, row, err)                load row i (branch-free), evaluate predicate/keys/arguments; status bits into err
-//   part_init(p) / part_add(p, row, m)  thread-local accumulate of rows with m == true
-//   part_reduce(p)                      wavefront reduction (all lanes active)
+//   part_init(p) / part_add<ROWS>(p, row, m)  thread-local accumulate of rows with m == true (ROWS: count them too)
+//   part_reduce<ROWS>(p)                wavefront reduction (all lanes active); part_set_rows(p, n) sets the row count
 //   (every cell's identity is all-zero bits, so a zero-filled table needs no per-slot initialisation)
 //   slot_update<M>(slot, p)             atomically merge a partial into a slot
 //   slot_merge(gslot, lslot)            merge an LDS slot into the HBM table slot
 //
-// Structure: persistent grid (a few workgroups per CU), grid-stride over tiles of 256*R rows.
-// Per tile each wave deduplicates its keys with ballot/readlane ("peeling"): rows of the wave that
-// share the leader's key are summed in registers and reduced across the wave with DPP, then ONE lane
-// updates the workgroup's LDS-staged table. This turns low-cardinality GROUP BYs (Q1: 4 groups) and
-// skewed keys into one LDS update per (wave, key) instead of 64 contended atomics. Rows left after
-// QH_MAX_PEELS peels (high-cardinality data: few duplicates inside a wave) update the table one lane
-// each, where contention is naturally low. Keys that do not fit the LDS table go straight to the
-// HBM table; at the end every workgroup merges its LDS table into the HBM table.
+// Structure: persistent grid (a few workgroups per CU), grid-stride over tiles of 256*R rows. Three levels:
+//  (1) wave-resident hot keys: each wave keeps up to KC keys (wave-uniform, SGPRs) with LANE-PRIVATE accumulators
+//      in VGPRs. A row whose key is cached costs a compare and an add under the EXEC mask; nothing crosses lanes
+//      and no table is touched until the kernel ends (one DPP reduction + one table update per wave and key per
+//      KERNEL). Keys are admitted first-come while the wave's rows keep showing duplicates (ballot/readlane
+//      discovery); the cache is flushed and switched off if it serves < 1/4 of the rows. This is what makes
+//      low-cardinality GROUP BYs (Q1: 4 groups) and skewed keys stream at memory speed.
+//  (2) the workgroup's LDS-staged open-addressing table, updated one lane per row with DS atomics (many
+//      distinct keys => little contention);
+//  (3) the HBM table for keys that do not fit the LDS table; at the end every workgroup merges its LDS table
+//      into the HBM table.
 #define QH_MAX_PEELS 8
 #define QH_LDS_MAX_PROBE 8
 #define QH_HBM_MAX_PROBE 128
@@ -272,10 +275,12 @@ __device__ __forceinline__ u64* qh_find_or_insert(u64* table, u32 nslots /*pow2*
 extern __shared__ __attribute__((aligned(16))) u8 qh_dyn_lds[];
 
 struct AggLaunch {
-  u64* gtable;      // HBM table, nslots * SLOT_WORDS words, zero-initialised
-  u32 g_nslots;     // power of two
+  u64* gtable;      // HBM table: `replicas` tables of g_nslots * SLOT_WORDS words each, zero-initialised
+  u32 g_nslots;     // slots per replica, power of two
   u32 l_nslots;     // LDS slots per workgroup (power of two, 0 = no LDS level)
   u32* status;      // QS_WORDS words
+  u32 replicas;     // workgroup b uses replica b % replicas (few groups: spreads the end-of-kernel merge of ~1000
+  u32 pad;          // workgroups over many cache lines instead of one slot per group; the host merges replicas)
 };
 
 template <class P, class M>
@@ -302,12 +307,14 @@ __device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L,
 }
 
 template <class P>
-__device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L) {
+__device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
   constexpr int R = P::R;
   u64* ltable = (u64*)qh_dyn_lds;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
+  AggLaunch L = L0;
+  L.gtable = L0.gtable + (size_t)(blockIdx.x % L0.replicas) * L0.g_nslots * P::SLOT_WORDS;
 
   if (W > 0) {
     // LDS table: zero = empty slots and identity cells
@@ -319,6 +326,14 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   typename P::Part acc;   // W == 0: whole-kernel per-thread accumulator
   if (W == 0) P::part_init(acc);
   u32 err = 0;            // QS_* bits raised by this thread, reported once at the end
+  // wave-resident hot-key cache (wave-uniform bookkeeping lives in SGPRs)
+  constexpr int KC = P::KC;
+  u64 ck[KC > 0 ? KC : 1][W > 0 ? W : 1];
+  typename P::Part cacc[KC > 0 ? KC : 1];
+  u64 crows[KC > 0 ? KC : 1];
+  int nc = 0, singles = 0;
+  bool cache_on = KC > 0, use_cache = true;
+  u64 seen_pass = 0, seen_hits = 0;
 
   const i64 tile_rows = (i64)QH_BLOCK * R;
   const i64 ntiles = (a.nrows + tile_rows - 1) / tile_rows;
@@ -327,74 +342,101 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     // issued with the tile's loads and consumed at the end of the iteration, wave-uniform)
     const u32 overflowed = W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     typename P::Row row[R];
-    const i64 base = t * tile_rows + tid;
+    const i64 tb = t * tile_rows;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      // out-of-range lanes re-read the last row (no branch around the loads) and are masked out afterwards
-      const i64 i = base + (i64)r * QH_BLOCK;
-      const bool inb = i < a.nrows;
+      // out-of-range lanes re-read the table's last row (no branch around the loads) and are masked out afterwards;
+      // addressing is (uniform 64-bit tile base) + (32-bit lane offset)
+      const u32 o = (u32)r * QH_BLOCK + (u32)tid;
+      const bool inb = tb + (i64)o < a.nrows;
       u32 e = 0;
-      P::eval(a, inb ? i : a.nrows - 1, row[r], e);
+      P::eval(a, tb, inb ? o : (u32)(a.nrows - 1 - tb), row[r], e);
       row[r].pass = row[r].pass && inb;
       err |= inb ? e : 0u;
     }
     if (W == 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) P::part_add(acc, row[r], row[r].pass);
+      for (int r = 0; r < R; ++r) P::template part_add<true>(acc, row[r], row[r].pass);
       continue;
     }
-    // ---- wave-level key dedup
-    u64 act[R];
+    // ---- wave-resident hot-key accumulators
     bool pend[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { pend[r] = row[r].pass; act[r] = qh_ballot(pend[r]); }
-    int peels = 0, singles = 0;
+    for (int r = 0; r < R; ++r) pend[r] = row[r].pass;
+    u32 tile_pass = 0, tile_hits = 0;
 #pragma unroll
-    for (int r0 = 0; r0 < R; ++r0) {
-      while (act[r0] != 0 && peels < QH_MAX_PEELS && singles < 3) {
-        const int leader = __builtin_ctzll(act[r0]);
-        u64 lk[W > 0 ? W : 1];
+    for (int r = 0; r < R; ++r) tile_pass += (u32)__builtin_popcountll(qh_ballot(pend[r]));
+    // (1) rows whose key is already cached: lane-private add under the EXEC mask, no cross-lane traffic, no table
 #pragma unroll
-        for (int w = 0; w < W; ++w) lk[w] = qh_readlane64(row[r0].key[w], leader);
-        // who else in this wave (this slice and later ones) carries the leader's key?
-        u64 msk[R];
-        int cnt = 0;
+    for (int k = 0; k < KC; ++k) {
+      if (k < nc && use_cache) {
 #pragma unroll
-        for (int r = r0; r < R; ++r) {
+        for (int r = 0; r < R; ++r) {
           bool m = pend[r];
 #pragma unroll
-          for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == lk[w]);
-          msk[r] = qh_ballot(m);
-          cnt += __builtin_popcountll(msk[r]);
+          for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == ck[k][w]);
+          P::template part_add<false>(cacc[k], row[r], m);
+          const u32 c = (u32)__builtin_popcountll(qh_ballot(m));
+          crows[k] += c;
+          tile_hits += c;
+          pend[r] = pend[r] && !m;
         }
-        if (cnt <= 1) {
-          // a key nobody shares: leave the row to the per-lane path (it stays pending)
-          act[r0] &= ~(1ULL << leader);
-          ++singles;
-          continue;
-        }
-        singles = 0;
-        typename P::Part part;
-        P::part_init(part);
-#pragma unroll
-        for (int r = r0; r < R; ++r) {
-          const bool m = (msk[r] >> lane) & 1;
-          P::part_add(part, row[r], m);
-          if (m) pend[r] = false;
-          act[r] &= ~msk[r];
-        }
-        P::part_reduce(part);   // all 64 lanes active: the tile loop and the peel loop are wave-uniform
-        if (lane == leader) qh_update_group<P>(ltable, L, lk, part);
-        ++peels;
       }
     }
-    // ---- rows not consumed by a peel: one lane per row
+    // (2) admit new keys while the cache has room and the data keeps showing duplicates inside a wave
+    if (cache_on && nc < KC) {
+#pragma unroll
+      for (int r0 = 0; r0 < R; ++r0) {
+        u64 act = qh_ballot(pend[r0]);
+        while (act != 0 && cache_on && nc < KC) {
+          const int leader = __builtin_ctzll(act);
+          u64 lk[W > 0 ? W : 1];
+#pragma unroll
+          for (int w = 0; w < W; ++w) lk[w] = qh_readlane64(row[r0].key[w], leader);
+          u32 cnt = 0;
+          bool mm[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            bool m = pend[r];
+#pragma unroll
+            for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == lk[w]);
+            mm[r] = m;
+            cnt += (u32)__builtin_popcountll(qh_ballot(m));
+          }
+          if (cnt <= 1) {
+            // nobody shares this key inside the wave: high-cardinality data, caching would only cost compares
+            act &= ~(1ULL << leader);
+            if (++singles >= 3) cache_on = false;
+            continue;
+          }
+#pragma unroll
+          for (int k = 0; k < KC; ++k) {
+            if (k == nc) {
+#pragma unroll
+              for (int w = 0; w < W; ++w) ck[k][w] = lk[w];
+              P::part_init(cacc[k]);
+              crows[k] = cnt;
+#pragma unroll
+              for (int r = 0; r < R; ++r) { P::template part_add<false>(cacc[k], row[r], mm[r]); pend[r] = pend[r] && !mm[r]; }
+            }
+          }
+          ++nc;
+          tile_hits += cnt;
+          act = qh_ballot(pend[r0]);
+        }
+      }
+    }
+    // the cache must earn its compares: a full cache that serves < 1/4 of the rows is no longer consulted (what it
+    // holds is merged at the end of the kernel like any other cached group)
+    seen_pass += tile_pass; seen_hits += tile_hits;
+    if (nc == KC && seen_pass >= 4096 && seen_hits * 4 < seen_pass) { use_cache = false; cache_on = false; }
+    // (3) everything else: one lane per row straight to the LDS-staged table (contention is low when keys are many)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (pend[r]) {
         typename P::Part part;
         P::part_init(part);
-        P::part_add(part, row[r], true);
+        P::template part_add<true>(part, row[r], true);
         qh_update_group<P>(ltable, L, row[r].key, part);
       }
     }
@@ -402,8 +444,17 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   }
 
   qh_report(L.status, err);
+  // hand the cached groups of this wave to the workgroup's table: one reduction + one update per (wave, key) per KERNEL
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    if (k < nc) {
+      P::template part_reduce<false>(cacc[k]);
+      P::part_set_rows(cacc[k], crows[k]);
+      if (lane == 0) qh_update_group<P>(ltable, L, ck[k], cacc[k]);
+    }
+  }
   if (W == 0) {
-    P::part_reduce(acc);
+    P::template part_reduce<true>(acc);
     if (lane == 0) P::template slot_update<MemHbm>(L.gtable, acc);
     return;
   }

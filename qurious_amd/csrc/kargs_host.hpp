@@ -30,7 +30,9 @@ struct HAggLaunch {
   uint32_t g_nslots;
   uint32_t l_nslots;
   uint32_t* status;
+  uint32_t replicas;
+  uint32_t pad;
 };
-static_assert(sizeof(HAggLaunch) == 24, "AggLaunch layout");
+static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
 
 }  // namespace qhip
