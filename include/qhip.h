@@ -224,7 +224,11 @@ int qhip_hash_aggregate_execute(qhip_ctx* ctx, const qhip_table* input,
  * (filter_sides[k] == 0 ? left : right).column(filter_cols[k]). Output: left ++ right
  * columns (left only for semi/anti), one batch per non-empty probe batch in probe order,
  * matches of a probe row in ascending build-row order, then the unmatched-build tail
- * (hash_join.rs:277-343). */
+ * (hash_join.rs:277-343).
+ * left/right_scan_filter_root >= 0 (Inner joins only): the child is a Scan with a pushed-down filter
+ * (datasource/memory.rs:90-93); pass the UNFILTERED table and the predicate (a root in left_exprs / right_exprs):
+ * rejected rows are never inserted / probed, so the filtered batch is never materialised. The result equals
+ * joining the filtered tables (one output batch per probe batch either way, Filter keeps batch boundaries). */
 int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right,
                            int32_t join_type,
                            const qhip_expr* left_exprs, int32_t n_left_exprs,
@@ -232,6 +236,7 @@ int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_tab
                            const int32_t* on_left, const int32_t* on_right, int32_t n_on,
                            const qhip_expr* filter_exprs, int32_t n_filter_exprs, int32_t filter_root,
                            const int32_t* filter_sides, const int32_t* filter_cols, int32_t n_filter_cols,
+                           int32_t left_scan_filter_root, int32_t right_scan_filter_root,
                            qhip_table** out);
 
 /* ---------------------------------------------------------------- exchange (multi-GPU hash-join repartition) */

@@ -675,13 +675,21 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
   out.bind = g.bind;
 }
 
-void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out) {
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root) {
   out = KeysPlan();
   layout_keys(es, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
   std::string code, all;
+  if (predicate_root >= 0) {
+    // scan filter fused into the key evaluation: a row the predicate rejects gets an invalid key, i.e. it is never
+    // inserted into / probed against the join table — the filtered batch is never materialised
+    if (es.at(predicate_root).type.id != QHIP_BOOL)
+      fail(QHIP_INVALID_ARGUMENT, "filter predicate must be Boolean, got " + dtype_name(es.at(predicate_root).type));
+    g.emit(predicate_root, code);
+  }
   emit_key_words(g, es, out.keys, false, "k", code, &all);
+  if (predicate_root >= 0) all = "(" + g.ok(predicate_root) + " && " + g.val(predicate_root) + ") && " + all;
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;

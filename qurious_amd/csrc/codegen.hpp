@@ -88,6 +88,6 @@ struct KeysPlan {
   std::vector<KeyDesc> keys;
   KernelBindings bind; std::string source; std::string kernel_name;
 };
-void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out);
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1);
 
 }  // namespace qhip

@@ -37,7 +37,7 @@ uint32_t read_u32(hipStream_t s, const void* dev) {
 
 qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int join_type, const qhip_expr* lex, int nlex, const qhip_expr* rex,
                       int nrex, const int32_t* on_l, const int32_t* on_r, int n_on, const qhip_expr* fex, int nfex, int froot,
-                      const int32_t* fsides, const int32_t* fcols, int nfcols) {
+                      const int32_t* fsides, const int32_t* fcols, int nfcols, int lpred, int rpred) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   if (n_on <= 0) fail(QHIP_INVALID_ARGUMENT, "Internal error: On constraints in HashJoinExec should be non-empty");
@@ -57,8 +57,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   KeysPlan lkp, rkp;
   DevBuf lkeys, lvalid, rkeys, rvalid;
   hipEventRecord(ctx->ev[0], s);
-  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid);
-  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid);
+  if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
+    fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
+  if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
+  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred);
+  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid, rpred);
   for (int k = 0; k < n_on; ++k)
     if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
       fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
@@ -242,11 +245,11 @@ extern "C" int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, con
                                       const qhip_expr* left_exprs, int32_t n_left_exprs, const qhip_expr* right_exprs, int32_t n_right_exprs,
                                       const int32_t* on_left, const int32_t* on_right, int32_t n_on, const qhip_expr* filter_exprs,
                                       int32_t n_filter_exprs, int32_t filter_root, const int32_t* filter_sides, const int32_t* filter_cols,
-                                      int32_t n_filter_cols, qhip_table** out) {
+                                      int32_t n_filter_cols, int32_t left_scan_filter_root, int32_t right_scan_filter_root, qhip_table** out) {
   if (!ctx || !left || !right || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
   return guarded(ctx, [&] {
     *out = hash_join(ctx, left, right, join_type, left_exprs, n_left_exprs, right_exprs, n_right_exprs, on_left, on_right, n_on, filter_exprs,
-                     n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols);
+                     n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols, left_scan_filter_root, right_scan_filter_root);
   });
 }

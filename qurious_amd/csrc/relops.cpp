@@ -92,8 +92,8 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uin
 }
 
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
-                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid) {
-  plan_keys(es, icols, roots, n, kp);
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root) {
+  plan_keys(es, icols, roots, n, kp, predicate_root);
   const int64_t N = t->num_rows;
   const uint64_t nwords = (uint64_t)(N + 63) / 64;
   keys.alloc((size_t)kp.W * (size_t)N * 8);

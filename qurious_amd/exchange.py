@@ -189,6 +189,8 @@ class DistributedHashJoinExec(HashJoinExec):
     def execute_device(self) -> DeviceTable:
         dist = _dist()
         world = dist.get_world_size() if dist.is_initialized() else 1
+        if world <= 1:
+            return HashJoinExec.execute_device(self)
         lt = self.left.execute_device()
         rt = self.right.execute_device()
         if world > 1:
@@ -196,9 +198,7 @@ class DistributedHashJoinExec(HashJoinExec):
             rparts = partition_by_key(rt, [r for _, r in self.on], world)
             lt = exchange_device_tables(lparts, self.left.schema())
             rt = exchange_device_tables(rparts, self.right.schema())
-        local = HashJoinExec(DeviceSource(self.left.schema(), lt), DeviceSource(self.right.schema(), rt), self.join_type, self.on,
-                             self.filter, self._schema, self.column_indices)
-        return HashJoinExec.execute_device(local)
+        return self._join_tables(lt, rt)
 
     @staticmethod
     def try_new(left, right, join_type, on, filter=None) -> "DistributedHashJoinExec":

@@ -273,13 +273,27 @@ class HashJoinExec(PhysicalPlan):
     def children(self):
         return [self.left, self.right]
 
+    @staticmethod
+    def _side(node: PhysicalPlan, fuse: bool):
+        """(device table, scan filter or None): an Inner join takes a Scan(filter) child as (unfiltered table, predicate)
+        and fuses the predicate into its key evaluation instead of materialising the filtered batches."""
+        if fuse and isinstance(node, Scan) and node.filter is not None and node.projections is None:
+            return node.datasource.device_table(), node.filter
+        return node.execute_device(), None
+
     def execute_device(self) -> DeviceTable:
-        lt = self.left.execute_device()
-        rt = self.right.execute_device()
+        fuse = self.join_type == JoinType.Inner
+        lt, lpred = self._side(self.left, fuse)
+        rt, rpred = self._side(self.right, fuse)
+        return self._join_tables(lt, rt, lpred, rpred)
+
+    def _join_tables(self, lt: DeviceTable, rt: DeviceTable, lpred=None, rpred=None) -> DeviceTable:
         ctx = lt.ctx
         le, re_, fe = ExprArray(), ExprArray(), ExprArray()
         on_l = [le.lower(l) for l, _ in self.on]
         on_r = [re_.lower(r) for _, r in self.on]
+        lp = le.lower(lpred) if lpred is not None else -1
+        rp = re_.lower(rpred) if rpred is not None else -1
         froot, fsides, fcols = -1, [], []
         if self.filter is not None:
             froot = fe.lower(self.filter.expr)
@@ -291,5 +305,5 @@ class HashJoinExec(PhysicalPlan):
         out = C.c_void_p()
         ctx.check(ctx.lib.qhip_hash_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), la, ln, ra, rn,
                                                  int32_array(on_l), int32_array(on_r), len(self.on), fa, fn, froot,
-                                                 int32_array(fsides), int32_array(fcols), len(fcols), C.byref(out)))
+                                                 int32_array(fsides), int32_array(fcols), len(fcols), lp, rp, C.byref(out)))
         return DeviceTable(ctx, out)
