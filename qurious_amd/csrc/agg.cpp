@@ -217,6 +217,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   //      launch with the exact size only when there are more groups than that
   uint32_t G = 0;
   std::vector<uint64_t> slots;
+  DevBuf dense_keep;                                   // [counter | dense slots] when the output is assembled on the device
+  const uint32_t dev_threshold = (uint32_t)env_int("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", 4096);
   if (plan.W == 0) {
     G = 1;
     slots.resize((size_t)plan.slot_words);
@@ -231,6 +233,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       QHIP_HIP_CHECK(hipMemcpyAsync(&G, dense.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
       if (G <= guess) {
+        if (replicas == 1 && G >= dev_threshold) { dense_keep = std::move(dense); break; }   // stays on the device
         slots.resize((size_t)G * plan.slot_words);
         if (G) copy_sync(ctx->stream, slots.data(), dense.as<uint64_t>() + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
         break;
@@ -276,9 +279,115 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
   }
 
-  // ---- assemble the output columns (GroupAccumulator::output, hash.rs:89-107; accumulator evaluate())
-  std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));
+  auto set_stats = [&]() {
+    ctx->stats.main_kernel_ms = main_ms;
+    ctx->stats.total_device_ms = main_ms;
+    ctx->stats.rows_in = N;
+    ctx->stats.rows_out = G;
+    ctx->stats.groups = G;
+    ctx->stats.table_capacity = (int64_t)cap * replicas;
+    ctx->stats.retries = retries;
+    ctx->stats.lds_table_slots = (int32_t)l_nslots;
+    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+  };
   const int cell0 = 1 + plan.W;
+  if (dense_keep.ptr) {
+    // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe
+    const uint64_t* dense = dense_keep.as<uint64_t>() + 1;
+    const int ncols = n_groups + n_aggs;
+    std::vector<FinCol> fc((size_t)ncols);
+    std::unique_ptr<qhip_table> out(new qhip_table());
+    out->ctx = ctx;
+    out->names = names;
+    out->nullable = nullable;
+    out->num_rows = G;
+    out->batch_offsets = {0, (int64_t)G};
+    const size_t vwords = ((size_t)G + 63) / 64 + 1;
+    std::vector<std::shared_ptr<DevBuf>> valid_bufs;
+    for (int k = 0; k < ncols; ++k) {
+      FinCol& f = fc[(size_t)k];
+      memset(&f, 0, sizeof f);
+      f.cnt_word = -1; f.key_index = -1; f.src_word = 0;
+      DevColumn col;
+      col.length = G;
+      if (k < n_groups) {
+        const KeyDesc& kd = plan.keys[(size_t)k];
+        col.type = kd.type;
+        f.src_word = 1 + kd.word_off;
+        f.key_index = (plan.null_mask_word && kd.nullable) ? k : -1;
+        if (kd.type.id == QHIP_UTF8) { f.kind = F_KEY_UTF8_LEN; f.width = 4; }
+        else if (kd.type.id == QHIP_DECIMAL128) { f.kind = F_KEY_DEC; f.width = 16; }
+        else { f.kind = F_KEY_FIXED; f.width = dtype_width(kd.type); }
+      } else {
+        const AggDesc& ad = plan.aggs[(size_t)(k - n_groups)];
+        col.type = ad.ret;
+        const int cntw = cell0 + plan.cells[(size_t)ad.count_cell].off;
+        f.src_word = ad.value_cell >= 0 ? cell0 + plan.cells[(size_t)ad.value_cell].off : 0;
+        f.width = dtype_width(ad.ret);
+        switch (ad.kind) {
+          case QHIP_AGG_COUNT: f.kind = F_COUNT; f.cnt_word = cntw; f.width = 8; break;
+          case QHIP_AGG_SUM: f.kind = ad.ret.id == QHIP_DECIMAL128 ? F_SUM128 : F_SUM64; f.cnt_word = cntw; break;
+          case QHIP_AGG_AVG:
+            f.cnt_word = cntw;
+            if (ad.ret.id == QHIP_FLOAT64) f.kind = F_AVG_F64;
+            else {
+              const DType& at = plan.args[(size_t)ad.arg].type;
+              if (ad.ret.scale < at.scale) fail(QHIP_EXEC_ERROR, "Internal error: Arithmetic Overflow in DecimalAvgAccumulator");
+              const i128 mul = pow10_i128(ad.ret.scale - at.scale), lim = pow10_i128(ad.ret.precision);
+              f.kind = F_AVG_DEC;
+              f.mul_lo = (uint64_t)(u128)mul; f.mul_hi = (uint64_t)((u128)mul >> 64);
+              f.lim_lo = (uint64_t)(u128)lim; f.lim_hi = (uint64_t)((u128)lim >> 64);
+            }
+            break;
+          default:
+            f.is_min = ad.kind == QHIP_AGG_MIN;
+            if (ad.ret.id == QHIP_DECIMAL128) f.kind = F_MM_DEC;
+            else if (ad.ret.id == QHIP_FLOAT64) f.kind = F_MM_F64;
+            else if (ad.ret.id == QHIP_FLOAT32) f.kind = F_MM_F32;
+            else { f.kind = F_MM_INT; f.is_signed = dtype_is_signed(ad.ret) || ad.ret.id == QHIP_DATE32 || ad.ret.id == QHIP_DATE64; }
+        }
+      }
+      col.values = std::make_shared<DevBuf>(f.kind == F_KEY_UTF8_LEN ? ((size_t)G + 1) * 4 : (size_t)G * f.width);
+      auto vb = std::make_shared<DevBuf>(vwords * 8);
+      f.out_values = col.values->ptr;
+      f.out_valid = vb->as<uint64_t>();
+      valid_bufs.push_back(vb);
+      out->cols.push_back(std::move(col));
+    }
+    DevBuf fc_dev(fc.size() * sizeof(FinCol)), nulls_dev((size_t)ncols * 4);
+    QHIP_HIP_CHECK(hipMemcpyAsync(fc_dev.ptr, fc.data(), fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
+    QHIP_HIP_CHECK(hipMemsetAsync(nulls_dev.ptr, 0, (size_t)ncols * 4, ctx->stream));
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+    launch_agg_finalize(dense, G, plan.slot_words, plan.null_mask_word ? 1 : 0, (const FinCol*)fc_dev.ptr, ncols, nulls_dev.as<uint32_t>(),
+                        ctx->status.as<uint32_t>(), ctx->stream);
+    std::vector<uint32_t> nulls((size_t)ncols);
+    QHIP_HIP_CHECK(hipMemcpyAsync(nulls.data(), nulls_dev.ptr, (size_t)ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
+    copy_sync(ctx->stream, status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost);
+    if (status[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
+    for (int k = 0; k < ncols; ++k) {
+      DevColumn& col = out->cols[(size_t)k];
+      col.null_count = nulls[(size_t)k];
+      if (col.null_count > 0) col.validity = valid_bufs[(size_t)k];
+      if (fc[(size_t)k].kind == F_KEY_UTF8_LEN) {
+        // lengths -> offsets (exclusive scan) -> bytes
+        uint32_t* off = col.values->as<uint32_t>();
+        DevBuf total(4);
+        exclusive_scan_u32(off, off, G, total.as<uint32_t>(), ctx->stream);
+        uint32_t nbytes = 0;
+        copy_sync(ctx->stream, &nbytes, total.ptr, 4, hipMemcpyDeviceToHost);
+        QHIP_HIP_CHECK(hipMemcpyAsync(off + G, total.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        col.data = std::make_shared<DevBuf>((size_t)nbytes);
+        col.data_bytes = nbytes;
+        launch_agg_utf8_key_bytes(dense, G, plan.slot_words, fc[(size_t)k].src_word, off, col.data->as<uint8_t>(), ctx->stream);
+      }
+    }
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // dense_keep is released on return
+    set_stats();
+    return out.release();
+  }
+
+  // ---- few groups: assemble the output columns on the host (GroupAccumulator::output, hash.rs:89-107; accumulator evaluate())
+  std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));
   for (int k = 0; k < n_groups; ++k) {
     const KeyDesc& kd = plan.keys[(size_t)k];
     HostColumn& hc = cols[(size_t)k];
@@ -379,15 +488,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       }
     }
   }
-  ctx->stats.main_kernel_ms = main_ms;
-  ctx->stats.total_device_ms = main_ms;
-  ctx->stats.rows_in = N;
-  ctx->stats.rows_out = G;
-  ctx->stats.groups = G;
-  ctx->stats.table_capacity = cap;
-  ctx->stats.retries = retries;
-  ctx->stats.lds_table_slots = (int32_t)l_nslots;
-  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+  set_stats();
   return table_from_host(ctx, names, nullable, cols, G, false);
 }
 

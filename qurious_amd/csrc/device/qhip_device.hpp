@@ -181,19 +181,24 @@ template <class M> __device__ __forceinline__ void qh_acc_add_f64(u64* cell, dou
 // MIN and MAX cells both store an order-preserving unsigned image of the value (MIN stores its complement),
 // so a zero-filled cell is the identity and one atomic max serves both (codegen.cpp ord64()).
 template <class M> __device__ __forceinline__ void qh_acc_max_u64(u64* cell, u64 v) { (void)__hip_atomic_fetch_max(cell, v, __ATOMIC_RELAXED, M::SCOPE); }
-// 128-bit max has no hardware atomic: the cell carries a third word used as a spin lock. The loop body
-// completes the critical section before any lane retries, so lanes of one wave contending for the same
-// cell cannot deadlock. All accesses are atomics of the table's scope (HBM level: sc1, L2-coherent).
+// 128-bit max has no hardware atomic: the cell carries a third word used as a spin lock. All accesses are atomics of
+// the table's scope (HBM level: sc1, L2-coherent).
 template <class M> __device__ __forceinline__ void qh_acc_max_u128(u64* cell, u128 v) {
-  bool done = false;
-  while (!done) {
-    if (qh_cas64<M>(cell + 2, 0ULL, 1ULL)) {
+  // The lanes of this wavefront that reached here take the lock ONE AT A TIME (wave-uniform loop over the ballot): a
+  // lane spinning on a lock held by another lane of its own wavefront would never let that lane release it (lockstep
+  // execution), whereas a holder in another wavefront always makes progress.
+  u64 todo = qh_ballot(true);
+  const int lane = qh_lane();
+  while (todo) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    if (lane == l) {
+      while (!qh_cas64<M>(cell + 2, 0ULL, 1ULL)) {}
       const u128 cur = ((u128)qh_ld64<M>(cell + 1) << 64) | (u128)qh_ld64<M>(cell);
       if (v > cur) { qh_st64<M>(cell, (u64)v); qh_st64<M>(cell + 1, (u64)(v >> 64)); }
       if (M::SCOPE == __HIP_MEMORY_SCOPE_AGENT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
       qh_st64<M>(cell + 2, 0ULL);
-      done = true;
     }
   }
 }

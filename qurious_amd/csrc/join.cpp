@@ -60,8 +60,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
-  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred);
-  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid, rpred);
+  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
+  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
+  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid, rpred, true);
   for (int k = 0; k < n_on; ++k)
     if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
       fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
@@ -74,7 +75,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   DevBuf sorted_slot((B + 1) * 4), sorted_rows((B + 1) * 4), iota((B + 1) * 4);
   QHIP_HIP_CHECK(hipMemsetAsync(table.ptr, 0, table.bytes, s));
   QHIP_HIP_CHECK(hipMemsetAsync(count.ptr, 0, count.bytes, s));
-  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
   launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table.as<uint64_t>(), nslots, row_slot.as<uint32_t>(),
                            count.as<uint32_t>(), ctx->status.as<uint32_t>(), s);
   launch_iota_u32(iota.as<uint32_t>(), B, s);
@@ -83,20 +83,23 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   exclusive_scan_u32(count.as<uint32_t>(), start.as<uint32_t>(), nslots, nullptr, s);
   {
     uint32_t st[QS_WORDS];
-    copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);
+    copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);   // key evaluation of both sides + build
+    check_status_words(st);
     if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
   }
 
   // ---- probe pass 1 + 2
   DevBuf slot_of((P + 1) * 4), cnt((P + 1) * 4), pair_off((P + 1) * 4), total(4);
   hipEventRecord(ctx->ev[2], s);
+  const uint64_t pwaves = (P + 63) / 64;
+  DevBuf wave_tot((pwaves + 1) * 4);
   launch_join_probe_count(W, rkeys.as<uint64_t>(), rvalid.as<uint64_t>(), P, table.as<uint64_t>(), nslots, count.as<uint32_t>(),
-                          slot_of.as<uint32_t>(), cnt.as<uint32_t>(), s);
-  exclusive_scan_u32(cnt.as<uint32_t>(), pair_off.as<uint32_t>(), P, total.as<uint32_t>(), s);
+                          slot_of.as<uint32_t>(), cnt.as<uint32_t>(), wave_tot.as<uint32_t>(), s);
+  exclusive_scan_u32(wave_tot.as<uint32_t>(), wave_tot.as<uint32_t>(), pwaves, total.as<uint32_t>(), s);   // P/64 values only
   uint64_t M = P ? read_u32(s, total.ptr) : 0;
   DevBuf b_idx((M + 1) * 4), p_idx((M + 1) * 4);
-  launch_join_probe_write(slot_of.as<uint32_t>(), pair_off.as<uint32_t>(), start.as<uint32_t>(), sorted_rows.as<uint32_t>(), cnt.as<uint32_t>(), P,
-                          b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), s);
+  launch_join_probe_write(slot_of.as<uint32_t>(), wave_tot.as<uint32_t>(), start.as<uint32_t>(), sorted_rows.as<uint32_t>(), cnt.as<uint32_t>(), P,
+                          pair_off.as<uint32_t>(), b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), s);
   hipEventRecord(ctx->ev[3], s);
 
   // ---- residual JoinFilter (join/mod.rs:125-154): evaluate over an intermediate batch of the filter's columns, keep true rows
@@ -158,7 +161,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const uint64_t M2 = P ? read_u32(s, tot.ptr) : 0;
     DevBuf b3((M2 + 1) * 4), p3((M2 + 1) * 4);
     launch_join_adjust_right(b_idx.as<uint32_t>(), final_cnt, final_off, out_off.as<uint32_t>(), P, b3.as<uint32_t>(), p3.as<uint32_t>(), s);
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
     b_idx = std::move(b3);
     p_idx = std::move(p3);
     M = M2;

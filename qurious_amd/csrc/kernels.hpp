@@ -32,9 +32,9 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
                               uint32_t* row_slot, uint32_t* count, uint32_t* status, hipStream_t s);
 void launch_join_probe_count(int W, const uint64_t* pkeys, const uint64_t* pvalid, uint64_t np, const uint64_t* table, uint32_t nslots,
-                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, hipStream_t s);
-void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* pair_off, const uint32_t* start, const uint32_t* sorted_rows,
-                             const uint32_t* cnt, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s);
+                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, uint32_t* wave_total, hipStream_t s);
+void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* wave_off, const uint32_t* start, const uint32_t* sorted_rows,
+                             const uint32_t* cnt, uint64_t np, uint32_t* pair_off, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s);
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s);
 void launch_join_out_counts(const uint32_t* cnt, uint64_t np, uint32_t* out_cnt, hipStream_t s);
 void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const uint32_t* in_off, const uint32_t* out_off, uint64_t np,
@@ -43,4 +43,27 @@ void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t npar
 void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
                            hipStream_t s);
 
+}  // namespace qhip
+
+namespace qhip {
+// ---- device-side assembly of aggregate output columns from dense group slots (kernels_rel.hip)
+enum FinKind { F_KEY_FIXED = 0, F_KEY_DEC, F_KEY_UTF8_LEN, F_SUM64, F_SUM128, F_COUNT, F_AVG_F64, F_AVG_DEC, F_MM_INT, F_MM_F64, F_MM_F32, F_MM_DEC };
+struct FinCol {
+  int32_t kind;
+  int32_t src_word;     // word offset of the value inside the slot (key word / value cell)
+  int32_t cnt_word;     // word offset of the non-null count cell, -1 = always valid
+  int32_t width;        // bytes per output value
+  int32_t key_index;    // key columns: bit in the null-mask word, -1 = not nullable
+  int32_t is_min;       // MIN cells store the complement of the order image
+  int32_t is_signed;    // F_MM_INT
+  int32_t pad;
+  uint64_t mul_lo, mul_hi;   // F_AVG_DEC: 10^(s_out - s)
+  uint64_t lim_lo, lim_hi;   // F_AVG_DEC: 10^p_out
+  void* out_values;     // device
+  uint64_t* out_valid;  // device, one ballot word per 64 groups
+};
+void launch_agg_finalize(const uint64_t* dense, uint32_t G, int slot_words, int null_mask_word, const FinCol* cols_dev, int ncols,
+                         uint32_t* null_counts, uint32_t* status, hipStream_t s);
+void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
+                               hipStream_t s);
 }  // namespace qhip

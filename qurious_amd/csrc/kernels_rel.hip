@@ -250,31 +250,47 @@ __device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const 
   return QH_NULL_IDX;
 }
 
-// probe pass 1 (get_matches_indices + key equality, hash_join.rs:70-107,177-216): matches per probe row
+// probe pass 1 (get_matches_indices + key equality, hash_join.rs:70-107,177-216): matches per probe row. One wavefront
+// owns 64 consecutive probe rows and also emits their total, so that only the per-wave totals (P/64 values) need a
+// device-wide scan; the position of a row's first pair inside its wavefront comes from a wave-level scan in pass 2.
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_join_probe_count(const u64* pkeys, const u64* pvalid, u64 np, const u64* table, u32 nslots,
-                                                              const u32* count, u32* out_slot, u32* out_cnt) {
-  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) {
+                                                              const u32* count, u32* out_slot, u32* out_cnt, u32* wave_total) {
+  const u64 nwords = (np + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 p = j * 64 + lane;
     u32 sid = QH_NULL_IDX, c = 0;
-    if ((pvalid[p >> 6] >> (p & 63)) & 1) {
+    if (p < np && ((pvalid[j] >> lane) & 1)) {
       u64 k[W];
 #pragma unroll
       for (int w = 0; w < W; ++w) k[w] = pkeys[(size_t)w * np + p];
       sid = qh_join_find<W>(table, nslots, k);
       if (sid != QH_NULL_IDX) c = count[sid];
     }
-    out_slot[p] = sid;
-    out_cnt[p] = c;
+    if (p < np) { out_slot[p] = sid; out_cnt[p] = c; }
+    const u32 tot = (u32)qh_wave_sum_u64(c);
+    if (lane == 0) wave_total[j] = tot;
   }
 }
 // probe pass 2: emit (build row, probe row) pairs — probe-row major, build rows ascending (hash_join.rs:475-512 pins it)
-__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_write(const u32* slot_of, const u32* pair_off, const u32* start, const u32* sorted_rows,
-                                                              const u32* cnt, u64 np, u32* b_idx, u32* p_idx) {
-  for (u64 p = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; p < np; p += (u64)gridDim.x * QH_BLOCK) {
-    const u32 c = cnt[p];
-    if (!c) continue;
-    const u32 s0 = start[slot_of[p]], o = pair_off[p];
-    for (u32 k = 0; k < c; ++k) { b_idx[o + k] = sorted_rows[s0 + k]; p_idx[o + k] = (u32)p; }
+__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_write(const u32* slot_of, const u32* wave_off, const u32* start, const u32* sorted_rows,
+                                                              const u32* cnt, u64 np, u32* pair_off, u32* b_idx, u32* p_idx) {
+  const u64 nwords = (np + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 p = j * 64 + lane;
+    const u32 c = p < np ? cnt[p] : 0u;
+    const u32 o = wave_off[j] + wave_incl_scan_u32(c) - c;
+    if (p < np) pair_off[p] = o;
+    if (c) {
+      const u32 s0 = start[slot_of[p]];
+      for (u32 k = 0; k < c; ++k) { b_idx[o + k] = sorted_rows[s0 + k]; p_idx[o + k] = (u32)p; }
+    }
   }
 }
 // visited bitmap (hash_join.rs:166-167,253-255) and surviving-pair count per probe row
@@ -319,6 +335,94 @@ __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64
     const u32 pid = (u32)(((h >> 32) * (u64)nparts) >> 32);
     part[i] = pid;
     atomicAdd(&hist[pid], 1u);
+  }
+}
+
+// ================================================================ aggregate output assembly on the device
+// GroupAccumulator::output (physical/plan/aggregate/hash.rs:89-107) + Accumulator::evaluate for every group: one
+// wavefront per 64 dense slots, one pass per output column (data-driven by FinCol descriptors, so no JIT is involved).
+// Used when there are too many groups to finish on the host (Q3: ~10^5 groups at SF10).
+__device__ __forceinline__ double qh_ord_to_f64(u64 k) { return qh_ord_f64(k); }
+
+__global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32 G, int slot_words, int null_mask_word, const FinCol* cols,
+                                                          int ncols, u32* null_counts, u32* status) {
+  const u64 nwords = ((u64)G + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  for (u64 j = wave_global; j < nwords; j += nwaves) {
+    const u64 g = j * 64 + lane;
+    const bool live = g < G;
+    const u64* slot = dense + (size_t)(live ? g : 0) * slot_words;
+    const u64 nullmask = null_mask_word ? slot[1] : 0ULL;
+    for (int c = 0; c < ncols; ++c) {
+      const FinCol fc = cols[c];
+      bool valid = live;
+      if (fc.cnt_word >= 0) valid = valid && slot[fc.cnt_word] != 0;
+      if (fc.key_index >= 0) valid = valid && !((nullmask >> fc.key_index) & 1);
+      const u64 w0 = slot[fc.src_word >= 0 ? fc.src_word : 0];
+      const u64 w1 = slot[(fc.src_word >= 0 ? fc.src_word : 0) + 1 < slot_words ? (fc.src_word >= 0 ? fc.src_word : 0) + 1 : 0];
+      u64 lo = 0, hi = 0;
+      switch (fc.kind) {
+        case F_KEY_FIXED: lo = w0; break;
+        case F_KEY_DEC: lo = w0; hi = w1; break;
+        case F_KEY_UTF8_LEN: lo = valid ? (w0 >> 56) : 0ULL; break;
+        case F_SUM64: lo = w0; break;
+        case F_SUM128: lo = w0; hi = w1; break;
+        case F_COUNT: lo = slot[fc.cnt_word]; valid = live; break;
+        case F_AVG_F64: { const double s = qh_f64(w0); const u64 n = slot[fc.cnt_word]; lo = (u64)__double_as_longlong(n ? s / (double)n : 0.0); break; }
+        case F_AVG_DEC: {
+          // avg.rs:91-116: (sum * 10^(s_out - s)) checked, precision check on the scaled sum, truncating division
+          const i128 sum = qh_mk128(w0, (i64)w1), mul = qh_mk128(fc.mul_lo, (i64)fc.mul_hi), lim = qh_mk128(fc.lim_lo, (i64)fc.lim_hi);
+          i128 value = 0;
+          const bool of = __builtin_mul_overflow(sum, mul, &value);
+          const u64 n = slot[fc.cnt_word];
+          if (valid && (of || value >= lim || value <= -lim)) atomicOr(&status[QS_ARITH_OVERFLOW], 1u);
+          const i128 q = n ? value / (i128)n : (i128)0;
+          lo = (u64)(u128)q; hi = (u64)((u128)q >> 64);
+          break;
+        }
+        case F_MM_INT: { const u64 o = fc.is_min ? ~w0 : w0; lo = fc.is_signed ? (o ^ 0x8000000000000000ULL) : o; valid = live; break; }
+        case F_MM_F64:
+        case F_MM_F32: {
+          // PrimitiveAccumulator seeded with NATIVE::MAX / MIN and PartialOrd merging (aggregate/mod.rs:60-84, min.rs:12-28)
+          const double big = fc.kind == F_MM_F32 ? 3.4028234663852886e38 : 1.7976931348623157e308;
+          double v = w0 == 0 ? (fc.is_min ? big : -big) : qh_ord_to_f64(fc.is_min ? ~w0 : w0);
+          if (v != v) v = fc.is_min ? big : -big;
+          if (fc.is_min && v > big) v = big;
+          if (!fc.is_min && v < -big) v = -big;
+          if (fc.kind == F_MM_F32) { const float f = (float)v; lo = (u64)__float_as_uint(f); } else lo = (u64)__double_as_longlong(v);
+          valid = live;
+          break;
+        }
+        case F_MM_DEC: { u128 o = ((u128)w1 << 64) | w0; if (fc.is_min) o = ~o; o ^= (u128)1 << 127; lo = (u64)o; hi = (u64)(o >> 64); valid = live; break; }
+      }
+      if (live) {
+        u8* out = (u8*)fc.out_values;
+        switch (fc.width) {
+          case 1: ((u8*)out)[g] = (u8)lo; break;
+          case 2: ((u16*)out)[g] = (u16)lo; break;
+          case 4: ((u32*)out)[g] = (u32)lo; break;
+          case 8: ((u64*)out)[g] = lo; break;
+          default: ((u64*)out)[2 * g] = lo; ((u64*)out)[2 * g + 1] = hi; break;
+        }
+      }
+      const u64 vb = qh_ballot(valid);
+      if (lane == 0) {
+        fc.out_valid[j] = vb;
+        const u32 live_n = (u32)(((u64)G - j * 64) < 64 ? ((u64)G - j * 64) : 64);
+        const u32 nulls = live_n - (u32)__builtin_popcountll(vb);
+        if (nulls) atomicAdd(&null_counts[c], nulls);
+      }
+    }
+  }
+}
+// bytes of packed (<= 7 byte) Utf8 group keys: word = bytes | len << 56
+__global__ __launch_bounds__(QH_BLOCK) void k_agg_utf8_key_bytes(const u64* dense, u32 G, int slot_words, int src_word, const u32* offsets, u8* data) {
+  for (u64 g = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * QH_BLOCK) {
+    const u64 w = dense[(size_t)g * slot_words + src_word];
+    const u32 o = offsets[g], len = offsets[g + 1] - o;
+    for (u32 b = 0; b < len; ++b) data[o + b] = (u8)(w >> (8 * b));
   }
 }
 
@@ -395,16 +499,16 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
                                    (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)status));
 }
 void launch_join_probe_count(int W, const uint64_t* pkeys, const uint64_t* pvalid, uint64_t np, const uint64_t* table, uint32_t nslots,
-                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, hipStream_t s) {
+                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, uint32_t* wave_total, hipStream_t s) {
   if (!np) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_probe_count<KW>, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u64*)pkeys, (const u64*)pvalid, (u64)np,
-                                   (const u64*)table, nslots, (const u32*)count, (u32*)out_slot, (u32*)out_cnt));
+                                   (const u64*)table, nslots, (const u32*)count, (u32*)out_slot, (u32*)out_cnt, (u32*)wave_total));
 }
-void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* pair_off, const uint32_t* start, const uint32_t* sorted_rows,
-                             const uint32_t* cnt, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s) {
+void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* wave_off, const uint32_t* start, const uint32_t* sorted_rows,
+                             const uint32_t* cnt, uint64_t np, uint32_t* pair_off, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s) {
   if (!np) return;
-  hipLaunchKernelGGL(k_join_probe_write, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)pair_off, (const u32*)start,
-                     (const u32*)sorted_rows, (const u32*)cnt, (u64)np, (u32*)b_idx, (u32*)p_idx);
+  hipLaunchKernelGGL(k_join_probe_write, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)wave_off, (const u32*)start,
+                     (const u32*)sorted_rows, (const u32*)cnt, (u64)np, (u32*)pair_off, (u32*)b_idx, (u32*)p_idx);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;
@@ -422,6 +526,19 @@ void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const u
 void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s) {
   if (!n) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
+}
+
+void launch_agg_finalize(const uint64_t* dense, uint32_t G, int slot_words, int null_mask_word, const FinCol* cols_dev, int ncols,
+                         uint32_t* null_counts, uint32_t* status, hipStream_t s) {
+  if (!G) return;
+  hipLaunchKernelGGL(k_agg_finalize, dim3(grid_for(((uint64_t)G + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u64*)dense, G, slot_words,
+                     null_mask_word, cols_dev, ncols, (u32*)null_counts, (u32*)status);
+}
+void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
+                               hipStream_t s) {
+  if (!G) return;
+  hipLaunchKernelGGL(k_agg_utf8_key_bytes, dim3(grid_for(G)), dim3(QH_BLOCK), 0, s, (const u64*)dense, G, slot_words, src_word,
+                     (const u32*)offsets, (u8*)data);
 }
 
 // stable sort of (key, value) pairs on the low `bits` bits of the key (rocPRIM LSD radix sort): groups build rows by

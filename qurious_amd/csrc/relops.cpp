@@ -45,8 +45,7 @@ uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int6
   copy_sync(ctx->stream, &m, total.ptr, 4, hipMemcpyDeviceToHost);
   sel.alloc((size_t)m * 4);
   launch_select_indices(mask.as<uint64_t>(), wave_count.as<uint32_t>(), (uint64_t)nrows, sel.as<uint32_t>(), ctx->stream);
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return m;
+  return m;   // consumers run on the same stream: no synchronisation needed here
 }
 
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null) {
@@ -87,12 +86,11 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uin
     out.data_bytes = nbytes;
     launch_gather_utf8_bytes(col.values->as<int32_t>(), col.data->as<uint8_t>(), idx, m, off, out.data->as<uint8_t>(), ctx->stream);
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  return out;
+  return out;   // stream-ordered: whoever reads the column next runs on ctx->stream or synchronises it first
 }
 
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
-                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root) {
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root, bool deferred_status) {
   plan_keys(es, icols, roots, n, kp, predicate_root);
   const int64_t N = t->num_rows;
   const uint64_t nwords = (uint64_t)(N + 63) / 64;
@@ -103,13 +101,16 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
   HKArgs ka;
   DevBuf strlit;
   fill_kargs(ctx, t, kp.bind, ka, strlit);
-  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+  if (!deferred_status) QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
   void* kptr = keys.ptr;
   void* vptr = keyvalid.ptr;
   void* sptr = ctx->status.ptr;
   void* args[] = {&ka, &kptr, &vptr, &sptr};
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
   QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  // deferred: the caller reads ctx->status at its next natural synchronisation point. The pooled literal buffer may be
+  // recycled after return: any later writer runs on the same stream, i.e. after this kernel.
+  if (deferred_status) return;
   uint32_t status[QS_WORDS];
   QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
   QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -23,6 +23,6 @@ uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int6
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null);
 // key words [W][N] + validity bitmap of the key expressions `roots`
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
-                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1);
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false);
 
 }  // namespace qhip

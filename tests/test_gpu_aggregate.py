@@ -128,3 +128,41 @@ def test_errors_match_reference_behaviour(ctx, oracle):
         q.HashAggregate(None, scan, [col("a", 0)], [q.SumAggregateExpr(q.BinaryExpr(col("a", 0), Operator.Div, q.CastExpr(col("b", 1), I64)), I64)]).execute()
     with pytest.raises(q.QuriousError, match="Sum not supported"):
         q.HashAggregate(None, scan, [col("a", 0)], [q.SumAggregateExpr(col("b", 1), pa.int32())]).execute()
+
+
+def test_device_side_output_assembly_matches_host_side(ctx, oracle, monkeypatch):
+    """many groups are finished on the device (k_agg_finalize); force that path on small inputs and compare every output kind"""
+    monkeypatch.setenv("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", "1")
+    monkeypatch.setenv("QHIP_AGG_REPLICAS", "1")
+    rng = np.random.default_rng(17)
+    n = 30000
+    D = decimal.Decimal
+    dec = pa.decimal128(15, 2)
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("d", dec), pa.field("v", I64), pa.field("f", pa.float64()),
+                        pa.field("dt", pa.date32()), pa.field("x", dec)])
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(rng.integers(0, 500, n), type=I64, mask=rng.random(n) < 0.05),
+        pa.array(["g%d" % v for v in rng.integers(0, 30, n)], type=pa.string(), mask=rng.random(n) < 0.05),
+        pa.array([D(int(v)).scaleb(-2) for v in rng.integers(0, 4, n)], type=dec),
+        pa.array(rng.integers(-10**9, 10**9, n), type=I64, mask=rng.random(n) < 0.1),
+        pa.array(rng.normal(size=n), type=pa.float64(), mask=rng.random(n) < 0.1),
+        pa.array(rng.integers(9000, 9100, n), type=pa.int32()).cast(pa.date32()),
+        pa.array([D(int(v)).scaleb(-2) for v in rng.integers(-10**9, 10**9, n)], type=dec, mask=rng.random(n) < 0.1)], schema=schema)
+    scan = table_scan(schema, [batch])
+    aggs = [q.SumAggregateExpr(col("v", 3), I64), q.CountAggregateExpr(col("v", 3)), q.CountAggregateExpr(lit_i64(1)),
+            q.MinAggregateExpr(col("v", 3), I64), q.MaxAggregateExpr(col("dt", 5), pa.date32()),
+            q.SumAggregateExpr(col("x", 6), dec), q.AvgAggregateExpr(col("x", 6), dec, q.avg_return_type(dec)),
+            q.MinAggregateExpr(col("x", 6), dec), q.MaxAggregateExpr(col("x", 6), dec)]
+    plan = q.HashAggregate(None, scan, [col("k", 0), col("s", 1), col("d", 2)], aggs)
+    got, want = plan.execute()[0], oracle.execute(plan)[0]
+    assert [f.type for f in got.schema] == [f.type for f in want.schema]
+    assert sorted_rows([got]) == sorted_rows([want]) and got.num_rows > 5000
+    fl = q.HashAggregate(None, scan, [col("k", 0)], [q.SumAggregateExpr(col("f", 4), pa.float64()),
+                                                     q.AvgAggregateExpr(col("f", 4), pa.float64(), pa.float64()),
+                                                     q.MinAggregateExpr(col("f", 4), pa.float64()), q.MaxAggregateExpr(col("f", 4), pa.float64())])
+    g2 = {r[0]: r[1:] for r in rows_of(fl.execute())}
+    w2 = {r[0]: r[1:] for r in rows_of(oracle.execute(fl))}
+    assert g2.keys() == w2.keys()
+    for k in g2:
+        for a, b in zip(g2[k], w2[k]):
+            assert (a is None and b is None) or abs(a - b) <= 1e-6 * max(1.0, abs(b))
