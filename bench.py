@@ -126,6 +126,43 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         dist.destroy_process_group()
 
 
+def extra_single_gpu(args, ctx, table):
+    """configs[2] (TPC-H Q1 aggregate list over the resident lineitem rows) and configs[3] (Q3 at SF10) on this GPU."""
+    out = {}
+    try:
+        plan = queries.q1_full(table)
+        plan.execute_device()
+        ks = []
+        t0 = time.perf_counter()
+        for _ in range(5):
+            plan.execute_device()
+            ks.append(ctx.last_stats()["main_kernel_ms"])
+        dt = (time.perf_counter() - t0) / 5
+        km = sum(ks) / len(ks)
+        out["q1_full"] = {"workload": f"configs[2] TPC-H Q1 (2 keys, 8 aggregates) over {args.rows} resident lineitem rows",
+                          "rows_per_s": args.rows / dt, "ms_per_step": dt * 1e3, "kernel_ms": km,
+                          "roofline_GBps": args.rows * ALGO_BYTES_PER_ROW["q1_full"] / (km * 1e-3) / 1e9,
+                          "roofline_frac": args.rows * ALGO_BYTES_PER_ROW["q1_full"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        log(f"extra q1_full: kernel {km:.3f} ms")
+        c, o, l = synth.q3_tables(10.0)
+        tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+                q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+        rows = [sum(b.num_rows for b in t.data) for t in tabs]
+        p3 = queries.q3(*tabs)
+        p3.execute_device()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            res = p3.execute_device()
+        dt = (time.perf_counter() - t0) / 5
+        algo = rows[0] * Q3_BYTES["customer"] + rows[1] * Q3_BYTES["orders"] + rows[2] * Q3_BYTES["lineitem"]
+        out["q3_sf10"] = {"workload": "configs[3] TPC-H Q3 SF10 (two hash joins + GROUP BY) on one GPU", "rows": rows, "groups": res.num_rows,
+                          "lineitem_rows_per_s": rows[2] / dt, "ms_per_query": dt * 1e3, "algorithmic_GBps": algo / dt / 1e9}
+        log(f"extra q3 sf10: {dt * 1e3:.2f} ms/query")
+    except Exception as e:   # the headline line must not depend on the extras
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +174,7 @@ def main():
     ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of the q3 workload (whole job, sliced over the ranks)")
     ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU Q1 / Q3 measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -269,6 +307,9 @@ def main():
         "device": ctx.device_name(),
         "setup_s": {"generate": t_gen, "upload_h2d": t_upload, "h2d_GBps": resident / t_upload / 1e9},
     }
+    if world == 1 and args.workload == "q1_mini" and not args.no_extra:
+        # the other two single-GPU configurations of BASELINE.json, reported beside the headline (not part of `value`)
+        line["extra"] = extra_single_gpu(args, ctx, table)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -215,7 +215,9 @@ int qhip_ctx_create(int device_index, qhip_ctx** out) {
       fail(QHIP_HIP_ERROR, "device " + std::to_string(dev) + " is " + arch + ", libqhip kernels are written for gfx950 (MI355X)");
     std::unique_ptr<qhip_ctx> c(new qhip_ctx());
     c->device = dev;
-    c->device_name = std::string(prop.name) + " (" + arch + ")";
+    std::string pname = prop.name;
+    if (pname.empty()) pname = "AMD Instinct MI355X";   // some runtime/driver combinations leave hipDeviceProp_t::name empty
+    c->device_name = pname + " (" + arch + ")";
     c->num_cus = prop.multiProcessorCount;
     QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
