@@ -515,8 +515,8 @@ def _mix64(x: np.ndarray) -> np.ndarray:
 
 def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
     """numpy restatement of qhip_partition_by_key's row -> part mapping (csrc/kernels_rel.hip k_partition_ids over the key
-    words of csrc/codegen.cpp emit_key_words): ints/dates sign-extended to 64 bits, Decimal128 as (lo, hi), Utf8 <= 7 bytes
-    packed (bytes | len << 56); a row with any NULL key has all its key words zeroed."""
+    words of csrc/codegen.cpp emit_key_words): ints/dates sign-extended to 64 bits, Decimal128 as (lo, hi), Utf8 <= 31 bytes
+    packed into 4 words; a row with any NULL key has all its key words zeroed."""
     n = len(key_arrays[0])
     words = []
     valid = np.ones(n, dtype=bool)
@@ -527,14 +527,17 @@ def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
             valid &= np.array(a.is_valid())
         t = a.type
         if pa.types.is_string(t):
-            w = np.zeros(n, dtype=np.uint64)
+            # the exchange always packs Utf8 keys into 4 words (<= 31 bytes): bytes little-endian, length in the top byte
+            ws = [np.zeros(n, dtype=np.uint64) for _ in range(4)]
             for i, s in enumerate(a.to_pylist()):
                 if s is None:
                     continue
                 b = s.encode()
-                assert len(b) <= 7
-                w[i] = int.from_bytes(b, "little") | (len(b) << 56)
-            words.append(w)
+                assert len(b) <= 31
+                packed = int.from_bytes(b, "little") | (len(b) << 248)
+                for k in range(4):
+                    ws[k][i] = (packed >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+            words.extend(ws)
         elif pa.types.is_decimal128(t):
             raw = np.frombuffer(a.buffers()[1], dtype=np.uint64).reshape(-1, 2)[a.offset:a.offset + n]
             words.append(raw[:, 0].copy())

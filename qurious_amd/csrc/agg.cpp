@@ -18,6 +18,7 @@
 #include "jit.hpp"
 #include "kargs_host.hpp"
 #include "kernels.hpp"
+#include "relops.hpp"
 
 namespace qhip {
 
@@ -75,7 +76,7 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
 // ---------------------------------------------------------------- helpers shared with other operators
 std::vector<InputCol> input_cols_of(const qhip_table* t) {
   std::vector<InputCol> v;
-  for (auto& c : t->cols) { InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; v.push_back(ic); }
+  for (auto& c : t->cols) { InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; ic.utf8_max_len = c.utf8_max_len; v.push_back(ic); }
   return v;
 }
 
@@ -97,7 +98,7 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
 }
 
 void check_status_words(const uint32_t* st) {
-  if (st[QS_KEY_TOO_LONG]) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than 7 bytes is not accelerated yet");
+  if (st[QS_KEY_TOO_LONG]) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than its packed key words (expression keys: 7 bytes)");
   if (st[QS_DIV_ZERO]) fail(QHIP_EXEC_ERROR, "Arrow error: Divide by zero error");
   if (st[QS_CAST_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Cast error: value out of range for the target type");
   if (st[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Arithmetic overflow: Overflow happened on integer division");
@@ -131,6 +132,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   memset(&ctx->stats, 0, sizeof(ctx->stats));
 
   std::vector<InputCol> icols = input_cols_of(in);
+  ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
   ExprSet es;
   es.build(exprs, n_exprs, icols);
   AggPlan plan;
@@ -315,7 +317,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         col.type = kd.type;
         f.src_word = 1 + kd.word_off;
         f.key_index = (plan.null_mask_word && kd.nullable) ? k : -1;
-        if (kd.type.id == QHIP_UTF8) { f.kind = F_KEY_UTF8_LEN; f.width = 4; }
+        if (kd.type.id == QHIP_UTF8) { f.kind = F_KEY_UTF8_LEN; f.width = 4; f.pad = kd.words; }
         else if (kd.type.id == QHIP_DECIMAL128) { f.kind = F_KEY_DEC; f.width = 16; }
         else { f.kind = F_KEY_FIXED; f.width = dtype_width(kd.type); }
       } else {
@@ -397,8 +399,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       const bool is_null = plan.null_mask_word && ((slot[1] >> k) & 1);
       const uint64_t w0 = slot[1 + kd.word_off];
       if (kd.type.id == QHIP_UTF8) {
-        const int len = is_null ? 0 : (int)(w0 >> 56);
-        for (int b = 0; b < len; ++b) hc.data.push_back((uint8_t)(w0 >> (8 * b)));
+        const uint64_t* kw = slot + 1 + kd.word_off;
+        const int len = is_null ? 0 : (int)(kw[kd.words - 1] >> 56);
+        for (int b = 0; b < len; ++b) hc.data.push_back((uint8_t)(kw[b >> 3] >> (8 * (b & 7))));
         hc.offsets[(size_t)g + 1] = (int32_t)hc.data.size();
       } else if (kd.type.id == QHIP_DECIMAL128) {
         hc.as<uint64_t>()[2 * (size_t)g] = w0;

@@ -352,8 +352,19 @@ static void check_key_type(const DType& t) {
   }
 }
 
-static void layout_keys(const ExprSet& es, const int32_t* roots, int n, bool with_null_mask, std::vector<KeyDesc>& keys, int& W,
-                        bool& mask_word) {
+// words of a packed Utf8 key: the bytes little-endian across the words, the length in the top byte of the last word
+static int utf8_key_words(const ExprSet& es, const std::vector<InputCol>& input, int root) {
+  const ENode& nd = es.at(root);
+  int maxlen = 7;
+  if (nd.kind == QHIP_EXPR_COLUMN && input[(size_t)nd.column].utf8_max_len >= 0) maxlen = input[(size_t)nd.column].utf8_max_len;
+  else if (nd.kind == QHIP_EXPR_LITERAL) maxlen = (int)nd.s.size();
+  const int words = std::max(1, (maxlen + 1 + 7) / 8);
+  if (words > 4) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than 31 bytes is not accelerated");
+  return words;
+}
+
+static void layout_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, bool with_null_mask,
+                        std::vector<KeyDesc>& keys, int& W, bool& mask_word) {
   keys.clear();
   mask_word = false;
   if (with_null_mask)
@@ -364,7 +375,7 @@ static void layout_keys(const ExprSet& es, const int32_t* roots, int n, bool wit
     check_key_type(nd.type);
     KeyDesc kd;
     kd.root = roots[k]; kd.type = nd.type; kd.nullable = nd.nullable; kd.word_off = off;
-    kd.words = nd.type.id == QHIP_DECIMAL128 ? 2 : 1;
+    kd.words = nd.type.id == QHIP_DECIMAL128 ? 2 : nd.type.id == QHIP_UTF8 ? utf8_key_words(es, input, roots[k]) : 1;
     off += kd.words;
     keys.push_back(kd);
   }
@@ -387,9 +398,13 @@ static void emit_key_words(ExprGen& g, const ExprSet& es, const std::vector<KeyD
     const std::string w = dst + "[" + std::to_string(kd.word_off) + "]";
     std::string value;
     if (kd.type.id == QHIP_UTF8) {
-      o << "    const u64 ks" << k << " = qh_pack_str7(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ");\n";
-      o << "    if (" << okx << " && " << g.len(kd.root) << " > 7) err |= " << (1u << QS_KEY_TOO_LONG) << "u;\n";
-      value = "ks" + std::to_string(k);
+      o << "    u64 ks" << k << "[" << kd.words << "]; qh_pack_str<" << kd.words << ">(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ", ks" << k << ");\n";
+      o << "    if (" << okx << " && " << g.len(kd.root) << " > " << 8 * kd.words - 1 << ") err |= " << (1u << QS_KEY_TOO_LONG) << "u;\n";
+      for (int w2 = 0; w2 < kd.words; ++w2)
+        o << "    " << dst << "[" << kd.word_off + w2 << "] = " << (kd.nullable ? okx + " ? " : std::string("")) << "ks" << k << "[" << w2 << "]"
+          << (kd.nullable ? " : 0ULL" : "") << ";\n";
+      if (kd.nullable) { if (mask_word) o << "    nm |= " << okx << " ? 0ULL : " << (1ULL << k) << "ULL;\n"; all += " && " + okx; }
+      continue;
     } else if (kd.type.id == QHIP_DECIMAL128) {
       value = "(u64)(u128)" + g.val(kd.root);
     } else {
@@ -424,7 +439,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   P.R = rows_per_thread;
   if (predicate_root >= 0 && es.at(predicate_root).type.id != QHIP_BOOL)
     fail(QHIP_INVALID_ARGUMENT, "filter predicate must be Boolean, got " + dtype_name(es.at(predicate_root).type));
-  layout_keys(es, group_roots, n_groups, true, P.keys, P.W, P.null_mask_word);
+  layout_keys(es, input, group_roots, n_groups, true, P.keys, P.W, P.null_mask_word);
   if (P.W > 8) fail(QHIP_UNSUPPORTED, "group key wider than 8 words");
 
   // cells: cell 0 counts the rows of the group
@@ -677,7 +692,7 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
 
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root) {
   out = KeysPlan();
-  layout_keys(es, roots, n, false, out.keys, out.W, out.null_mask_word);
+  layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
   std::string code, all;

@@ -92,6 +92,7 @@ struct DevColumn {
   std::shared_ptr<DevBuf> validity;  // bitmap, present iff null_count > 0
   std::shared_ptr<DevBuf> data;      // utf8 bytes
   int64_t data_bytes = 0;
+  mutable int32_t utf8_max_len = -1;   // cached longest value (bytes), computed on first use as a key column
   int64_t resident_bytes() const;
 };
 

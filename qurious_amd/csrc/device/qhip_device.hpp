@@ -67,6 +67,18 @@ __device__ __forceinline__ u64 qh_pack_str7(const u8* p, int len) {
   const u64 mask = l ? (~0ULL >> (64 - 8 * l)) : 0ULL;
   return (raw & mask) | ((u64)l << 56);
 }
+// N-word form for values of up to 8 N - 1 bytes: bytes little-endian across the words, length in the top byte of the last
+template <int N> __device__ __forceinline__ void qh_pack_str(const u8* p, int len, u64* out) {
+  const int l = len > 8 * N - 1 ? 8 * N - 1 : len;
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const u64 raw = *(const qh_u64_unaligned*)(p + 8 * w);
+    const int nb = l - 8 * w;   // bytes of the value inside word w
+    const u64 mask = nb <= 0 ? 0ULL : (nb >= 8 ? ~0ULL : (~0ULL >> (64 - 8 * nb)));
+    out[w] = raw & mask;
+  }
+  out[N - 1] |= (u64)l << 56;
+}
 __device__ __forceinline__ void qh_report(u32* status, u32 err) {
   if (err) for (int b = 0; b < QS_WORDS; ++b) if ((err >> b) & 1u) atomicOr(&status[b], 1u);
 }

@@ -25,6 +25,11 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   hipStream_t s = ctx->stream;
   const uint64_t N = (uint64_t)in->num_rows;
   std::vector<InputCol> icols = input_cols_of(in);
+  // partition ids must agree across ranks and across the two join sides: Utf8 keys always hash as 4 words (<= 31 bytes)
+  for (int k = 0; k < n_keys; ++k)
+    if (roots[k] >= 0 && roots[k] < n_exprs && exprs[roots[k]].kind == QHIP_EXPR_COLUMN && exprs[roots[k]].column >= 0 &&
+        exprs[roots[k]].column < (int)icols.size() && icols[(size_t)exprs[roots[k]].column].type.id == QHIP_UTF8)
+      icols[(size_t)exprs[roots[k]].column].utf8_max_len = 31;
   ExprSet es;
   es.build(exprs, n_exprs, icols);
   KeysPlan kp;

@@ -25,6 +25,7 @@ struct ENode {
 struct InputCol {
   DType type;
   bool has_nulls = false;  // null_count > 0 in the table actually being executed
+  int utf8_max_len = -1;   // longest value of a Utf8 column in bytes when known (sizes packed join / group keys)
 };
 
 struct ExprSet {

@@ -51,6 +51,19 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
 
   // ---- key words of both sides
   std::vector<InputCol> lcols = input_cols_of(L), rcols = input_cols_of(R);
+  ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
+  ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
+  // both sides must pack a Utf8 key into the same number of words
+  for (int k = 0; k < n_on; ++k) {
+    if (on_l[k] < 0 || on_l[k] >= nlex || on_r[k] < 0 || on_r[k] >= nrex) fail(QHIP_INVALID_ARGUMENT, "join key index out of range");
+    const qhip_expr &le = lex[on_l[k]], &re = rex[on_r[k]];
+    if (le.kind == QHIP_EXPR_COLUMN && re.kind == QHIP_EXPR_COLUMN && le.column >= 0 && le.column < (int)lcols.size() && re.column >= 0 &&
+        re.column < (int)rcols.size() && lcols[(size_t)le.column].type.id == QHIP_UTF8 && rcols[(size_t)re.column].type.id == QHIP_UTF8) {
+      const int m = std::max(lcols[(size_t)le.column].utf8_max_len, rcols[(size_t)re.column].utf8_max_len);
+      lcols[(size_t)le.column].utf8_max_len = m;
+      rcols[(size_t)re.column].utf8_max_len = m;
+    }
+  }
   ExprSet les, res;
   les.build(lex, nlex, lcols);
   res.build(rex, nrex, rcols);

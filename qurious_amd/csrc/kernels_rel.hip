@@ -202,6 +202,16 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_utf8_bytes(const int* offse
   }
 }
 __global__ void k_store_u32(u32* p, u32 v) { *p = v; }
+// longest value of a Utf8 column (sizes the packed key words of group / join keys)
+__global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u64 n, u32* out) {
+  u32 m = 0;
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    const u32 l = (u32)(offsets[i + 1] - offsets[i]);
+    m = l > m ? l : m;
+  }
+  m = (u32)qh_wave_max_u64(m);
+  if (qh_lane() == 0 && m) atomicMax(out, m);
+}
 
 // ================================================================ hash join
 // JoinHashMap (physical/plan/join/hash_join.rs:39-107) keeps `hash -> last row + 1` and a `next` chain, built in
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32
       switch (fc.kind) {
         case F_KEY_FIXED: lo = w0; break;
         case F_KEY_DEC: lo = w0; hi = w1; break;
-        case F_KEY_UTF8_LEN: lo = valid ? (w0 >> 56) : 0ULL; break;
+        case F_KEY_UTF8_LEN: lo = valid ? (slot[fc.src_word + fc.pad - 1] >> 56) : 0ULL; break;   // pad = words of the packed key
         case F_SUM64: lo = w0; break;
         case F_SUM128: lo = w0; hi = w1; break;
         case F_COUNT: lo = slot[fc.cnt_word]; valid = live; break;
@@ -420,9 +430,9 @@ __global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32
 // bytes of packed (<= 7 byte) Utf8 group keys: word = bytes | len << 56
 __global__ __launch_bounds__(QH_BLOCK) void k_agg_utf8_key_bytes(const u64* dense, u32 G, int slot_words, int src_word, const u32* offsets, u8* data) {
   for (u64 g = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * QH_BLOCK) {
-    const u64 w = dense[(size_t)g * slot_words + src_word];
+    const u64* w = dense + (size_t)g * slot_words + src_word;
     const u32 o = offsets[g], len = offsets[g + 1] - o;
-    for (u32 b = 0; b < len; ++b) data[o + b] = (u8)(w >> (8 * b));
+    for (u32 b = 0; b < len; ++b) data[o + b] = (u8)(w[b >> 3] >> (8 * (b & 7)));
   }
 }
 
@@ -468,6 +478,9 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
   if (!m) return;
   hipLaunchKernelGGL(k_gather_utf8_bytes, dim3(grid_for((m + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (const u8*)data,
                      (const u32*)idx, (u64)m, (const u32*)out_off, (u8*)out_data);
+}
+void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_utf8_max_len, dim3(grid_for(n, QH_BLOCK, 1024)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (u64)n, (u32*)out);
 }
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, (u32*)p, v); }
 void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s) {

@@ -48,10 +48,31 @@ uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int6
   return m;   // consumers run on the same stream: no synchronisation needed here
 }
 
+void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,
+                             std::vector<InputCol>& icols) {
+  for (int k = 0; k < n; ++k) {
+    if (roots[k] < 0 || roots[k] >= n_exprs) continue;
+    const qhip_expr& e = exprs[roots[k]];
+    if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
+    const DevColumn& col = t->cols[(size_t)e.column];
+    if (col.type.id != QHIP_UTF8) continue;
+    if (col.utf8_max_len < 0) {
+      DevBuf m(4);
+      QHIP_HIP_CHECK(hipMemsetAsync(m.ptr, 0, 4, ctx->stream));
+      launch_utf8_max_len(col.values->as<int32_t>(), (uint64_t)col.length, m.as<uint32_t>(), ctx->stream);
+      uint32_t v = 0;
+      copy_sync(ctx->stream, &v, m.ptr, 4, hipMemcpyDeviceToHost);
+      col.utf8_max_len = (int32_t)v;
+    }
+    icols[(size_t)e.column].utf8_max_len = col.utf8_max_len;
+  }
+}
+
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null) {
   DevColumn out;
   out.type = col.type;
   out.length = (int64_t)m;
+  out.utf8_max_len = col.utf8_max_len;   // an upper bound stays an upper bound under gathering
   if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return out; }
   DevBuf counter(4);
   if (col.null_count > 0 || idx_may_be_null) {

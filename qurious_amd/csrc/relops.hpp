@@ -21,6 +21,10 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
 uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel);
 // out[k] = col[idx[k]] (device u32 indices, kNullIdx -> NULL when idx_may_be_null)
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null);
+// make sure every Utf8 column used directly as a key (roots are Column nodes) has its longest-value length cached in the
+// table and copied into icols (packed key words are sized from it)
+void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,
+                             std::vector<InputCol>& icols);
 // key words [W][N] + validity bitmap of the key expressions `roots`
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
                     KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false);

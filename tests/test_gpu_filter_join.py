@@ -195,3 +195,26 @@ def test_join_then_aggregate_stays_on_device(ctx, oracle):
     got = sorted(rows_of(agg.execute()))
     want = sorted(rows_of(oracle.execute(agg)))
     assert got == want and len(got) > 100
+
+
+def test_utf8_keys_longer_than_one_word(ctx, oracle):
+    """Utf8 group / join keys are packed into 1..4 key words sized from the column's longest value (<= 31 bytes)"""
+    rng = np.random.default_rng(77)
+    segs = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY", "", "4-NOT SPECIFIED", "x" * 31, "y" * 16, "ab"]
+    n = 20000
+    schema = pa.schema([pa.field("seg", pa.string()), pa.field("v", I64)])
+    batch = pa.RecordBatch.from_arrays([pa.array([segs[k] for k in rng.integers(0, len(segs), n)], type=pa.string(), mask=rng.random(n) < 0.05),
+                                        pa.array(rng.integers(0, 1000, n), type=I64)], schema=schema)
+    scan = table_scan(schema, [batch.slice(0, 9000), batch.slice(9000, 11000)])
+    agg = q.HashAggregate(None, scan, [col("seg", 0)], [q.SumAggregateExpr(col("v", 1), I64), q.CountAggregateExpr(lit_i64(1))])
+    assert sorted(rows_of(agg.execute()), key=repr) == sorted(rows_of(oracle.execute(agg)), key=repr)
+    # join on the string key: right side has shorter strings only -> both sides still pack to the same width
+    rs = pa.schema([pa.field("name", pa.string()), pa.field("w", I64)])
+    rb = pa.RecordBatch.from_arrays([pa.array(["BUILDING", "ab", "MACHINERY", "zz", None, "BUILDING"]), pa.array([1, 2, 3, 4, 5, 6], type=I64)], schema=rs)
+    for jt in (JoinType.Inner, JoinType.Left, JoinType.Full):
+        plan = q.HashJoinExec.try_new(table_scan(rs, [rb]), scan, jt, [(col("name", 0), col("seg", 0))], None)
+        _batches_equal(plan.execute(), oracle.execute(plan))
+    long_schema = pa.schema([pa.field("s", pa.string())])
+    long_scan = table_scan(long_schema, [pa.RecordBatch.from_arrays([pa.array(["z" * 32, "a"])], schema=long_schema)])
+    with pytest.raises(q.UnsupportedError, match="longer than 31 bytes"):
+        q.HashAggregate(None, long_scan, [col("s", 0)], [q.CountAggregateExpr(lit_i64(1))]).execute()

@@ -53,6 +53,11 @@ def test_partition_by_key_matches_mirror_and_roundtrips(ctx, oracle):
         got = rows_of(part.to_batches())
         want = rows_of([batch.filter(pa.array(pid == p))])
         assert got == want            # rows keep their relative order inside a part
+    # Utf8 partition key (packed into 4 words on both sides of the exchange)
+    sparts = exchange.partition_by_key(dev, [col("s", 1)], 3)
+    spid = oracle.partition_ids([batch.column("s")], 3)
+    for p, part in enumerate(sparts):
+        assert rows_of(part.to_batches()) == rows_of([batch.filter(pa.array(spid == p))])
     back = exchange.concat_tables(parts)
     assert sorted(rows_of(back.to_batches()), key=repr) == sorted(rows_of([batch]), key=repr)
     # raw buffers -> qhip_table_from_device -> same rows (what the all-to-all receiver does)
