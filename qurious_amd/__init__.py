@@ -10,6 +10,7 @@ from ._ffi import (ArrowError, Context, DeviceTable, HipError, InternalError, Qu
 from .datatypes import JoinSide, JoinType, Operator, ScalarValue  # noqa: F401
 from .expr import (AvgAggregateExpr, BinaryExpr, CastExpr, Column, CountAggregateExpr, IsNotNull, IsNull,  # noqa: F401
                    Literal, MaxAggregateExpr, MinAggregateExpr, Negative, PhysicalExpr, SumAggregateExpr, avg_return_type)
+from .planner import DefaultQueryPlanner  # noqa: F401
 from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, MemoryTable, NoGroupingAggregate, PhysicalPlan,  # noqa: F401
                    Scan, build_join_schema)
 

@@ -119,20 +119,46 @@ void ExprGen::emit(int k, std::string& out) {
     case QHIP_EXPR_COLUMN: {
       const int s = col_slot(n.column);
       const std::string S = std::to_string(s);
+      // `ld` receives the loads; in raw mode they go to load_code (fields of `Raw w`) and only aliases are emitted here
+      std::ostringstream ld;
+      const std::string W = raw_ ? "w." : "";
+      const std::string decl = raw_ ? "" : "const ";
+      auto field = [&](const std::string& type, const std::string& name) { if (raw_) raw_fields += "    " + type + " " + name + ";\n"; };
       if (n.type.id == QHIP_UTF8) {
-        o << "    const int* o" << K << " = (const int*)a.c[" << S << "].v" << base_ << "; const int b" << K << " = o" << K << "[" << idx_ << "];\n";
-        o << "    const int l" << K << " = o" << K << "[" << idx_ << " + 1] - b" << K << "; const u8* p" << K << " = a.c[" << S << "].d + b" << K << ";\n";
+        field("int", "b" + K); field("int", "l" + K);
+        ld << "    " << (raw_ ? "" : "const int ") << W << "b" << K << " = ((const int*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
+        ld << "    " << (raw_ ? "" : "const int ") << W << "l" << K << " = ((const int*)a.c[" << S << "].v" << base_ << ")[" << idx_ << " + 1] - " << W << "b" << K << ";\n";
+        if (raw_) {
+          auto it = utf8_key_words_.find(k);
+          if (it != utf8_key_words_.end()) {
+            field("u64", "k" + K + "[" + std::to_string(it->second) + "]");
+            for (int w2 = 0; w2 < it->second; ++w2)
+              ld << "    w.k" << K << "[" << w2 << "] = *(const qh_u64_unaligned*)(a.c[" << S << "].d + w.b" << K << " + " << 8 * w2 << ");\n";
+          }
+          o << "    const int l" << K << " = w.l" << K << "; const u8* p" << K << " = a.c[" << S << "].d + w.b" << K << ";\n";
+        } else {
+          ld << "    const u8* p" << K << " = a.c[" << S << "].d + b" << K << ";\n";
+        }
       } else if (n.type.id == QHIP_BOOL) {
-        o << "    const bool " << v << " = qh_bit((const u8*)a.c[" << S << "].v, " << row_ << ");\n";
+        field("bool", v);
+        ld << "    " << (raw_ ? "" : "const bool ") << W << v << " = qh_bit((const u8*)a.c[" << S << "].v, " << row_ << ");\n";
+        if (raw_) o << "    const bool " << v << " = w." << v << ";\n";
       } else if (n.type.id == QHIP_NULL) {
         o << "    const int " << v << " = 0;\n";
       } else {
-        o << "    const " << ctype(n.type) << " " << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
+        field(ctype(n.type), v);
+        ld << "    " << (raw_ ? "" : "const " + ctype(n.type) + " ") << W << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
+        if (raw_) o << "    const " << ctype(n.type) << " " << v << " = w." << v << ";\n";
       }
       if (n.nullable) {
         if (n.type.id == QHIP_NULL) o << "    const bool " << nn << " = false;\n";
-        else o << "    const bool " << nn << " = qh_bit(a.c[" << S << "].n, " << row_ << ");\n";
+        else {
+          field("bool", nn);
+          ld << "    " << (raw_ ? "" : "const bool ") << W << nn << " = qh_bit(a.c[" << S << "].n, " << row_ << ");\n";
+          if (raw_) o << "    const bool " << nn << " = w." << nn << ";\n";
+        }
       }
+      if (raw_) load_code += ld.str(); else o << ld.str();
       break;
     }
     case QHIP_EXPR_LITERAL: {
@@ -215,7 +241,7 @@ void ExprGen::emit(int k, std::string& out) {
             };
             o << "    const double " << v << " = " << tof(l, lv) << " / " << tof(r, rv) << ";\n";
           } else if (n.op == QHIP_OP_MUL) {
-            o << "    const i128 " << v << " = (i128)((u128)" << lv << " * (u128)" << rv << ");\n";
+            o << "    const i128 " << v << " = " << (raw_ ? "qh_mul_i128(" : "qh_mul_i128_plain(") << lv << ", " << rv << ");\n";
           } else {
             const int s = n.type.scale;
             std::string a = "(u128)" + lv, b = "(u128)" + rv;
@@ -398,7 +424,10 @@ static void emit_key_words(ExprGen& g, const ExprSet& es, const std::vector<KeyD
     const std::string w = dst + "[" + std::to_string(kd.word_off) + "]";
     std::string value;
     if (kd.type.id == QHIP_UTF8) {
-      o << "    u64 ks" << k << "[" << kd.words << "]; qh_pack_str<" << kd.words << ">(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ", ks" << k << ");\n";
+      if (g.raw_key_prefetched(kd.root))
+        o << "    u64 ks" << k << "[" << kd.words << "]; qh_pack_words<" << kd.words << ">(w.k" << kd.root << ", " << g.len(kd.root) << ", ks" << k << ");\n";
+      else
+        o << "    u64 ks" << k << "[" << kd.words << "]; qh_pack_str<" << kd.words << ">(" << g.ptr(kd.root) << ", " << g.len(kd.root) << ", ks" << k << ");\n";
       o << "    if (" << okx << " && " << g.len(kd.root) << " > " << 8 * kd.words - 1 << ") err |= " << (1u << QS_KEY_TOO_LONG) << "u;\n";
       for (int w2 = 0; w2 < kd.words; ++w2)
         o << "    " << dst << "[" << kd.word_off + w2 << "] = " << (kd.nullable ? okx + " ? " : std::string("")) << "ks" << k << "[" << w2 << "]"
@@ -537,6 +566,9 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   // tile-relative addressing: uniform 64-bit tile base (SGPRs) + 32-bit lane offset, so that a load needs one VALU
   // instruction for its address instead of a 64-bit multiply-add chain per column
   g.set_indexing(" + tb", "o", "(tb + (i64)o)");
+  g.set_raw_mode(true);
+  for (auto& kd : P.keys)
+    if (kd.type.id == QHIP_UTF8 && es.at(kd.root).kind == QHIP_EXPR_COLUMN) g.mark_utf8_key(kd.root, kd.words);
   std::ostringstream s;
   const int KW = P.W > 0 ? P.W : 1;
   s << "struct P {\n";
@@ -562,30 +594,33 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   }
   s << "  };\n";
   // eval
-  // straight-line code: every load of the row is issued unconditionally so that the loads of all R rows of a
-  // tile are in flight together (a branch on the predicate would serialise the memory latencies)
-  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const i64 tb, const u32 o, Row& r, u32& err) {\n";
+  // two phases per row: load() is branch-free and only issues the row's loads into `Raw w` (the kernel calls it for all R
+  // rows of a tile first, so their memory latencies overlap); eval() computes predicate, keys and aggregate arguments
+  // from w and may contain control flow (string compares, the tiered decimal multiply) without serialising any load
+  std::ostringstream ev;
   std::string code;
   if (predicate_root >= 0) {
     g.emit(predicate_root, code);
-    s << code;
-    s << "    r.pass = " << g.ok(predicate_root) << " && " << g.val(predicate_root) << ";\n";
+    ev << code;
+    ev << "    r.pass = " << g.ok(predicate_root) << " && " << g.val(predicate_root) << ";\n";
   } else {
-    s << "    r.pass = true;\n";
+    ev << "    r.pass = true;\n";
   }
   code.clear();
   emit_key_words(g, es, P.keys, P.null_mask_word, "r.key", code, nullptr);
-  s << code;
+  ev << code;
   for (size_t a = 0; a < P.args.size(); ++a) {
     code.clear();
     g.emit(P.args[a].root, code);
-    s << code;
+    ev << code;
     bool value_needed = false;
     for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
-    if (value_needed) s << "    r.a" << a << " = " << g.val(P.args[a].root) << ";\n";
-    if (P.args[a].nullable) s << "    r.h" << a << " = " << g.ok(P.args[a].root) << ";\n";
+    if (value_needed) ev << "    r.a" << a << " = " << g.val(P.args[a].root) << ";\n";
+    if (P.args[a].nullable) ev << "    r.h" << a << " = " << g.ok(P.args[a].root) << ";\n";
   }
-  s << "  }\n";
+  s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
+  s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
+  s << "  __device__ static __forceinline__ void eval(const KArgs& a, const Raw& w, Row& r, u32& err) {\n" << ev.str() << "  }\n";
   // part_init
   s << "  __device__ static __forceinline__ void part_init(Part& p) {\n";
   for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";

@@ -1,6 +1,7 @@
 // codegen.hpp — turns typed expression trees into the policy structs the hand-written kernel
 // templates of device/qhip_device.hpp are instantiated with.
 #pragma once
+#include <map>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,12 @@ class ExprGen {
   KernelBindings bind;
   // how a column element is addressed in the generated code: ((T*)col + base)[idx]; `row` is the absolute row (bitmaps)
   void set_indexing(const std::string& base, const std::string& idx, const std::string& row) { base_ = base; idx_ = idx; row_ = row; }
+  // raw mode: column loads are collected into `load_code` (branch-free, writes fields of `Raw w`) and the expression code
+  // only aliases those fields, so a kernel can issue the loads of several rows before any row's (branchy) computation
+  void set_raw_mode(bool on) { raw_ = on; }
+  void mark_utf8_key(int node, int words) { utf8_key_words_[node] = words; }
+  bool raw_key_prefetched(int node) const { return raw_ && utf8_key_words_.count(node) > 0; }
+  std::string raw_fields, load_code;
   static std::string ctype(const DType& t);
   static std::string i128_const(i128 v);
 
@@ -39,6 +46,8 @@ class ExprGen {
   const std::vector<InputCol>& in_;
   std::vector<bool> done_;
   std::string base_ = "", idx_ = "i", row_ = "i";
+  bool raw_ = false;
+  std::map<int, int> utf8_key_words_;
 };
 
 // ---------------------------------------------------------------- aggregate plan

@@ -79,6 +79,17 @@ template <int N> __device__ __forceinline__ void qh_pack_str(const u8* p, int le
   }
   out[N - 1] |= (u64)l << 56;
 }
+// the same packing from bytes already loaded as N unaligned words (load phase of a split load/eval policy)
+template <int N> __device__ __forceinline__ void qh_pack_words(const u64* raw, int len, u64* out) {
+  const int l = len > 8 * N - 1 ? 8 * N - 1 : len;
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const int nb = l - 8 * w;
+    const u64 mask = nb <= 0 ? 0ULL : (nb >= 8 ? ~0ULL : (~0ULL >> (64 - 8 * nb)));
+    out[w] = raw[w] & mask;
+  }
+  out[N - 1] |= (u64)l << 56;
+}
 __device__ __forceinline__ void qh_report(u32* status, u32 err) {
   if (err) for (int b = 0; b < QS_WORDS; ++b) if ((err >> b) & 1u) atomicOr(&status[b], 1u);
 }
@@ -93,6 +104,22 @@ __device__ __forceinline__ bool qh_streq(const u8* a, int la, const u8* b, int l
   for (int k = 0; k < la; ++k) if (a[k] != b[k]) return false;
   return true;
 }
+// Wrapping 128-bit product with wave-uniform fast paths: Decimal128 operands of real tables are small (TPC-H money
+// fits 32..40 bits), and a generic 128 x 128 multiply costs ~45 VALU instructions. If every active lane's operands
+// fit i32 the product is one 32 x 32 -> 64 multiply; if they fit i64 it is a 64 x 64 -> 128 multiply; else the full one.
+__device__ __forceinline__ i128 qh_mul_i128(i128 a, i128 b) {
+  const i64 alo = (i64)(u64)(u128)a, blo = (i64)(u64)(u128)b;
+  const bool fit64 = ((i128)alo == a) && ((i128)blo == b);
+  const bool fit32 = fit64 && ((i64)(int)alo == alo) && ((i64)(int)blo == blo);
+  if (__all(fit32)) return (i128)((i64)(int)alo * (i64)(int)blo);
+  if (__all(fit64)) {
+    const u64 lo = (u64)alo * (u64)blo;
+    const i64 hi = __mul64hi(alo, blo);
+    return qh_mk128(lo, hi);
+  }
+  return (i128)((u128)a * (u128)b);
+}
+__device__ __forceinline__ i128 qh_mul_i128_plain(i128 a, i128 b) { return (i128)((u128)a * (u128)b); }   // branch-free form
 __device__ __forceinline__ i128 qh_pow10(int e) { i128 r = 1; for (int k = 0; k < e; ++k) r *= 10; return r; }
 
 // ------------------------------------------------------------------ wavefront primitives (wave64)
@@ -267,7 +294,8 @@ __device__ __forceinline__ u64* qh_find_or_insert(u64* table, u32 nslots /*pow2*
 //   SLOT_WORDS   u64 words per slot: 1 state + W key + cells
 //   struct Row   { bool pass; u64 key[W]; <per-argument value + validity> }
 //   struct Part  per-cell partial aggregate of one (thread, key)
-//   eval(a, i, row, err)                load row i (branch-free), evaluate predicate/keys/arguments; status bits into err
+//   load(a, tb, o, raw)                 issue the loads of row tb + o into `raw` (branch-free)
+//   eval(a, raw, row, err)              predicate / key words / aggregate arguments from raw; status bits into err
 //   part_init(p) / part_add<ROWS>(p, row, m)  thread-local accumulate of rows with m == true (ROWS: count them too)
 //   part_reduce<ROWS>(p)                wavefront reduction (all lanes active); part_set_rows(p, n) sets the row count
 //   (every cell's identity is all-zero bits, so a zero-filled table needs no per-slot initialisation)
@@ -360,14 +388,21 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     const u32 overflowed = W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     typename P::Row row[R];
     const i64 tb = t * tile_rows;
+    typename P::Raw raw[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      // out-of-range lanes re-read the table's last row (no branch around the loads) and are masked out afterwards;
-      // addressing is (uniform 64-bit tile base) + (32-bit lane offset)
+      // phase 1: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
+      // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
       const u32 o = (u32)r * QH_BLOCK + (u32)tid;
       const bool inb = tb + (i64)o < a.nrows;
+      P::load(a, tb, inb ? o : (u32)(a.nrows - 1 - tb), raw[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // phase 2: predicate, key words and aggregate arguments of each row (may branch)
+      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < a.nrows;
       u32 e = 0;
-      P::eval(a, tb, inb ? o : (u32)(a.nrows - 1 - tb), row[r], e);
+      P::eval(a, raw[r], row[r], e);
       row[r].pass = row[r].pass && inb;
       err |= inb ? e : 0u;
     }

@@ -120,10 +120,11 @@ def _filter_device(table: DeviceTable, predicate: Optional[PhysicalExpr], projec
     ctx = table.ctx
     ea = ExprArray()
     root = -1
+    if predicate is not None and projection is not None:
+        # memory.rs:79-93: the projection is applied first (column buffers are shared, nothing is copied), the filter
+        # then sees — and indexes — the projected batch
+        return _filter_device(_filter_device(table, None, projection), predicate, None)
     if predicate is not None:
-        if projection is not None:
-            # memory.rs:79-93: the projection is applied first, the filter then sees the projected batch
-            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "scan with both projection and filter is not used by the planner")
         root = ea.lower(predicate)
     arr, n = ea.c_array()
     out = C.c_void_p()

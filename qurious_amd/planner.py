@@ -1,0 +1,38 @@
+"""Physical-planner choices of the reference for the hot path (planner/mod.rs:174-321), restated at the physical level:
+which node a filter / aggregate / table scan / join becomes. The logical plan, the SQL front-end and the optimizer are out
+of scope; a Rust `HipQueryPlanner` makes exactly these choices."""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import pyarrow as pa
+
+from . import _ffi
+from .datatypes import JoinType
+from .expr import AggregateExpr, PhysicalExpr
+from .plan import Filter, HashAggregate, HashJoinExec, JoinFilter, MemoryTable, NoGroupingAggregate, PhysicalPlan, Scan
+
+
+class DefaultQueryPlanner:
+    def physical_plan_filter(self, input: PhysicalPlan, predicate: PhysicalExpr) -> PhysicalPlan:
+        """planner/mod.rs:174-179"""
+        return Filter(input, predicate)
+
+    def physical_plan_aggregate(self, schema: pa.Schema, input: PhysicalPlan, group_expr: Sequence[PhysicalExpr],
+                                aggr_expr: Sequence[AggregateExpr]) -> PhysicalPlan:
+        """planner/mod.rs:181-242: NoGroupingAggregate iff there is no GROUP BY expression, else HashAggregate"""
+        if len(group_expr) == 0:
+            return NoGroupingAggregate(schema, input, aggr_expr)
+        return HashAggregate(schema, input, group_expr, aggr_expr)
+
+    def physical_plan_table_scan(self, schema: pa.Schema, source: MemoryTable, filter: Optional[PhysicalExpr]) -> PhysicalPlan:
+        """planner/mod.rs:244-257: projections are always None (no projection pushdown), the pushed-down filter rides along"""
+        return Scan(schema, source, None, filter)
+
+    def physical_plan_join(self, left: PhysicalPlan, right: PhysicalPlan, join_type: JoinType,
+                           on: Sequence[Tuple[PhysicalExpr, PhysicalExpr]], filter: Optional[JoinFilter]) -> PhysicalPlan:
+        """planner/mod.rs:265-321: HashJoinExec iff there are equi-join keys; otherwise the reference builds a
+        NestedLoopJoinExec, which is outside the accelerated path (the shim keeps the CPU node)"""
+        if len(on) == 0:
+            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "join without equi-keys: NestedLoopJoinExec stays on the CPU path")
+        return HashJoinExec.try_new(left, right, join_type, on, filter)

