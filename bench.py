@@ -76,6 +76,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = plan.execute_device()
+    ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -219,6 +220,7 @@ def main():
     for _ in range(args.steps):
         plan.execute_device()
         kernel_ms.append(ctx.last_stats()["main_kernel_ms"])
+    ctx.synchronize()   # the result table of the last step is ordered on libqhip's stream
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -173,6 +173,9 @@ const char* qhip_last_error(const qhip_ctx* ctx);  /* ctx may be NULL: last crea
 const char* qhip_version(void);
 /* 1 if a HIP device is visible to this process (does not create a context) */
 int qhip_device_available(void);
+/* Operators return as soon as their result is ordered on the context's stream; wait for it explicitly before handing raw
+ * device pointers (qhip_table_column_buffer) to another stream or library. Downloads (qhip_table_to_arrow) wait by themselves. */
+int qhip_ctx_synchronize(qhip_ctx* ctx);
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out);
 int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
 

@@ -121,6 +121,7 @@ def load_library() -> C.CDLL:
             "qhip_version": (C.c_char_p, []),
             "qhip_device_available": (C.c_int, []),
             "qhip_ctx_last_stats": (C.c_int, [vp, P(qhip_exec_stats)]),
+            "qhip_ctx_synchronize": (C.c_int, [vp]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
             "qhip_table_to_arrow": (C.c_int, [vp, vp, i64, vp, vp]),
@@ -173,6 +174,9 @@ class Context:
         d = {f[0]: getattr(st, f[0]) for f in qhip_exec_stats._fields_}
         d["main_kernel_name"] = st.main_kernel_name.decode()
         return d
+
+    def synchronize(self):
+        self.check(self.lib.qhip_ctx_synchronize(self.handle))
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 
@@ -49,8 +51,13 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
     DevColumn dc;
     dc.type = hc.type; dc.length = nrows; dc.null_count = hc.null_count;
     auto up = [&](const void* src, size_t n) {
+      // asynchronous upload: the bytes are moved into a staging vector owned by the table, so no synchronisation is needed
       auto b = std::make_shared<DevBuf>(n);
-      if (n) QHIP_HIP_CHECK(hipMemcpyAsync(b->ptr, src, n, hipMemcpyHostToDevice, ctx->stream));
+      if (n) {
+        auto stage = std::make_shared<std::vector<uint8_t>>((const uint8_t*)src, (const uint8_t*)src + n);
+        t->host_keepalive.push_back(stage);
+        QHIP_HIP_CHECK(hipMemcpyAsync(b->ptr, stage->data(), n, hipMemcpyHostToDevice, ctx->stream));
+      }
       return b;
     };
     if (hc.null_count > 0 && hc.type.id != QHIP_NULL) {
@@ -69,7 +76,6 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
     }
     t->cols.push_back(std::move(dc));
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return t.release();
 }
 
@@ -123,6 +129,12 @@ static double ord_to_f64(uint64_t k) {
 static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, int pred_root,
                                   const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs,
                                   const char* const* out_names) {
+  const bool trace = getenv("QHIP_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace) fprintf(stderr, "[qhip agg] %-28s %8.1f us\n", what,
+                       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   if (n_groups < 0 || n_aggs < 0 || (n_groups > 0 && !group_roots) || (n_aggs > 0 && !aggs) || (n_exprs > 0 && !exprs))
     fail(QHIP_INVALID_ARGUMENT, "qhip_hash_aggregate_execute: bad arguments");
@@ -133,10 +145,36 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
 
   std::vector<InputCol> icols = input_cols_of(in);
   ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
-  ExprSet es;
-  es.build(exprs, n_exprs, icols);
-  AggPlan plan;
-  plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, env_int("QHIP_AGG_R", 0), plan);
+  // lowered plans are cached per context: a repeated query (same expression PODs over the same column signature) skips
+  // typing and code generation; literal VALUES are part of the key because they are bound into the plan's KernelBindings
+  std::string key = "agg|";
+  auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
+  for (auto& ic : icols) { const int v[5] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len}; put(v, sizeof v); }
+  for (int k = 0; k < n_exprs; ++k) {
+    qhip_expr e = exprs[k];
+    const char* str = e.lit_str; const int64_t len = e.lit_len;
+    e.lit_str = nullptr;
+    put(&e, sizeof e);
+    if (str && len > 0 && e.kind == QHIP_EXPR_LITERAL) put(str, (size_t)len);
+  }
+  put(&pred_root, sizeof pred_root);
+  put(group_roots, sizeof(int32_t) * (size_t)n_groups);
+  put(aggs, sizeof(qhip_agg) * (size_t)n_aggs);
+  const int r_env = env_int("QHIP_AGG_R", 0), kc_env = env_int("QHIP_AGG_KC", -1);
+  put(&r_env, sizeof r_env); put(&kc_env, sizeof kc_env);
+  std::shared_ptr<AggPlan> plan_ptr;
+  auto cached = ctx->plan_cache.find(key);
+  if (cached != ctx->plan_cache.end()) plan_ptr = std::static_pointer_cast<AggPlan>(cached->second);
+  else {
+    ExprSet es;
+    es.build(exprs, n_exprs, icols);
+    plan_ptr = std::make_shared<AggPlan>();
+    plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, r_env, *plan_ptr);
+    if (ctx->plan_cache.size() > 4096) ctx->plan_cache.clear();
+    ctx->plan_cache[key] = plan_ptr;
+  }
+  const AggPlan& plan = *plan_ptr;
+  mark("planned");
 
   // output schema: keys then aggregates (hash.rs:166-169)
   std::vector<std::string> names;
@@ -158,6 +196,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   HKArgs ka;
   DevBuf strlit;
   fill_kargs(ctx, in, plan.bind, ka, strlit);
+  mark("module + kargs");
 
   const int64_t N = in->num_rows;
   const int slot_bytes = plan.slot_words * 8;
@@ -183,10 +222,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
   uint32_t cap = plan.W == 0 ? 1 : std::min<uint32_t>(cap_max, (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 4096));
   uint32_t replicas = plan.W == 0 ? 1 : (uint32_t)std::max(1, env_int("QHIP_AGG_REPLICAS", 32));
-  DevBuf gtable;
+  DevBuf gtable, dense;
   uint32_t status[QS_WORDS];
   int retries = 0;
   float main_ms = 0;
+  uint32_t G = 0, guess = 0;
+  std::vector<uint64_t> slots;
+  // dense slots fetched together with the status words (one sync), through the context's page-locked scratch
+  const uint32_t PRE = (uint32_t)std::min<size_t>(256, (ctx->pinned_bytes - 64 - 8) / (size_t)slot_bytes);
+  uint32_t* status_pinned = (uint32_t*)ctx->pinned;
+  uint64_t* pre_host = (uint64_t*)((uint8_t*)ctx->pinned + 64);
   for (;;) {
     const size_t table_bytes = (size_t)cap * replicas * slot_bytes;
     gtable.alloc(table_bytes);
@@ -204,8 +249,24 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (N > 0)
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
-    QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    if (plan.W == 0) {
+      QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      // speculative compaction right behind the kernel: [counter | dense slots]; the common case (few groups, no
+      // overflow) then needs a single synchronisation for status + result
+      const uint32_t total_slots = cap * replicas;
+      guess = std::min<uint32_t>(total_slots, 8192);
+      dense.alloc((size_t)guess * slot_bytes + 8);
+      QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
+      launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
+      const uint32_t pre = std::min(PRE, guess);
+      QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, dense.ptr, 8 + (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    mark("launched");
     QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(status, status_pinned, sizeof(status));
+    mark("synchronised");
     QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;
@@ -215,32 +276,30 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ++retries;
   }
 
-  // ---- dense slots -> host: one compaction launch into a buffer sized for the common case (few groups); a second
-  //      launch with the exact size only when there are more groups than that
-  uint32_t G = 0;
-  std::vector<uint64_t> slots;
+  // ---- dense slots -> host (few groups) or kept on the device (many groups)
   DevBuf dense_keep;                                   // [counter | dense slots] when the output is assembled on the device
   const uint32_t dev_threshold = (uint32_t)env_int("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", 4096);
   if (plan.W == 0) {
     G = 1;
-    slots.resize((size_t)plan.slot_words);
-    copy_sync(ctx->stream, slots.data(), gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost);
+    slots.assign(pre_host, pre_host + plan.slot_words);
   } else {
+    G = (uint32_t)pre_host[0];
     const uint32_t total_slots = cap * replicas;
-    uint32_t guess = std::min<uint32_t>(total_slots, 8192);
-    for (int pass = 0; pass < 2; ++pass) {
-      DevBuf dense((size_t)guess * slot_bytes + 8);   // [counter | slots]
+    if (G > guess) {
+      // more groups than the speculative buffer holds: compact again with the exact size
+      guess = G;
+      dense.alloc((size_t)guess * slot_bytes + 8);
       QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
       launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
-      QHIP_HIP_CHECK(hipMemcpyAsync(&G, dense.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      if (G <= guess) {
-        if (replicas == 1 && G >= dev_threshold) { dense_keep = std::move(dense); break; }   // stays on the device
-        slots.resize((size_t)G * plan.slot_words);
-        if (G) copy_sync(ctx->stream, slots.data(), dense.as<uint64_t>() + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
-        break;
-      }
-      guess = G;
+    }
+    if (replicas == 1 && G >= dev_threshold) {
+      dense_keep = std::move(dense);
+    } else if (G <= std::min(PRE, guess)) {
+      slots.assign(pre_host + 1, pre_host + 1 + (size_t)G * plan.slot_words);
+    } else {
+      slots.resize((size_t)G * plan.slot_words);
+      copy_sync(ctx->stream, slots.data(), dense.as<uint64_t>() + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
     }
     if (replicas > 1 && G > 1) {
       // merge the replicas: same key words -> one slot; every cell is a commutative monoid (wrapping adds, max)
@@ -492,7 +551,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
   }
   set_stats();
-  return table_from_host(ctx, names, nullable, cols, G, false);
+  mark("assembled");
+  qhip_table* result = table_from_host(ctx, names, nullable, cols, G, false);
+  mark("result table");
+  return result;
 }
 
 }  // namespace qhip

@@ -106,6 +106,7 @@ struct qhip_table {
   std::vector<qhip::DevColumn> cols;
   int64_t num_rows = 0;
   std::vector<int64_t> batch_offsets;     // size = num_batches + 1; batch b = rows [off[b], off[b+1])
+  std::vector<std::shared_ptr<std::vector<uint8_t>>> host_keepalive;   // staging of asynchronous host->HBM uploads
   int64_t num_batches() const { return (int64_t)batch_offsets.size() - 1; }
 };
 
@@ -123,7 +124,10 @@ struct Ctx {
   qhip_exec_stats stats;
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
+  void* pinned = nullptr;            // small page-locked scratch for status / result read-backs (truly asynchronous D2H)
+  size_t pinned_bytes = 0;
   std::string cache_dir;
+  std::unordered_map<std::string, std::shared_ptr<void>> plan_cache;   // lowered plans keyed by their POD description
 };
 
 // wraps a C entry point: runs f(), converts exceptions to status codes + last_error

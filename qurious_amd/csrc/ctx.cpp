@@ -222,6 +222,8 @@ int qhip_ctx_create(int device_index, qhip_ctx** out) {
     QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
     c->status.alloc(QS_WORDS * sizeof(uint32_t));
+    c->pinned_bytes = 256 * 1024;
+    QHIP_HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
     memset(&c->stats, 0, sizeof(c->stats));
     const char* cd = getenv("QHIP_KERNEL_CACHE");
     c->cache_dir = cd ? cd : "";
@@ -234,6 +236,7 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->modules.clear();
   ctx->status.release();
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -245,6 +248,11 @@ const char* qhip_last_error(const qhip_ctx* ctx) {
   std::lock_guard<std::mutex> l(g_err_mu);
   copy = g_err;
   return copy.c_str();
+}
+
+int qhip_ctx_synchronize(qhip_ctx* ctx) {
+  if (!ctx) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] { QHIP_HIP_CHECK(hipSetDevice(ctx->device)); QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); });
 }
 
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {

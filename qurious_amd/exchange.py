@@ -139,6 +139,7 @@ def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> 
     ctx = parts[0].ctx
     ncols = len(schema)
     dev = torch.device("cuda", torch.cuda.current_device())
+    ctx.synchronize()   # the parts were produced on libqhip's stream; RCCL reads them on torch's
     # metadata: rows, then per column (null_count, data_bytes)
     metas = []
     for p in parts:
