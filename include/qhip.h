@@ -285,6 +285,11 @@ int qhip_plan_filter_source(const qhip_dtype* col_types, const int32_t* col_has_
 int qhip_plan_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
                           const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
                           char* buf, size_t buflen, size_t* needed);
+/* The fused probe kernel of qhip_hash_join_execute (scan filter + key words + table lookup + ordered pair emit) for the
+ * probe side's key expressions; predicate_root = -1 for no fused scan filter. */
+int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                           const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
+                           int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
 

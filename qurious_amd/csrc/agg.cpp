@@ -115,10 +115,6 @@ static uint32_t pow2_ceil(uint64_t x) {
   while (p < x) p <<= 1;
   return (uint32_t)std::min<uint64_t>(p, 1ULL << 31);
 }
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 static double ord_to_f64(uint64_t k) {
   uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
@@ -222,6 +218,11 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
   uint32_t cap = plan.W == 0 ? 1 : std::min<uint32_t>(cap_max, (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 4096));
   uint32_t replicas = plan.W == 0 ? 1 : (uint32_t)std::max(1, env_int("QHIP_AGG_REPLICAS", 32));
+  if (plan.W > 0 && plan.last_groups > cap / 4) {
+    // the same plan produced many groups last time: go straight to one table with room for them
+    cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(1u << 16, pow2_ceil((uint64_t)plan.last_groups * 2)));
+    replicas = 1;
+  }
   DevBuf gtable, dense;
   uint32_t status[QS_WORDS];
   int retries = 0;
@@ -340,6 +341,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
   }
 
+  plan.last_groups = G;
   auto set_stats = [&]() {
     ctx->stats.main_kernel_ms = main_ms;
     ctx->stats.total_device_ms = main_ms;

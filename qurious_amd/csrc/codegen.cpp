@@ -725,7 +725,8 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
   out.bind = g.bind;
 }
 
-void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root) {
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root,
+               bool probe_kernel) {
   out = KeysPlan();
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
@@ -744,10 +745,13 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
   s << "    return " << all << ";\n  }\n};\n";
-  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
-       "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
+  if (probe_kernel)
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P>(a, L); }\n";
+  else
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
+         "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
   out.source = s.str();
-  out.kernel_name = "qk_eval_keys";
+  out.kernel_name = probe_kernel ? "qk_join_probe" : "qk_eval_keys";
   out.bind = g.bind;
 }
 

@@ -83,6 +83,7 @@ struct AggPlan {
   KernelBindings bind;
   std::string source;          // policy struct + extern "C" kernel, to be appended to the device header
   std::string kernel_name;
+  mutable uint32_t last_groups = 0;   // groups the plan produced the last time it ran (sizes the first table attempt)
 };
 
 // group_roots / aggs refer to nodes of `es`; predicate_root < 0 = no filter
@@ -97,6 +98,8 @@ struct KeysPlan {
   std::vector<KeyDesc> keys;
   KernelBindings bind; std::string source; std::string kernel_name;
 };
-void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1);
+// probe_kernel: emit qk_join_probe (fused filter + key + lookup + ordered pair emit, qh_join_probe_body) instead of qk_eval_keys
+void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
+               bool probe_kernel = false);
 
 }  // namespace qhip

@@ -154,4 +154,9 @@ template <class F> int guarded(qhip_ctx* c, F&& f) {
     return QHIP_INVALID_ARGUMENT;
   }
 }
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 }  // namespace qhip

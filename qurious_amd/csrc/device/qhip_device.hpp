@@ -550,6 +550,115 @@ __device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32
   qh_report(status, err);
 }
 
+// ------------------------------------------------------------------ hash join: fused scan-filter + key + probe + ordered emit
+// read-only lookup in the distinct-key table of the build side (slot = [state][key words W]) after the build kernels
+// have completed (plain cached loads)
+template <int W>
+__device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const u64* k, u64 h) {
+  u32 s = (u32)h & (nslots - 1);
+  for (u32 probes = 0; probes < nslots; ++probes) {
+    const u64* slot = table + (size_t)s * (1 + W);
+    if (slot[0] != QH_READY) return 0xFFFFFFFFu;
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) eq &= slot[1 + w] == k[w];
+    if (eq) return s;
+    s = (s + 1) & (nslots - 1);
+  }
+  return 0xFFFFFFFFu;
+}
+template <int W> __device__ __forceinline__ u64 qh_key_hash(const u64* k) {
+  u64 h = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) h = qh_mix64(h ^ k[w]);
+  return h;
+}
+
+struct ProbeLaunch {
+  const u64* table;      // distinct build keys
+  const u32* bloom;      // one bit per (hash >> 32) & bloom_mask: 0 => the key is not in the table (the filter stays in L2)
+  const u32* count;      // build rows per slot (unused when start == nullptr)
+  const u32* start;      // first position of a slot's rows in `rows` (nullptr: unique build keys, rows[slot] is the row)
+  const u32* rows;       // build rows grouped by slot, ascending inside a slot
+  u32* slot_of;          // out, per probe row: slot of its key, 0xFFFFFFFF = no match / NULL key / rejected by the filter
+  u32* tile_total;       // out, per tile of 64 * QH_PROBE_R consecutive probe rows (one wavefront's share): number of pairs
+  u32* visited;          // build-row bitmap to mark here (LeftSemi / LeftAnti without a residual filter) or nullptr
+  u32* status;
+  u32 nslots, bloom_mask;
+};
+
+#define QH_PROBE_R 4   // probe rows per thread and tile
+// Probe pass 1 (hash_join.rs:218-275 for every probe batch at once): evaluate the fused scan filter and the key words
+// straight from the probe table's columns, look the key up, keep only the slot per row (4 B) and the pair count per tile.
+// Pass 2 (k_join_emit) turns slots into ordered (build row, probe row) pairs once the tile totals have been scanned.
+// Phases, each a branch-free pass over the thread's R rows so that their loads are in flight together (a lookup is a
+// chain of dependent random reads; R independent chains per thread and many waves per CU hide its latency):
+// key words -> filter bit -> home slot of the table -> (rarely) the rest of the probe sequence -> row count.
+template <class P>
+__device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLaunch& L) {
+  constexpr int R = QH_PROBE_R, TILE = 64 * R, NW = QH_BLOCK / 64;
+  const int lane = qh_lane();
+  const i64 ntiles = (a.nrows + TILE - 1) / TILE;
+  u32 err = 0;
+  for (i64 tile = (i64)blockIdx.x * NW + (threadIdx.x >> 6); tile < ntiles; tile += (i64)gridDim.x * NW) {
+    u32 sid[R];
+    u64 k[R][P::W], h[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i64 i = tile * TILE + r * 64 + lane;
+      const bool inb = i < a.nrows;
+      u32 e = 0;
+      ok[r] = P::keys(a, inb ? i : a.nrows - 1, k[r], e) && inb;
+      err |= inb ? e : 0u;
+      h[r] = qh_key_hash<P::W>(k[r]);
+    }
+    u32 fw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) fw[r] = L.bloom[ok[r] ? (((u32)(h[r] >> 32) & L.bloom_mask) >> 5) : 0u];
+    u64 st[R], kw[R][P::W];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      ok[r] = ok[r] && ((fw[r] >> ((u32)(h[r] >> 32) & 31u)) & 1u);
+      const u64* slot = L.table + (size_t)(ok[r] ? ((u32)h[r] & (L.nslots - 1)) : 0u) * (1 + P::W);
+      st[r] = slot[0];
+#pragma unroll
+      for (int w = 0; w < P::W; ++w) kw[r][w] = slot[1 + w];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      sid[r] = 0xFFFFFFFFu;
+      if (ok[r] && st[r] == QH_READY) {
+        bool eq = true;
+#pragma unroll
+        for (int w = 0; w < P::W; ++w) eq &= kw[r][w] == k[r][w];
+        const u32 home = (u32)h[r] & (L.nslots - 1);
+        sid[r] = eq ? home : qh_join_find<P::W>(L.table, L.nslots, k[r], (u64)home + 1);   // collision: walk on from the next slot
+      }
+    }
+    u32 total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool found = sid[r] != 0xFFFFFFFFu;
+      const u32 c = L.start ? L.count[found ? sid[r] : 0u] : 1u;
+      total += found ? c : 0u;
+      const i64 i = tile * TILE + r * 64 + lane;
+      if (i < a.nrows) L.slot_of[i] = sid[r];
+    }
+    if (L.visited) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (sid[r] != 0xFFFFFFFFu) {
+          const u32 s0 = L.start ? L.start[sid[r]] : sid[r], c = L.start ? L.count[sid[r]] : 1u;
+          for (u32 q = 0; q < c; ++q) { const u32 b = L.rows[s0 + q]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
+        }
+    }
+    total = (u32)qh_wave_sum_u64(total);
+    if (lane == 0) L.tile_total[tile] = total;
+  }
+  qh_report(L.status, err);
+}
+
 // ------------------------------------------------------------------ expression -> key words kernel (hash join keys, partition keys)
 // Evaluates the W key words of every row into word-major arrays keys[w * nrows + i]; keyvalid bit i is
 // set when every key column of the row is non-null (NULL keys never match, hash_join.rs:191-215).

@@ -8,5 +8,6 @@ enum {
   QS_CAST_OVERFLOW = 3,  // cast with safe=false overflowed (cast.rs:15-18)
   QS_ARITH_OVERFLOW = 4, // checked arithmetic overflowed (integer MIN / -1)
   QS_LDS_SPILL = 5,      // informational: some keys bypassed the LDS-staged table
+  QS_MAXCOUNT = 7,       // value, not a flag: largest number of build rows sharing one join key
   QS_WORDS = 8
 };

@@ -1,20 +1,25 @@
 // join.cpp — qhip_hash_join_execute: HashJoinExec::execute (physical/plan/join/hash_join.rs:354-384).
 //
-//   build (left, hash_join.rs:148-175)    key words (JIT) -> open-addressing table of distinct keys -> rows grouped by slot
-//                                          with a stable radix sort (ascending build row inside a key, the order the
+//   build (left, hash_join.rs:148-175)    key words (JIT) -> open-addressing table of distinct keys + a one-bit-per-hash
+//                                          filter (stays in L2) -> unique keys: slot -> row; duplicated keys: rows grouped by
+//                                          slot with a stable radix sort (ascending build row inside a key, the order the
 //                                          reference's reverse-built chains yield) -> CSR start/count per slot
-//   probe (right, hash_join.rs:218-275)   key words (JIT) -> pass 1 matches per probe row -> scan -> pass 2 (build, probe) pairs
+//   probe (right, hash_join.rs:218-275)   pass 1 (JIT): fused scan filter + key words + lookup straight from the probe
+//                                          table's columns -> slot per probe row, pair count per 256-row tile -> scan
+//                                          -> pass 2: (build, probe) pairs in probe-row order
 //                                          [-> residual JoinFilter on an intermediate batch, join/mod.rs:125-154]
 //                                          -> visited bitmap -> Right/Full NULL padding (join/mod.rs:176-207)
 //   output (utils/batch.rs:18-61)         every column gathered by the index vectors; one batch per non-empty probe batch,
 //                                          then the unmatched-build / semi tail batch (hash_join.rs:277-343, 374-381)
-// All probe batches are probed in one launch; batch boundaries are recovered from the scanned offsets.
+// All probe batches are probed in one launch; batch boundaries are recovered from the pairs' (ascending) probe rows.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 
 #include "common.hpp"
 #include "device/qhip_status.h"
+#include "jit.hpp"
+#include "kargs_host.hpp"
 #include "kernels.hpp"
 #include "relops.hpp"
 
@@ -68,51 +73,113 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   les.build(lex, nlex, lcols);
   res.build(rex, nrex, rcols);
   KeysPlan lkp, rkp;
-  DevBuf lkeys, lvalid, rkeys, rvalid;
+  DevBuf lkeys, lvalid;
   hipEventRecord(ctx->ev[0], s);
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
   QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
   eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
-  eval_key_words(ctx, R, res, rcols, on_r, n_on, rkp, rkeys, rvalid, rpred, true);
+  plan_keys(res, rcols, on_r, n_on, rkp, rpred, true);   // the probe side's keys are evaluated inside the probe kernel
   for (int k = 0; k < n_on; ++k)
     if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
       fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
                                       " == " + dtype_name(rkp.keys[(size_t)k].type));
   const int W = lkp.W;
+  if (rkp.W != W) fail(QHIP_HIP_ERROR, "join key layouts of the two sides differ (internal error)");
 
-  // ---- build: distinct-key table + CSR of build rows per key
+  // ---- build: distinct-key table (+ a one-bit-per-hash filter that stays in L2) and the build rows of every key
   const uint32_t nslots = std::max<uint32_t>(16, pow2_ceil32(B * 2));
-  DevBuf table((size_t)nslots * (1 + W) * 8), count((size_t)(nslots + 1) * 4), start((size_t)(nslots + 1) * 4), row_slot((B + 1) * 4);
-  DevBuf sorted_slot((B + 1) * 4), sorted_rows((B + 1) * 4), iota((B + 1) * 4);
-  QHIP_HIP_CHECK(hipMemsetAsync(table.ptr, 0, table.bytes, s));
-  QHIP_HIP_CHECK(hipMemsetAsync(count.ptr, 0, count.bytes, s));
-  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table.as<uint64_t>(), nslots, row_slot.as<uint32_t>(),
-                           count.as<uint32_t>(), ctx->status.as<uint32_t>(), s);
-  launch_iota_u32(iota.as<uint32_t>(), B, s);
-  stable_sort_pairs_u32(row_slot.as<uint32_t>(), sorted_slot.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), B,
-                        log2u(nslots) + 1, s);
-  exclusive_scan_u32(count.as<uint32_t>(), start.as<uint32_t>(), nslots, nullptr, s);
+  const uint32_t bloom_bits = std::max<uint32_t>(1024, nslots < (1u << 29) ? nslots * 4 : nslots);
+  // one zero-filled arena: [table | count | bloom]
+  const size_t table_bytes = (size_t)nslots * (1 + W) * 8, count_bytes = ((size_t)nslots + 2) * 4, bloom_bytes = (size_t)bloom_bits / 8;
+  DevBuf arena(table_bytes + count_bytes + bloom_bytes);
+  QHIP_HIP_CHECK(hipMemsetAsync(arena.ptr, 0, arena.bytes, s));
+  uint64_t* table = arena.as<uint64_t>();
+  uint32_t* count = (uint32_t*)(arena.as<uint8_t>() + table_bytes);
+  uint32_t* bloom = (uint32_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
+  DevBuf start, row_slot((B + 1) * 4), slot_row(((size_t)nslots + 1) * 4), sorted_rows;
+  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count,
+                           slot_row.as<uint32_t>(), bloom, bloom_bits - 1, ctx->status.as<uint32_t>(), s);
+  uint32_t max_count = 0;
   {
     uint32_t st[QS_WORDS];
     copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);   // key evaluation of both sides + build
     check_status_words(st);
     if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
+    max_count = st[QS_MAXCOUNT];
+  }
+  // Unique build keys (every FK -> PK join): slot_row[slot] already is the CSR. Otherwise group the build rows by slot
+  // with a stable radix sort (ascending build row inside a key: the order the reference's reverse-built chains yield).
+  const bool unique_keys = max_count <= 1 && env_int("QHIP_JOIN_FORCE_CSR", 0) == 0;
+  const uint32_t* start_ptr = nullptr;
+  const uint32_t* rows_ptr = slot_row.as<uint32_t>();
+  if (!unique_keys) {
+    DevBuf sorted_slot((B + 1) * 4), iota((B + 1) * 4);
+    sorted_rows.alloc((B + 1) * 4);
+    start.alloc(((size_t)nslots + 1) * 4);
+    launch_iota_u32(iota.as<uint32_t>(), B, s);
+    stable_sort_pairs_u32(row_slot.as<uint32_t>(), sorted_slot.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), B,
+                          log2u(nslots) + 1, s);
+    exclusive_scan_u32(count, start.as<uint32_t>(), nslots, nullptr, s);
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));   // sort temporaries go back to the pool
+    start_ptr = start.as<uint32_t>();
+    rows_ptr = sorted_rows.as<uint32_t>();
   }
 
-  // ---- probe pass 1 + 2
-  DevBuf slot_of((P + 1) * 4), cnt((P + 1) * 4), pair_off((P + 1) * 4), total(4);
+  const bool has_tail = join_type == QHIP_JOIN_LEFT || join_type == QHIP_JOIN_FULL || semi_anti;
+  const uint64_t vwords = ((B + 63) / 64) * 2 + 2;
+  DevBuf visited(vwords * 4);
+  if (has_tail) QHIP_HIP_CHECK(hipMemsetAsync(visited.ptr, 0, visited.bytes, s));
+  bool visited_done = false;
+
+  // ---- probe. Pass 1 (JIT: fused scan filter + key words + lookup straight from the probe table's columns) leaves one
+  // slot per probe row and one pair count per 256-row tile; the tile counts are scanned; pass 2 writes the pairs in
+  // probe-row order. LeftSemi / LeftAnti without a residual filter only need the visited bits: pass 1 sets them.
+  DevBuf slot_of((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
+  uint64_t M = 0;
   hipEventRecord(ctx->ev[2], s);
-  const uint64_t pwaves = (P + 63) / 64;
-  DevBuf wave_tot((pwaves + 1) * 4);
-  launch_join_probe_count(W, rkeys.as<uint64_t>(), rvalid.as<uint64_t>(), P, table.as<uint64_t>(), nslots, count.as<uint32_t>(),
-                          slot_of.as<uint32_t>(), cnt.as<uint32_t>(), wave_tot.as<uint32_t>(), s);
-  exclusive_scan_u32(wave_tot.as<uint32_t>(), wave_tot.as<uint32_t>(), pwaves, total.as<uint32_t>(), s);   // P/64 values only
-  uint64_t M = P ? read_u32(s, total.ptr) : 0;
-  DevBuf b_idx((M + 1) * 4), p_idx((M + 1) * 4);
-  launch_join_probe_write(slot_of.as<uint32_t>(), wave_tot.as<uint32_t>(), start.as<uint32_t>(), sorted_rows.as<uint32_t>(), cnt.as<uint32_t>(), P,
-                          pair_off.as<uint32_t>(), b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), s);
+  const bool want_pairs = !(semi_anti && froot < 0);
+  const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
+  if (P > 0) {
+    std::shared_ptr<Module> mod = get_module(ctx, rkp.source, rkp.kernel_name);
+    HKArgs ka;
+    DevBuf strlit;
+    fill_kargs(ctx, R, rkp.bind, ka, strlit);
+    const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
+    DevBuf tile_tot((ntiles + 1) * 4), total(4);
+    HProbeLaunch pl;
+    pl.table = table; pl.bloom = bloom; pl.count = count; pl.start = start_ptr; pl.rows = rows_ptr;
+    pl.slot_of = slot_of.as<uint32_t>();
+    pl.tile_total = tile_tot.as<uint32_t>();
+    pl.visited = (mark_in_probe && !want_pairs) ? visited.as<uint32_t>() : nullptr;
+    pl.status = ctx->status.as<uint32_t>();
+    pl.nslots = nslots; pl.bloom_mask = bloom_bits - 1;
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
+    void* args[] = {&ka, &pl};
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 8));
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    uint32_t st[QS_WORDS];
+    uint32_t m32 = 0;
+    if (want_pairs) {
+      exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, total.as<uint32_t>(), s);
+      QHIP_HIP_CHECK(hipMemcpyAsync(&m32, total.ptr, 4, hipMemcpyDeviceToHost, s));
+    }
+    QHIP_HIP_CHECK(hipMemcpyAsync(st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    check_status_words(st);
+    M = m32;
+    if (want_pairs) {
+      b_idx.alloc((M + 1) * 4);
+      p_idx.alloc((M + 1) * 4);
+      if (pad_right) { cnt.alloc((P + 1) * 4); pair_off.alloc((P + 1) * 4); }
+      launch_join_emit(slot_of.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+                       pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
+                       mark_in_probe ? visited.as<uint32_t>() : nullptr, s);
+      QHIP_HIP_CHECK(hipStreamSynchronize(s));   // tile_tot / total go back to the pool
+    }
+    visited_done = mark_in_probe;
+  }
   hipEventRecord(ctx->ev[3], s);
 
   // ---- residual JoinFilter (join/mod.rs:125-154): evaluate over an intermediate batch of the filter's columns, keep true rows
@@ -145,20 +212,19 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     filtered = true;
   }
 
-  // ---- visited bitmap; per-probe-row surviving counts when they changed or are needed
-  const uint64_t vwords = ((B + 63) / 64) * 2 + 2;
-  DevBuf visited(vwords * 4);
-  QHIP_HIP_CHECK(hipMemsetAsync(visited.ptr, 0, visited.bytes, s));
+  // ---- visited bitmap (when the probe kernel has not marked it already); per-probe-row surviving counts for the
+  // Right / Full padding when the residual filter changed them
   DevBuf cnt2;
-  if (filtered) {
+  if (filtered && pad_right) {
     cnt2.alloc((P + 1) * 4);
     QHIP_HIP_CHECK(hipMemsetAsync(cnt2.ptr, 0, cnt2.bytes, s));
   }
-  launch_join_mark(b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), M, visited.as<uint32_t>(), filtered ? cnt2.as<uint32_t>() : nullptr, s);
-  const uint32_t* final_cnt = filtered ? cnt2.as<uint32_t>() : cnt.as<uint32_t>();
+  if ((has_tail && !visited_done) || cnt2.ptr)
+    launch_join_mark(b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), M, visited.as<uint32_t>(), cnt2.ptr ? cnt2.as<uint32_t>() : nullptr, s);
+  const uint32_t* final_cnt = cnt2.ptr ? cnt2.as<uint32_t>() : cnt.as<uint32_t>();
   DevBuf off2;                                  // exclusive scan of final_cnt (position of a probe row's first pair)
   const uint32_t* final_off = pair_off.as<uint32_t>();
-  if (filtered) {
+  if (cnt2.ptr) {
     off2.alloc((P + 1) * 4);
     exclusive_scan_u32(final_cnt, off2.as<uint32_t>(), P, nullptr, s);
     final_off = off2.as<uint32_t>();
@@ -182,7 +248,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if (semi_anti) M = 0;   // hash_join.rs:260-262: nothing is emitted while probing
 
   // ---- tail: unmatched build rows (Left / Full / LeftAnti) or matched ones (LeftSemi), ascending build index
-  const bool has_tail = join_type == QHIP_JOIN_LEFT || join_type == QHIP_JOIN_FULL || semi_anti;
   uint64_t T = 0;
   DevBuf tail_sel;
   if (has_tail && B > 0) {
@@ -194,12 +259,17 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if (total_rows >= kNullIdx) fail(QHIP_UNSUPPORTED, "join output of 2^32 - 1 rows or more is not supported");
 
   // ---- index vectors of the whole output: [pairs | tail]
-  DevBuf b_all((total_rows + 1) * 4), p_all((total_rows + 1) * 4);
-  if (M) {
-    QHIP_HIP_CHECK(hipMemcpyAsync(b_all.ptr, b_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
-    QHIP_HIP_CHECK(hipMemcpyAsync(p_all.ptr, p_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
-  }
-  if (T) {
+  DevBuf b_all, p_all;
+  if (T == 0) {
+    b_all = std::move(b_idx);   // no tail rows: the pair vectors are the output index vectors
+    p_all = std::move(p_idx);
+  } else {
+    b_all.alloc((total_rows + 1) * 4);
+    p_all.alloc((total_rows + 1) * 4);
+    if (M) {
+      QHIP_HIP_CHECK(hipMemcpyAsync(b_all.ptr, b_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+      QHIP_HIP_CHECK(hipMemcpyAsync(p_all.ptr, p_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+    }
     QHIP_HIP_CHECK(hipMemcpyAsync(b_all.as<uint32_t>() + M, tail_sel.ptr, T * 4, hipMemcpyDeviceToDevice, s));
     launch_fill_u32(p_all.as<uint32_t>() + M, T, kNullIdx, s);
   }
@@ -231,7 +301,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     std::vector<uint64_t> rows(R->batch_offsets.begin(), R->batch_offsets.end());
     DevBuf drows(nb1 * 8), dpos(nb1 * 4);
     QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, s));
-    launch_lookup_u32(final_off, drows.as<uint64_t>(), (uint32_t)nb1, P, (uint32_t)M, dpos.as<uint32_t>(), s);
+    if (pad_right) launch_lookup_u32(final_off, drows.as<uint64_t>(), (uint32_t)nb1, P, (uint32_t)M, dpos.as<uint32_t>(), s);
+    else launch_lower_bound_u32(p_all.as<uint32_t>(), M, drows.as<uint64_t>(), (uint32_t)nb1, dpos.as<uint32_t>(), s);   // probe rows ascend
     std::vector<uint32_t> pos(nb1);
     QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, s));
     QHIP_HIP_CHECK(hipStreamSynchronize(s));

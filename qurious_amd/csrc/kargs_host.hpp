@@ -35,4 +35,19 @@ struct HAggLaunch {
 };
 static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
 
+struct HProbeLaunch {
+  const uint64_t* table;
+  const uint32_t* bloom;
+  const uint32_t* count;
+  const uint32_t* start;
+  const uint32_t* rows;
+  uint32_t* slot_of;
+  uint32_t* tile_total;
+  uint32_t* visited;
+  uint32_t* status;
+  uint32_t nslots, bloom_mask;
+};
+static_assert(sizeof(HProbeLaunch) == 9 * 8 + 8, "ProbeLaunch layout");
+constexpr int kProbeTileRows = 64 * 4;   // one wavefront's share: 64 * QH_PROBE_R consecutive probe rows
+
 }  // namespace qhip

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
     m = l > m ? l : m;
   }
   m = (u32)qh_wave_max_u64(m);
-  if (qh_lane() == 0 && m) atomicMax(out, m);
+  if (qh_lane() == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
 // ================================================================ hash join
@@ -221,85 +221,73 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
 // CSR layout (start/count per slot). NULL keys are never inserted and never probe (eq of NULL is NULL).
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys, const u64* keyvalid, u64 n, u64* table, u32 nslots,
-                                                               u32* row_slot, u32* count, u32* status) {
+                                                               u32* row_slot, u32* count, u32* slot_row, u32* bloom, u32 bloom_mask, u32* status) {
+  u32 maxc = 0;
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
     u32 sid = nslots;   // NULL key: sorts behind every real slot, never probed
     if ((keyvalid[i >> 6] >> (i & 63)) & 1) {
       u64 k[W];
-      u64 h = 0;
 #pragma unroll
-      for (int w = 0; w < W; ++w) { k[w] = keys[(size_t)w * n + i]; h = qh_mix64(h ^ k[w]); }
+      for (int w = 0; w < W; ++w) k[w] = keys[(size_t)w * n + i];
+      const u64 h = qh_key_hash<W>(k);
       bool inserted;
       u64* slot = qh_find_or_insert<MemHbm, W>(table, nslots, 1 + W, k, h, (int)nslots, &inserted);
       if (!slot) atomicOr(&status[QS_OVERFLOW], 1u);
       else {
         sid = (u32)((slot - table) / (1 + W));
-        atomicAdd(&count[sid], 1u);
+        const u32 old = atomicAdd(&count[sid], 1u);
+        maxc = old + 1 > maxc ? old + 1 : maxc;
+        slot_row[sid] = (u32)i;          // the row of a unique key (the only writer then); unused otherwise
+        if (inserted) { const u32 bit = (u32)(h >> 32) & bloom_mask; atomicOr(&bloom[bit >> 5], 1u << (bit & 31)); }
       }
     }
     row_slot[i] = sid;
   }
+  maxc = (u32)qh_wave_max_u64(maxc);
+  // thousands of waves would serialise on this one word: only those that raise the maximum touch it atomically
+  if (qh_lane() == 0 && maxc > __hip_atomic_load(&status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[QS_MAXCOUNT], maxc);
 }
 
-// read-only lookup after the build kernel has completed (plain cached loads)
-template <int W>
-__device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const u64* k) {
-  u64 h = 0;
-#pragma unroll
-  for (int w = 0; w < W; ++w) h = qh_mix64(h ^ k[w]);
-  u32 s = (u32)h & (nslots - 1);
-  for (u32 probes = 0; probes < nslots; ++probes) {
-    const u64* slot = table + (size_t)s * (1 + W);
-    if (slot[0] != QH_READY) return QH_NULL_IDX;
-    bool eq = true;
-#pragma unroll
-    for (int w = 0; w < W; ++w) eq &= slot[1 + w] == k[w];
-    if (eq) return s;
-    s = (s + 1) & (nslots - 1);
-  }
-  return QH_NULL_IDX;
-}
-
-// probe pass 1 (get_matches_indices + key equality, hash_join.rs:70-107,177-216): matches per probe row. One wavefront
-// owns 64 consecutive probe rows and also emits their total, so that only the per-wave totals (P/64 values) need a
-// device-wide scan; the position of a row's first pair inside its wavefront comes from a wave-level scan in pass 2.
-template <int W>
-__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_count(const u64* pkeys, const u64* pvalid, u64 np, const u64* table, u32 nslots,
-                                                              const u32* count, u32* out_slot, u32* out_cnt, u32* wave_total) {
-  const u64 nwords = (np + 63) / 64;
-  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
-  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+// probe pass 2 (get_matches_indices + probe_hash_table's index vectors, hash_join.rs:70-107,177-216): turn the slot
+// per probe row that pass 1 (qk_join_probe, device/qhip_device.hpp) left behind into (build row, probe row) pairs —
+// probe-row major, build rows ascending (hash_join.rs:475-512 pins that order). A wavefront owns the same 64 * R
+// consecutive probe rows as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts.
+__global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* slot_of, const u32* tile_off, const u32* count, const u32* start,
+                                                       const u32* rows, u64 np, u32* b_idx, u32* p_idx, u32* pair_off, u32* cnt_out,
+                                                       u32* visited) {
+  constexpr int R = QH_PROBE_R, TILE = 64 * R;
   const int lane = qh_lane();
-  for (u64 j = wave_global; j < nwords; j += nwaves) {
-    const u64 p = j * 64 + lane;
-    u32 sid = QH_NULL_IDX, c = 0;
-    if (p < np && ((pvalid[j] >> lane) & 1)) {
-      u64 k[W];
+  const u64 ntiles = (np + TILE - 1) / TILE;
+  for (u64 tile = (u64)blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6); tile < ntiles; tile += (u64)gridDim.x * (QH_BLOCK / 64)) {
+    u32 sid[R], c[R];
 #pragma unroll
-      for (int w = 0; w < W; ++w) k[w] = pkeys[(size_t)w * np + p];
-      sid = qh_join_find<W>(table, nslots, k);
-      if (sid != QH_NULL_IDX) c = count[sid];
+    for (int r = 0; r < R; ++r) {
+      const u64 i = tile * TILE + r * 64 + lane;
+      sid[r] = i < np ? slot_of[i] : QH_NULL_IDX;
     }
-    if (p < np) { out_slot[p] = sid; out_cnt[p] = c; }
-    const u32 tot = (u32)qh_wave_sum_u64(c);
-    if (lane == 0) wave_total[j] = tot;
-  }
-}
-// probe pass 2: emit (build row, probe row) pairs — probe-row major, build rows ascending (hash_join.rs:475-512 pins it)
-__global__ __launch_bounds__(QH_BLOCK) void k_join_probe_write(const u32* slot_of, const u32* wave_off, const u32* start, const u32* sorted_rows,
-                                                              const u32* cnt, u64 np, u32* pair_off, u32* b_idx, u32* p_idx) {
-  const u64 nwords = (np + 63) / 64;
-  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
-  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
-  const int lane = qh_lane();
-  for (u64 j = wave_global; j < nwords; j += nwaves) {
-    const u64 p = j * 64 + lane;
-    const u32 c = p < np ? cnt[p] : 0u;
-    const u32 o = wave_off[j] + wave_incl_scan_u32(c) - c;
-    if (p < np) pair_off[p] = o;
-    if (c) {
-      const u32 s0 = start[slot_of[p]];
-      for (u32 k = 0; k < c; ++k) { b_idx[o + k] = sorted_rows[s0 + k]; p_idx[o + k] = (u32)p; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool found = sid[r] != QH_NULL_IDX;
+      c[r] = start ? count[found ? sid[r] : 0u] : 1u;
+      c[r] = found ? c[r] : 0u;
+    }
+    u32 base = tile_off[tile];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u64 i = tile * TILE + r * 64 + lane;
+      const u32 incl = wave_incl_scan_u32(c[r]);
+      const u32 o = base + incl - c[r];
+      base += qh_readlane32(incl, 63);
+      if (pair_off && i < np) { pair_off[i] = o; cnt_out[i] = c[r]; }
+      if (c[r]) {
+        const u32 s0 = start ? start[sid[r]] : sid[r];
+        for (u32 q = 0; q < c[r]; ++q) {
+          const u32 b = rows[s0 + q];
+          b_idx[o + q] = b;
+          p_idx[o + q] = (u32)i;
+          if (visited) atomicOr(&visited[b >> 5], 1u << (b & 31));
+        }
+      }
     }
   }
 }
@@ -323,6 +311,16 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_adjust_right(const u32* b_in,
     const u32 i0 = in_off[p];
     for (u32 k = 0; k < c; ++k) { b_out[o + k] = b_in[i0 + k]; p_out[o + k] = (u32)p; }
   }
+}
+// first position in the ascending array `a` (m values) whose value is >= bound[k] — output-batch boundaries of a join
+// from the probe rows of its pairs (hash_join.rs:363-372: one output batch per probe batch)
+__global__ __launch_bounds__(QH_BLOCK) void k_lower_bound_u32(const u32* a, u64 m, const u64* bound, u32 nb, u32* pos) {
+  const u32 k = blockIdx.x * QH_BLOCK + threadIdx.x;
+  if (k >= nb) return;
+  const u64 v = bound[k];
+  u64 lo = 0, hi = m;
+  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if ((u64)a[mid] < v) lo = mid + 1; else hi = mid; }
+  pos[k] = (u32)lo;
 }
 __global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n) {
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (u32)i;
@@ -506,22 +504,21 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
   }
 
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
-                              uint32_t* row_slot, uint32_t* count, uint32_t* status, hipStream_t s) {
+                              uint32_t* row_slot, uint32_t* count, uint32_t* slot_row, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status,
+                              hipStream_t s) {
   if (!n) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_build_insert<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (const u64*)keyvalid, (u64)n,
-                                   (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)status));
+                                   (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)slot_row, (u32*)bloom, bloom_mask, (u32*)status));
 }
-void launch_join_probe_count(int W, const uint64_t* pkeys, const uint64_t* pvalid, uint64_t np, const uint64_t* table, uint32_t nslots,
-                             const uint32_t* count, uint32_t* out_slot, uint32_t* out_cnt, uint32_t* wave_total, hipStream_t s) {
-  if (!np) return;
-  DISPATCH_W(W, hipLaunchKernelGGL(k_join_probe_count<KW>, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u64*)pkeys, (const u64*)pvalid, (u64)np,
-                                   (const u64*)table, nslots, (const u32*)count, (u32*)out_slot, (u32*)out_cnt, (u32*)wave_total));
+void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
+  if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u64*)bound, nb, (u32*)pos);
 }
-void launch_join_probe_write(const uint32_t* slot_of, const uint32_t* wave_off, const uint32_t* start, const uint32_t* sorted_rows,
-                             const uint32_t* cnt, uint64_t np, uint32_t* pair_off, uint32_t* b_idx, uint32_t* p_idx, hipStream_t s) {
+void launch_join_emit(const uint32_t* slot_of, const uint32_t* tile_off, const uint32_t* count, const uint32_t* start, const uint32_t* rows,
+                      uint64_t np, uint32_t* b_idx, uint32_t* p_idx, uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, hipStream_t s) {
   if (!np) return;
-  hipLaunchKernelGGL(k_join_probe_write, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)wave_off, (const u32*)start,
-                     (const u32*)sorted_rows, (const u32*)cnt, (u64)np, (u32*)pair_off, (u32*)b_idx, (u32*)p_idx);
+  hipLaunchKernelGGL(k_join_emit, dim3(grid_for(np, QH_BLOCK * QH_PROBE_R)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)tile_off,
+                     (const u32*)count, (const u32*)start, (const u32*)rows, (u64)np, (u32*)b_idx, (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out,
+                     (u32*)visited);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;

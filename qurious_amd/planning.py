@@ -78,6 +78,20 @@ def keys_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], has_nulls: Opti
     return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)))
 
 
+def probe_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: Optional[PhysicalExpr] = None,
+                 has_nulls: Optional[Sequence[bool]] = None) -> str:
+    """Source of the fused probe kernel HashJoinExec launches for its probe (right) side."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_probe_source
+    fn.restype = C.c_int
+    types, hn, n = _cols(schema, has_nulls)
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    proot = ea.lower(predicate) if predicate is not None else -1
+    arr, ne = ea.c_array()
+    return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot))
+
+
 def compile_to_cache(policy_source: str, cache_dir: str = KERNEL_CACHE_DIR) -> str:
     """hiprtc-compile (device templates + policy) for gfx950 into the kernel cache; returns the compiler log."""
     lib = _ffi.load_library()

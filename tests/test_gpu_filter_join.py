@@ -157,6 +157,46 @@ def test_hash_join_all_types_random_vs_oracle(ctx, oracle, jt):
     _batches_equal(plan.execute(), oracle.execute(plan))
 
 
+@pytest.mark.parametrize("force_csr", [False, True])
+@pytest.mark.parametrize("unique_build", [True, False])
+def test_hash_join_probe_many_tiles(ctx, oracle, monkeypatch, force_csr, unique_build):
+    """2.5 M probe rows (~10^4 probe tiles) with a fused scan filter, over unique build keys (slot -> row, also forced
+    through the CSR path) and duplicated ones (CSR from the stable sort): the reference's pair order in every case."""
+    if force_csr:
+        monkeypatch.setenv("QHIP_JOIN_FORCE_CSR", "1")
+    rng = np.random.default_rng(77)
+    nb, npr = 60_000, 2_500_000
+    bkeys = rng.permutation(nb * 4)[:nb] if unique_build else rng.integers(0, nb // 3, nb)
+    ls = pa.schema([pa.field("b_key", I64), pa.field("b_pay", pa.int32())])
+    rs = pa.schema([pa.field("p_key", I64), pa.field("p_pay", pa.int32()), pa.field("p_date", pa.date32())])
+    lb = pa.RecordBatch.from_arrays([pa.array(bkeys, type=I64), pa.array(np.arange(nb), type=pa.int32())], schema=ls)
+    pk = pa.array(rng.integers(0, nb * 4, npr), type=I64, mask=rng.random(npr) < 0.01)
+    rb = pa.RecordBatch.from_arrays([pk, pa.array(np.arange(npr), type=pa.int32()),
+                                     pa.array(rng.integers(9000, 9400, npr), type=pa.int32()).cast(pa.date32())], schema=rs)
+    left = table_scan(ls, [lb])
+    cuts = list(range(0, npr, 400_000)) + [npr]
+    batches = [rb.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    pred = q.BinaryExpr(col("p_date", 2), Operator.Gt, q.Literal(S.Date32(9100)))
+    on = [(col("b_key", 0), col("p_key", 0))]
+    plan = q.HashJoinExec.try_new(left, table_scan(rs, batches, pred), JoinType.Inner, on, None)
+    _batches_equal(plan.execute(), oracle.execute(plan))
+    for jt in (JoinType.Left, JoinType.Right, JoinType.LeftSemi, JoinType.LeftAnti, JoinType.Full):
+        plan = q.HashJoinExec.try_new(left, table_scan(rs, batches[:2]), jt, on, None)
+        _batches_equal(plan.execute(), oracle.execute(plan))
+
+
+def test_hash_join_many_pairs_per_probe_row(ctx, oracle):
+    """heavily duplicated keys on both sides: ~100 build rows per probe row"""
+    rng = np.random.default_rng(78)
+    (ls, lb), (rs, rb) = _random_sides(rng, 4000, 3000, 40, null_p=0.02)
+    on = [(col("l_k1", 0), col("r_k1", 0))]
+    for jt in (JoinType.Inner, JoinType.Left):
+        plan = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb.slice(0, 1000), rb.slice(1000, 2000)]), jt, on, None)
+        got = plan.execute()
+        assert sum(b.num_rows for b in got) > 3000 * 10
+        _batches_equal(got, oracle.execute(plan))
+
+
 def test_hash_join_edge_cases(ctx, oracle):
     (ls, lb), (rs, rb) = _random_sides(np.random.default_rng(5), 50, 80, 10)
     empty_l = table_scan(ls, [lb.slice(0, 0)])
