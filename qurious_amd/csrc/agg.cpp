@@ -257,7 +257,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       // speculative compaction right behind the kernel: [counter | dense slots]; the common case (few groups, no
       // overflow) then needs a single synchronisation for status + result
       const uint32_t total_slots = cap * replicas;
-      guess = std::min<uint32_t>(total_slots, 8192);
+      // (a plan that produced many groups last time gets a buffer that should hold them all at once)
+      guess = std::min<uint32_t>(total_slots, std::max<uint32_t>(8192, plan.last_groups + plan.last_groups / 4));
       dense.alloc((size_t)guess * slot_bytes + 8);
       QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
       launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);

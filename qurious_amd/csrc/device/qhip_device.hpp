@@ -90,9 +90,6 @@ template <int N> __device__ __forceinline__ void qh_pack_words(const u64* raw, i
   }
   out[N - 1] |= (u64)l << 56;
 }
-__device__ __forceinline__ void qh_report(u32* status, u32 err) {
-  if (err) for (int b = 0; b < QS_WORDS; ++b) if ((err >> b) & 1u) atomicOr(&status[b], 1u);
-}
 // bytewise compare like arrow's Utf8 ordering: <0, 0, >0
 __device__ __forceinline__ int qh_strcmp(const u8* a, int la, const u8* b, int lb) {
   int n = la < lb ? la : lb;
@@ -125,6 +122,15 @@ __device__ __forceinline__ i128 qh_pow10(int e) { i128 r = 1; for (int k = 0; k 
 // ------------------------------------------------------------------ wavefront primitives (wave64)
 __device__ __forceinline__ u64 qh_ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ u32 qh_readlane32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// Raise the status flags in `err` (bit b -> status word b). One atomic per wavefront and flag, and none when the flag is
+// already up: thousands of waves OR-ing the same word serialise (measured ~10 ns per atomic on one address).
+__device__ __forceinline__ void qh_report(u32* status, u32 err) {
+  if (!__builtin_amdgcn_readfirstlane((int)(qh_ballot(err != 0) != 0))) return;
+  for (int b = 0; b < QS_WORDS; ++b) {
+    const u64 m = qh_ballot((err >> b) & 1u);
+    if (m && qh_lane() == __builtin_ctzll(m) && !__hip_atomic_load(&status[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&status[b], 1u);
+  }
+}
 __device__ __forceinline__ u64 qh_readlane64(u64 v, int lane) {
   return ((u64)qh_readlane32((u32)(v >> 32), lane) << 32) | qh_readlane32((u32)v, lane);
 }
@@ -341,13 +347,13 @@ __device__ __forceinline__ void qh_apply(u64* table, u32 nslots, int max_probe, 
 }
 
 template <class P>
-__device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L, const u64* key, const typename P::Part& part) {
+__device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L, const u64* key, const typename P::Part& part, u32& err) {
   u64* slot = nullptr;
   if (L.l_nslots) qh_apply<P, MemLds>(ltable, L.l_nslots, QH_LDS_MAX_PROBE, key, part, slot);
   if (!slot) {
     qh_apply<P, MemHbm>(L.gtable, L.g_nslots, QH_HBM_MAX_PROBE, key, part, slot);
-    if (!slot) atomicOr(&L.status[QS_OVERFLOW], 1u);
-    else if (L.l_nslots) atomicOr(&L.status[QS_LDS_SPILL], 1u);
+    if (!slot) atomicOr(&L.status[QS_OVERFLOW], 1u);            // prompt: the other workgroups stop streaming on it
+    else if (L.l_nslots) err |= 1u << QS_LDS_SPILL;             // informational: reported once, at the end of the kernel
   }
 }
 
@@ -489,22 +495,22 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
         typename P::Part part;
         P::part_init(part);
         P::template part_add<true>(part, row[r], true);
-        qh_update_group<P>(ltable, L, row[r].key, part);
+        qh_update_group<P>(ltable, L, row[r].key, part, err);
       }
     }
     if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
   }
 
-  qh_report(L.status, err);
   // hand the cached groups of this wave to the workgroup's table: one reduction + one update per (wave, key) per KERNEL
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     if (k < nc) {
       P::template part_reduce<false>(cacc[k]);
       P::part_set_rows(cacc[k], crows[k]);
-      if (lane == 0) qh_update_group<P>(ltable, L, ck[k], cacc[k]);
+      if (lane == 0) qh_update_group<P>(ltable, L, ck[k], cacc[k], err);
     }
   }
+  qh_report(L.status, err);
   if (W == 0) {
     P::template part_reduce<true>(acc);
     if (lane == 0) P::template slot_update<MemHbm>(L.gtable, acc);

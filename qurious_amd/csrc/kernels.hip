@@ -1,6 +1,8 @@
 // kernels.hip — plan-independent gfx950 kernels compiled ahead of time with hipcc into libqhip.so.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device/qhip_status.h"
 #include "device/qhip_device.hpp"
 #include "kernels.hpp"
@@ -18,17 +20,36 @@ __global__ __launch_bounds__(QH_BLOCK) void k_count_ready(const u64* table, u32 
   if (qh_lane() == 0 && total) atomicAdd(counter, (u32)total);
 }
 
+// Every wavefront owns a contiguous range of slots: it counts the ready ones (state words only), reserves its share of
+// the output with ONE atomic, then copies. (Atomics on one address cost ~10 ns each across the 8 XCDs: one per group
+// or even one per 64 slots would dominate the kernel.)
 __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u32 nslots, int slot_words, u64* out, u32* counter,
                                                             u32 out_capacity) {
-  for (u32 s = blockIdx.x * QH_BLOCK + threadIdx.x; s < nslots; s += gridDim.x * QH_BLOCK) {
+  const int lane = qh_lane();
+  const u32 nwaves = gridDim.x * (QH_BLOCK / 64), wave = blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6);
+  const u32 per_wave = ((nslots + nwaves - 1) / nwaves + 63) / 64 * 64;
+  const u64 lo = (u64)wave * per_wave, hi = lo + per_wave < (u64)nslots ? lo + per_wave : (u64)nslots;
+  if (lo >= hi) return;
+  u32 mine = 0;
+  for (u64 s = lo + lane; s < hi; s += 64) mine += table[(size_t)s * slot_words] == QH_READY ? 1u : 0u;
+  const u32 total = (u32)qh_wave_sum_u64(mine);
+  if (!total) return;
+  u32 base = 0;
+  if (lane == 0) base = atomicAdd(counter, total);
+  base = qh_readlane32(base, 0);
+  for (u64 s0 = lo; s0 < hi; s0 += 64) {
+    const u64 s = s0 + lane;
     const u64* slot = table + (size_t)s * slot_words;
-    if (slot[0] == QH_READY) {
-      const u32 idx = atomicAdd(counter, 1u);
+    const bool ready = s < hi && slot[0] == QH_READY;
+    const u64 m = qh_ballot(ready);
+    if (ready) {
+      const u32 idx = base + (u32)__popcll(m & ((1ULL << lane) - 1));
       if (idx < out_capacity) {
         u64* o = out + (size_t)idx * slot_words;
         for (int k = 0; k < slot_words; ++k) o[k] = slot[k];
       }
     }
+    base += (u32)__popcll(m);
   }
 }
 
@@ -44,8 +65,10 @@ void launch_count_ready(const uint64_t* table, uint32_t nslots, int slot_words, 
 }
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
                           uint32_t out_capacity, hipStream_t s) {
-  hipLaunchKernelGGL(k_compact_slots, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, slot_words, (u64*)out,
-                     counter, out_capacity);
+  // few, long-lived wavefronts: 64 .. 2048 of them, each with >= 256 slots
+  const unsigned blocks = (unsigned)std::max<uint64_t>(16, std::min<uint64_t>(512, ((uint64_t)nslots + 1023) / 1024));
+  hipLaunchKernelGGL(k_compact_slots, dim3(blocks), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, slot_words, (u64*)out, counter,
+                     out_capacity);
 }
 
 }  // namespace qhip

@@ -334,16 +334,24 @@ __global__ void k_lookup_u32(const u32* off, const u64* rows, u32 n, u64 nrows, 
   if (k < n) out[k] = rows[k] >= nrows ? total : off[rows[k]];
 }
 // partition id per row from its key words (exchange): mix64 of the key, top bits -> [0, nparts)
+#define QH_MAX_PARTS 1024
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64 n, u32 nparts, u32* part, u32* hist) {
+  // histogram in LDS, one global atomic per workgroup and part (the parts are few: per-row atomics would all land on
+  // the same handful of words)
+  __shared__ u32 lh[QH_MAX_PARTS];
+  for (u32 p = threadIdx.x; p < nparts; p += QH_BLOCK) lh[p] = 0;
+  __syncthreads();
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
     u64 h = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) h = qh_mix64(h ^ keys[(size_t)w * n + i]);
     const u32 pid = (u32)(((h >> 32) * (u64)nparts) >> 32);
     part[i] = pid;
-    atomicAdd(&hist[pid], 1u);
+    atomicAdd(&lh[pid], 1u);
   }
+  __syncthreads();
+  for (u32 p = threadIdx.x; p < nparts; p += QH_BLOCK) if (lh[p]) atomicAdd(&hist[p], lh[p]);
 }
 
 // ================================================================ aggregate output assembly on the device
@@ -535,7 +543,7 @@ void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const u
 }
 void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s) {
   if (!n) return;
-  DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
+  DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n, QH_BLOCK * 16, 1024)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
 }
 
 void launch_agg_finalize(const uint64_t* dense, uint32_t G, int slot_words, int null_mask_word, const FinCol* cols_dev, int ncols,
