@@ -82,14 +82,18 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
 // ---------------------------------------------------------------- helpers shared with other operators
 std::vector<InputCol> input_cols_of(const qhip_table* t) {
   std::vector<InputCol> v;
-  for (auto& c : t->cols) { InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; ic.utf8_max_len = c.utf8_max_len; v.push_back(ic); }
+  for (auto& c0 : t->cols) {
+    // a deferred column that nobody resolved is not referenced by the plan being typed: its may-have-nulls flag is enough
+    const DevColumn& c = (c0.deferred && c0.deferred->done) ? c0.deferred->result : c0;
+    InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; ic.utf8_max_len = c.utf8_max_len; v.push_back(ic);
+  }
   return v;
 }
 
 void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& a, DevBuf& strlit_dev) {
   memset(&a, 0, sizeof(a));
   for (size_t s = 0; s < b.cols.size(); ++s) {
-    const DevColumn& c = t->cols[(size_t)b.cols[s]];
+    const DevColumn& c = resolved(ctx, t->cols[(size_t)b.cols[s]]);
     a.c[s].v = c.values ? c.values->ptr : nullptr;
     a.c[s].n = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
     a.c[s].d = c.data ? (const uint8_t*)c.data->ptr : nullptr;
@@ -138,7 +142,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (group_roots[k] < 0 || group_roots[k] >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "group expression index out of range");
   if (pred_root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "predicate index out of range");
   memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats_timing_pending = 0;
 
+  resolve_referenced(ctx, in, exprs, n_exprs);
   std::vector<InputCol> icols = input_cols_of(in);
   ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
   // lowered plans are cached per context: a repeated query (same expression PODs over the same column signature) skips

@@ -93,7 +93,20 @@ struct DevColumn {
   std::shared_ptr<DevBuf> data;      // utf8 bytes
   int64_t data_bytes = 0;
   mutable int32_t utf8_max_len = -1;   // cached longest value (bytes), computed on first use as a key column
+  // A join / filter output column may be DEFERRED: (source column, row index vector), gathered only when somebody reads
+  // it (an expression that references it, an export, an exchange). The reference gathers every column of every join
+  // output (utils/batch.rs:18-61) although most are never looked at downstream (Q3: c_mktsegment, o_custkey, ...).
+  // While deferred, values / validity / data are empty and null_count is a may-have-nulls flag (0 / 1).
+  std::shared_ptr<struct DeferredGather> deferred;
   int64_t resident_bytes() const;
+};
+struct DeferredGather {
+  DevColumn src;                  // never itself deferred (index vectors are composed instead)
+  std::shared_ptr<DevBuf> idx;    // u32 row numbers into src; kNullIdx -> NULL when idx_may_be_null
+  uint64_t m = 0;
+  bool idx_may_be_null = false;
+  bool done = false;
+  DevColumn result;
 };
 
 }  // namespace qhip
@@ -122,6 +135,7 @@ struct Ctx {
   std::string device_name;
   int num_cus = 256;
   qhip_exec_stats stats;
+  mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 — read when the stats are asked for
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
   void* pinned = nullptr;            // small page-locked scratch for status / result read-backs (truly asynchronous D2H)

@@ -257,6 +257,15 @@ int qhip_ctx_synchronize(qhip_ctx* ctx) {
 
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
   if (!ctx || !out) return QHIP_INVALID_ARGUMENT;
+  if (ctx->stats_timing_pending) {
+    // operators do not wait for their last kernels just to time them: the events are read here
+    qhip_ctx* c = const_cast<qhip_ctx*>(ctx);
+    float ms = 0;
+    if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.total_device_ms = ms;
+    if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.main_kernel_ms = ms;
+    else if (c->stats_timing_pending == 1) c->stats.main_kernel_ms = c->stats.total_device_ms;
+    c->stats_timing_pending = 0;
+  }
   *out = ctx->stats;
   return QHIP_OK;
 }

@@ -24,6 +24,7 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
   hipStream_t s = ctx->stream;
   const uint64_t N = (uint64_t)in->num_rows;
+  resolve_all(ctx, in);   // every column travels
   std::vector<InputCol> icols = input_cols_of(in);
   // partition ids must agree across ranks and across the two join sides: Utf8 keys always hash as 4 words (<= 31 bytes)
   for (int k = 0; k < n_keys; ++k)
@@ -69,6 +70,7 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
   out->nullable = first->nullable;
   out->batch_offsets.push_back(0);
   int64_t N = 0;
+  for (int k = 0; k < n; ++k) resolve_all(ctx, ts[k]);
   for (int k = 0; k < n; ++k) {
     if (ts[k]->cols.size() != first->cols.size()) fail(QHIP_INVALID_ARGUMENT, "qhip_table_concat: schemas differ");
     for (int64_t b = 0; b < ts[k]->num_batches(); ++b) out->batch_offsets.push_back(N + ts[k]->batch_offsets[(size_t)b + 1]);
@@ -204,6 +206,11 @@ int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n,
 
 int qhip_table_column_buffer(const qhip_table* t, int64_t col, int32_t which, void** device_ptr, int64_t* n_bytes) {
   if (!t || col < 0 || col >= (int64_t)t->cols.size() || !device_ptr || !n_bytes) return QHIP_INVALID_ARGUMENT;
+  if (t->cols[(size_t)col].deferred) {
+    if (!t->ctx) return QHIP_INVALID_ARGUMENT;
+    const int rc = guarded(static_cast<qhip_ctx*>(t->ctx), [&] { QHIP_HIP_CHECK(hipSetDevice(t->ctx->device)); (void)resolved(t->ctx, t->cols[(size_t)col]); });
+    if (rc != QHIP_OK) return rc;
+  }
   const DevColumn& c = t->cols[(size_t)col];
   const std::shared_ptr<DevBuf>& b = which == 0 ? c.values : which == 1 ? c.validity : c.data;
   *device_ptr = b ? b->ptr : nullptr;

@@ -15,6 +15,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
                                   int n_projection) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats_timing_pending = 0;
   std::vector<int> cols;
   if (projection && n_projection >= 0) {
     for (int k = 0; k < n_projection; ++k) {
@@ -36,6 +37,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
   }
   if (root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "predicate index out of range");
   if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+  resolve_referenced(ctx, in, exprs, n_exprs);
   std::vector<InputCol> icols = input_cols_of(in);
   ExprSet es;
   es.build(exprs, n_exprs, icols);
@@ -61,11 +63,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
     QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     out->batch_offsets.assign(pos.begin(), pos.end());
   }
-  float ms = 0;
-  hipEventSynchronize(ctx->ev[1]);
-  hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-  ctx->stats.total_device_ms = ms;
-  ctx->stats.main_kernel_ms = ms;
+  ctx->stats_timing_pending = 1;   // ev0..ev1, read by qhip_ctx_last_stats
   ctx->stats.rows_in = in->num_rows;
   ctx->stats.rows_out = m;
   snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_pred_mask+gather");

@@ -45,6 +45,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
                       const int32_t* fsides, const int32_t* fcols, int nfcols, int lpred, int rpred) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats_timing_pending = 0;
   if (n_on <= 0) fail(QHIP_INVALID_ARGUMENT, "Internal error: On constraints in HashJoinExec should be non-empty");
   if (join_type < QHIP_JOIN_LEFT || join_type > QHIP_JOIN_LEFT_ANTI) fail(QHIP_INVALID_ARGUMENT, "unknown join type");
   if (L->num_rows >= (int64_t)kNullIdx - 1 || R->num_rows >= (int64_t)kNullIdx - 1)
@@ -54,7 +55,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool semi_anti = join_type == QHIP_JOIN_LEFT_SEMI || join_type == QHIP_JOIN_LEFT_ANTI;
   const bool pad_right = join_type == QHIP_JOIN_RIGHT || join_type == QHIP_JOIN_FULL;
 
-  // ---- key words of both sides
+  // ---- key words of both sides (only the columns the key / scan-filter expressions read are gathered if deferred)
+  resolve_referenced(ctx, L, lex, nlex);
+  resolve_referenced(ctx, R, rex, nrex);
   std::vector<InputCol> lcols = input_cols_of(L), rcols = input_cols_of(R);
   ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
   ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
@@ -122,7 +125,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     stable_sort_pairs_u32(row_slot.as<uint32_t>(), sorted_slot.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), B,
                           log2u(nslots) + 1, s);
     exclusive_scan_u32(count, start.as<uint32_t>(), nslots, nullptr, s);
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));   // sort temporaries go back to the pool
+    // (the sort temporaries go back to the pool here; whoever gets them next runs on the same stream, i.e. afterwards)
     start_ptr = start.as<uint32_t>();
     rows_ptr = sorted_rows.as<uint32_t>();
   }
@@ -176,7 +179,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       launch_join_emit(slot_of.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
                        mark_in_probe ? visited.as<uint32_t>() : nullptr, s);
-      QHIP_HIP_CHECK(hipStreamSynchronize(s));   // tile_tot / total go back to the pool
     }
     visited_done = mark_in_probe;
   }
@@ -259,38 +261,38 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if (total_rows >= kNullIdx) fail(QHIP_UNSUPPORTED, "join output of 2^32 - 1 rows or more is not supported");
 
   // ---- index vectors of the whole output: [pairs | tail]
-  DevBuf b_all, p_all;
+  auto b_all = std::make_shared<DevBuf>(), p_all = std::make_shared<DevBuf>();
   if (T == 0) {
-    b_all = std::move(b_idx);   // no tail rows: the pair vectors are the output index vectors
-    p_all = std::move(p_idx);
+    *b_all = std::move(b_idx);   // no tail rows: the pair vectors are the output index vectors
+    *p_all = std::move(p_idx);
   } else {
-    b_all.alloc((total_rows + 1) * 4);
-    p_all.alloc((total_rows + 1) * 4);
+    b_all->alloc((total_rows + 1) * 4);
+    p_all->alloc((total_rows + 1) * 4);
     if (M) {
-      QHIP_HIP_CHECK(hipMemcpyAsync(b_all.ptr, b_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
-      QHIP_HIP_CHECK(hipMemcpyAsync(p_all.ptr, p_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+      QHIP_HIP_CHECK(hipMemcpyAsync(b_all->ptr, b_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
+      QHIP_HIP_CHECK(hipMemcpyAsync(p_all->ptr, p_idx.ptr, M * 4, hipMemcpyDeviceToDevice, s));
     }
-    QHIP_HIP_CHECK(hipMemcpyAsync(b_all.as<uint32_t>() + M, tail_sel.ptr, T * 4, hipMemcpyDeviceToDevice, s));
-    launch_fill_u32(p_all.as<uint32_t>() + M, T, kNullIdx, s);
+    QHIP_HIP_CHECK(hipMemcpyAsync(b_all->as<uint32_t>() + M, tail_sel.ptr, T * 4, hipMemcpyDeviceToDevice, s));
+    launch_fill_u32(p_all->as<uint32_t>() + M, T, kNullIdx, s);
   }
 
-  // ---- gather output columns (build_batch_from_indices, utils/batch.rs:18-61)
+  // ---- output columns (build_batch_from_indices, utils/batch.rs:18-61): the reference gathers every column of both
+  // sides; here the gathers are deferred until a column is read (a parent join / aggregate touches only a few)
   std::unique_ptr<qhip_table> out(new qhip_table());
   out->ctx = ctx;
   const bool left_nullable = pad_right;
   const bool right_nullable = has_tail;
-  for (size_t c = 0; c < L->cols.size(); ++c) {
-    out->cols.push_back(gather_column(ctx, L->cols[c], b_all.as<uint32_t>(), total_rows, left_nullable));
-    out->names.push_back(L->names[c]);
-    out->nullable.push_back(L->nullable[c] || left_nullable);
-  }
-  if (!semi_anti) {
-    for (size_t c = 0; c < R->cols.size(); ++c) {
-      out->cols.push_back(gather_column(ctx, R->cols[c], p_all.as<uint32_t>(), total_rows, right_nullable));
-      out->names.push_back(R->names[c]);
-      out->nullable.push_back(R->nullable[c] || right_nullable);
+  const bool eager = env_int("QHIP_EAGER_GATHER", 0) != 0;
+  auto add_side = [&](const qhip_table* src, const std::shared_ptr<DevBuf>& idx, bool side_nullable) {
+    if (eager) for (auto& c : src->cols) out->cols.push_back(gather_column(ctx, c, idx->as<uint32_t>(), total_rows, side_nullable));
+    else defer_gather(ctx, src->cols, idx, total_rows, side_nullable, out->cols);
+    for (size_t c = 0; c < src->cols.size(); ++c) {
+      out->names.push_back(src->names[c]);
+      out->nullable.push_back(src->nullable[c] || side_nullable);
     }
-  }
+  };
+  add_side(L, b_all, left_nullable);
+  if (!semi_anti) add_side(R, p_all, right_nullable);
   out->num_rows = (int64_t)total_rows;
 
   // ---- output batches: one per non-empty probe batch (hash_join.rs:363-372), then the tail batch
@@ -302,7 +304,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     DevBuf drows(nb1 * 8), dpos(nb1 * 4);
     QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, s));
     if (pad_right) launch_lookup_u32(final_off, drows.as<uint64_t>(), (uint32_t)nb1, P, (uint32_t)M, dpos.as<uint32_t>(), s);
-    else launch_lower_bound_u32(p_all.as<uint32_t>(), M, drows.as<uint64_t>(), (uint32_t)nb1, dpos.as<uint32_t>(), s);   // probe rows ascend
+    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, drows.as<uint64_t>(), (uint32_t)nb1, dpos.as<uint32_t>(), s);   // probe rows ascend
     std::vector<uint32_t> pos(nb1);
     QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, s));
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
@@ -311,12 +313,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   }
   if (has_tail) out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
   hipEventRecord(ctx->ev[1], s);
-  hipEventSynchronize(ctx->ev[1]);
-  float all_ms = 0, probe_ms = 0;
-  hipEventElapsedTime(&all_ms, ctx->ev[0], ctx->ev[1]);
-  hipEventElapsedTime(&probe_ms, ctx->ev[2], ctx->ev[3]);
-  ctx->stats.total_device_ms = all_ms;
-  ctx->stats.main_kernel_ms = probe_ms;
+  ctx->stats_timing_pending = 2;   // total = ev0..ev1, probe = ev2..ev3, read by qhip_ctx_last_stats
   ctx->stats.rows_in = (int64_t)P;
   ctx->stats.rows_out = (int64_t)total_rows;
   ctx->stats.groups = (int64_t)M;

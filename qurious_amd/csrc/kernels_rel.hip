@@ -322,6 +322,13 @@ __global__ __launch_bounds__(QH_BLOCK) void k_lower_bound_u32(const u32* a, u64 
   while (lo < hi) { const u64 mid = (lo + hi) >> 1; if ((u64)a[mid] < v) lo = mid + 1; else hi = mid; }
   pos[k] = (u32)lo;
 }
+// index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    out[k] = i == QH_NULL_IDX ? QH_NULL_IDX : inner[i];
+  }
+}
 __global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n) {
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (u32)i;
 }
@@ -517,6 +524,9 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
   if (!n) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_build_insert<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (const u64*)keyvalid, (u64)n,
                                    (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)slot_row, (u32*)bloom, bloom_mask, (u32*)status));
+}
+void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s) {
+  if (m) hipLaunchKernelGGL(k_gather_u32_nullable, dim3(grid_for(m)), dim3(QH_BLOCK), 0, s, (const u32*)inner, (const u32*)idx, (u32*)out, (u64)m);
 }
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u64*)bound, nb, (u32*)pos);

@@ -54,7 +54,7 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
     if (roots[k] < 0 || roots[k] >= n_exprs) continue;
     const qhip_expr& e = exprs[roots[k]];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
-    const DevColumn& col = t->cols[(size_t)e.column];
+    const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
     if (col.type.id != QHIP_UTF8) continue;
     if (col.utf8_max_len < 0) {
       DevBuf m(4);
@@ -68,7 +68,70 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
   }
 }
 
-DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null) {
+const DevColumn& resolved(Ctx* ctx, const DevColumn& col) {
+  if (!col.deferred) return col;
+  DeferredGather& d = *col.deferred;
+  if (!d.done) {
+    d.result = gather_column(ctx, d.src, d.idx->as<uint32_t>(), d.m, d.idx_may_be_null);
+    d.done = true;
+    d.src = DevColumn();   // the source buffers and the index vector are no longer needed by this column
+    d.idx.reset();
+  }
+  if (col.utf8_max_len >= 0 && d.result.utf8_max_len < 0) d.result.utf8_max_len = col.utf8_max_len;
+  // the table keeps the gathered column from now on (tables are immutable to their users; this only fills in a value
+  // that was owed). Other tables sharing the DeferredGather find the cached result.
+  DevColumn r = d.result;
+  const_cast<DevColumn&>(col) = std::move(r);
+  return col;
+}
+
+void resolve_all(Ctx* ctx, const qhip_table* t) {
+  for (const DevColumn& c : t->cols) (void)resolved(ctx, c);
+}
+
+void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::shared_ptr<DevBuf>& idx, uint64_t m, bool idx_may_be_null,
+                  std::vector<DevColumn>& out) {
+  std::vector<std::pair<const DevBuf*, std::shared_ptr<DevBuf>>> composed;   // inner index vector -> inner[idx]
+  for (const DevColumn& c : cols) {
+    DevColumn o;
+    o.type = c.type;
+    o.length = (int64_t)m;
+    o.utf8_max_len = c.utf8_max_len;
+    auto d = std::make_shared<DeferredGather>();
+    d->m = m;
+    if (c.deferred && !c.deferred->done) {
+      const DeferredGather& in = *c.deferred;
+      std::shared_ptr<DevBuf> both;
+      for (auto& e : composed) if (e.first == in.idx.get()) both = e.second;
+      if (!both) {
+        both = std::make_shared<DevBuf>((m + 1) * 4);
+        launch_gather_u32_nullable(in.idx->as<uint32_t>(), idx->as<uint32_t>(), both->as<uint32_t>(), m, ctx->stream);
+        composed.emplace_back(in.idx.get(), both);
+      }
+      d->src = in.src;
+      d->idx = both;
+      d->idx_may_be_null = in.idx_may_be_null || idx_may_be_null;
+    } else {
+      d->src = c.deferred ? c.deferred->result : c;
+      d->src.deferred.reset();
+      d->idx = idx;
+      d->idx_may_be_null = idx_may_be_null;
+    }
+    o.null_count = (d->src.null_count > 0 || d->idx_may_be_null) ? 1 : 0;
+    if (d->src.type.id == QHIP_NULL) o.null_count = (int64_t)m;
+    o.deferred = d;
+    out.push_back(std::move(o));
+  }
+}
+
+void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs) {
+  for (int k = 0; k < n_exprs; ++k)
+    if (exprs[k].kind == QHIP_EXPR_COLUMN && exprs[k].column >= 0 && exprs[k].column < (int)t->cols.size())
+      (void)resolved(ctx, t->cols[(size_t)exprs[k].column]);
+}
+
+DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, uint64_t m, bool idx_may_be_null) {
+  const DevColumn& col = resolved(ctx, col_in);
   DevColumn out;
   out.type = col.type;
   out.length = (int64_t)m;

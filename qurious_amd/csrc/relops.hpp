@@ -21,6 +21,15 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
 uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel);
 // out[k] = col[idx[k]] (device u32 indices, kNullIdx -> NULL when idx_may_be_null)
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null);
+// The column itself, gathered now if it was deferred (the result is cached in the column's DeferredGather).
+const DevColumn& resolved(Ctx* ctx, const DevColumn& col);
+// Deferred out[k] = col[idx[k]] for every column of `cols`, appended to `out`: nothing is gathered until a column is
+// read. Deferred inputs are composed (one u32 gather per distinct inner index vector), never chained.
+void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::shared_ptr<DevBuf>& idx, uint64_t m, bool idx_may_be_null,
+                  std::vector<DevColumn>& out);
+void resolve_all(Ctx* ctx, const qhip_table* t);
+// gather the columns the expression trees reference (everything else may stay deferred)
+void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs);
 // make sure every Utf8 column used directly as a key (roots are Column nodes) has its longest-value length cached in the
 // table and copied into icols (packed key words are sized from it)
 void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,

@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "relops.hpp"
 
 namespace qhip {
 
@@ -226,7 +227,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
   std::vector<OffFix> offfix;
   std::vector<std::pair<ArrowArray*, uint8_t*>> nullfix;
   for (size_t c = 0; c < t->cols.size(); ++c) {
-    const DevColumn& col = t->cols[c];
+    const DevColumn& col = resolved(ctx, t->cols[c]);
     ArrowArray* ca = &top->child_storage[c];
     HostArrayPrivate* p = new HostArrayPrivate();
     ca->private_data = p;
