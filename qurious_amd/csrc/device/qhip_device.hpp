@@ -564,7 +564,7 @@ __device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const 
   u32 s = (u32)h & (nslots - 1);
   for (u32 probes = 0; probes < nslots; ++probes) {
     const u64* slot = table + (size_t)s * (1 + W);
-    if (slot[0] != QH_READY) return 0xFFFFFFFFu;
+    if (slot[0] < QH_READY) return 0xFFFFFFFFu;
     bool eq = true;
 #pragma unroll
     for (int w = 0; w < W; ++w) eq &= slot[1 + w] == k[w];
@@ -584,9 +584,10 @@ struct ProbeLaunch {
   const u64* table;      // distinct build keys
   const u32* bloom;      // one bit per (hash >> 32) & bloom_mask: 0 => the key is not in the table (the filter stays in L2)
   const u32* count;      // build rows per slot (unused when start == nullptr)
-  const u32* start;      // first position of a slot's rows in `rows` (nullptr: unique build keys, rows[slot] is the row)
+  const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
-  u32* slot_of;          // out, per probe row: slot of its key, 0xFFFFFFFF = no match / NULL key / rejected by the filter
+  u32* slot_of;          // out, per probe row: slot of its key (unique build keys: the build row itself), 0xFFFFFFFF = no match
+                         // / NULL key / rejected by the filter
   u32* tile_total;       // out, per tile of 64 * QH_PROBE_R consecutive probe rows (one wavefront's share): number of pairs
   u32* visited;          // build-row bitmap to mark here (LeftSemi / LeftAnti without a residual filter) or nullptr
   u32* status;
@@ -634,12 +635,14 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       sid[r] = 0xFFFFFFFFu;
-      if (ok[r] && st[r] == QH_READY) {
+      if (ok[r] && st[r] >= QH_READY) {
         bool eq = true;
 #pragma unroll
         for (int w = 0; w < P::W; ++w) eq &= kw[r][w] == k[r][w];
         const u32 home = (u32)h[r] & (L.nslots - 1);
         sid[r] = eq ? home : qh_join_find<P::W>(L.table, L.nslots, k[r], (u64)home + 1);   // collision: walk on from the next slot
+        // unique build keys: the slot's state word carries its one build row, which is all pass 2 needs
+        if (!L.start && sid[r] != 0xFFFFFFFFu) sid[r] = (u32)((eq ? st[r] : L.table[(size_t)sid[r] * (1 + P::W)]) - 2);
       }
     }
     u32 total = 0;
@@ -655,8 +658,8 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (sid[r] != 0xFFFFFFFFu) {
-          const u32 s0 = L.start ? L.start[sid[r]] : sid[r], c = L.start ? L.count[sid[r]] : 1u;
-          for (u32 q = 0; q < c; ++q) { const u32 b = L.rows[s0 + q]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
+          const u32 s0 = L.start ? L.start[sid[r]] : 0u, c = L.start ? L.count[sid[r]] : 1u;
+          for (u32 q = 0; q < c; ++q) { const u32 b = L.start ? L.rows[s0 + q] : sid[r]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
         }
     }
     total = (u32)qh_wave_sum_u64(total);

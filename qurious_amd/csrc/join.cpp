@@ -101,9 +101,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   uint64_t* table = arena.as<uint64_t>();
   uint32_t* count = (uint32_t*)(arena.as<uint8_t>() + table_bytes);
   uint32_t* bloom = (uint32_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
-  DevBuf start, row_slot((B + 1) * 4), slot_row(((size_t)nslots + 1) * 4), sorted_rows;
-  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count,
-                           slot_row.as<uint32_t>(), bloom, bloom_bits - 1, ctx->status.as<uint32_t>(), s);
+  DevBuf start, row_slot((B + 1) * 4), sorted_rows;
+  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
+                           bloom_bits - 1, ctx->status.as<uint32_t>(), s);
   uint32_t max_count = 0;
   {
     uint32_t st[QS_WORDS];
@@ -112,12 +112,14 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
     max_count = st[QS_MAXCOUNT];
   }
-  // Unique build keys (every FK -> PK join): slot_row[slot] already is the CSR. Otherwise group the build rows by slot
-  // with a stable radix sort (ascending build row inside a key: the order the reference's reverse-built chains yield).
+  // Unique build keys (every FK -> PK join): each slot's state word names its one build row and nothing else is needed.
+  // Otherwise group the build rows by slot with a stable radix sort (ascending build row inside a key: the order the
+  // reference's reverse-built chains yield) into a CSR.
   const bool unique_keys = max_count <= 1 && env_int("QHIP_JOIN_FORCE_CSR", 0) == 0;
   const uint32_t* start_ptr = nullptr;
-  const uint32_t* rows_ptr = slot_row.as<uint32_t>();
+  const uint32_t* rows_ptr = nullptr;
   if (!unique_keys) {
+    launch_join_full_counts(W, table, nslots, count, s);
     DevBuf sorted_slot((B + 1) * 4), iota((B + 1) * 4);
     sorted_rows.alloc((B + 1) * 4);
     start.alloc(((size_t)nslots + 1) * 4);

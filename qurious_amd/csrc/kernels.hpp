@@ -31,8 +31,8 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
 
 // hash join (kernels_rel.hip)
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
-                              uint32_t* row_slot, uint32_t* count, uint32_t* slot_row, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status,
-                              hipStream_t s);
+                              uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
+void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s);
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s);
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s);
 void launch_join_emit(const uint32_t* slot_of, const uint32_t* tile_off, const uint32_t* count, const uint32_t* start, const uint32_t* rows,

@@ -219,10 +219,14 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
 // candidate re-check, hash_join.rs:191-215) maps every distinct build key to a slot; rows are then grouped by slot
 // (stable radix sort => ascending row order inside a group, the order the reverse-built chains produce) into a
 // CSR layout (start/count per slot). NULL keys are never inserted and never probe (eq of NULL is NULL).
+// Slot = [state][key words W]. state: 0 empty, 1 being written, v >= 2 ready with v - 2 = the build row that inserted the
+// key — for unique build keys (every FK -> PK join) that row IS the whole match list, so neither the per-slot counts nor
+// a slot -> row array are ever touched (a build row then costs two random accesses: the slot and its filter bit).
+// Further rows of a key only count themselves in extra[slot] and raise the duplicates flag (status[QS_MAXCOUNT] = 2).
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys, const u64* keyvalid, u64 n, u64* table, u32 nslots,
-                                                               u32* row_slot, u32* count, u32* slot_row, u32* bloom, u32 bloom_mask, u32* status) {
-  u32 maxc = 0;
+                                                               u32* row_slot, u32* extra, u32* bloom, u32 bloom_mask, u32* status) {
+  u32 flags = 0;
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
     u32 sid = nslots;   // NULL key: sorts behind every real slot, never probed
     if ((keyvalid[i >> 6] >> (i & 63)) & 1) {
@@ -230,28 +234,55 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys,
 #pragma unroll
       for (int w = 0; w < W; ++w) k[w] = keys[(size_t)w * n + i];
       const u64 h = qh_key_hash<W>(k);
-      bool inserted;
-      u64* slot = qh_find_or_insert<MemHbm, W>(table, nslots, 1 + W, k, h, (int)nslots, &inserted);
-      if (!slot) atomicOr(&status[QS_OVERFLOW], 1u);
-      else {
-        sid = (u32)((slot - table) / (1 + W));
-        const u32 old = atomicAdd(&count[sid], 1u);
-        maxc = old + 1 > maxc ? old + 1 : maxc;
-        slot_row[sid] = (u32)i;          // the row of a unique key (the only writer then); unused otherwise
-        if (inserted) { const u32 bit = (u32)(h >> 32) & bloom_mask; atomicOr(&bloom[bit >> 5], 1u << (bit & 31)); }
+      u32 s = (u32)h & (nslots - 1);
+      u32 probes = 0;
+      while (probes < nslots) {
+        u64* slot = table + (size_t)s * (1 + W);
+        const u64 st = qh_ld64<MemHbm>(slot);
+        if (st >= QH_READY) {
+          bool eq = true;
+#pragma unroll
+          for (int w = 0; w < W; ++w) eq &= qh_ld64<MemHbm>(slot + 1 + w) == k[w];
+          if (eq) { sid = s; atomicAdd(&extra[s], 1u); flags |= 1u << QS_MAXCOUNT; break; }
+          s = (s + 1) & (nslots - 1); ++probes;
+        } else if (st == QH_EMPTY) {
+          if (qh_cas64<MemHbm>(slot, QH_EMPTY, QH_BUSY)) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) qh_st64<MemHbm>(slot + 1 + w, k[w]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // key words visible before the slot reads as ready
+            qh_st64<MemHbm>(slot, (u64)i + 2);
+            const u32 bit = (u32)(h >> 32) & bloom_mask;
+            atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
+            sid = s;
+            break;
+          }
+          // lost the claim: look at the same slot again
+        }
+        // QH_BUSY: the claimer is between claim and publish; look again (a lane never spins inside an iteration)
       }
+      if (probes >= nslots) flags |= 1u << QS_OVERFLOW;
     }
     row_slot[i] = sid;
   }
-  maxc = (u32)qh_wave_max_u64(maxc);
-  // thousands of waves would serialise on this one word: only those that raise the maximum touch it atomically
-  if (qh_lane() == 0 && maxc > __hip_atomic_load(&status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&status[QS_MAXCOUNT], maxc);
+  // one flag update per wavefront, none when the flag is already up
+  const u64 dup = qh_ballot((flags >> QS_MAXCOUNT) & 1u), ovf = qh_ballot((flags >> QS_OVERFLOW) & 1u);
+  if (qh_lane() == 0) {
+    if (dup && __hip_atomic_load(&status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) atomicMax(&status[QS_MAXCOUNT], 2u);
+    if (ovf) atomicOr(&status[QS_OVERFLOW], 1u);
+  }
+}
+// duplicated build keys: rows per slot = (slot occupied ? 1 : 0) + extra[slot]
+template <int W>
+__global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table, u32 nslots, u32* count) {
+  for (u32 s = blockIdx.x * QH_BLOCK + threadIdx.x; s < nslots; s += gridDim.x * QH_BLOCK)
+    if (table[(size_t)s * (1 + W)] >= QH_READY) count[s] += 1u;
 }
 
 // probe pass 2 (get_matches_indices + probe_hash_table's index vectors, hash_join.rs:70-107,177-216): turn the slot
 // per probe row that pass 1 (qk_join_probe, device/qhip_device.hpp) left behind into (build row, probe row) pairs —
 // probe-row major, build rows ascending (hash_join.rs:475-512 pins that order). A wavefront owns the same 64 * R
-// consecutive probe rows as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts.
+// consecutive probe rows as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts. Unique build
+// keys (start == nullptr): pass 1 already resolved the slot to its one build row.
 __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* slot_of, const u32* tile_off, const u32* count, const u32* start,
                                                        const u32* rows, u64 np, u32* b_idx, u32* p_idx, u32* pair_off, u32* cnt_out,
                                                        u32* visited) {
@@ -280,9 +311,9 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* slot_of, cons
       base += qh_readlane32(incl, 63);
       if (pair_off && i < np) { pair_off[i] = o; cnt_out[i] = c[r]; }
       if (c[r]) {
-        const u32 s0 = start ? start[sid[r]] : sid[r];
+        const u32 s0 = start ? start[sid[r]] : 0u;
         for (u32 q = 0; q < c[r]; ++q) {
-          const u32 b = rows[s0 + q];
+          const u32 b = start ? rows[s0 + q] : sid[r];
           b_idx[o + q] = b;
           p_idx[o + q] = (u32)i;
           if (visited) atomicOr(&visited[b >> 5], 1u << (b & 31));
@@ -519,11 +550,13 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
   }
 
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
-                              uint32_t* row_slot, uint32_t* count, uint32_t* slot_row, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status,
-                              hipStream_t s) {
+                              uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s) {
   if (!n) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_build_insert<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (const u64*)keyvalid, (u64)n,
-                                   (u64*)table, nslots, (u32*)row_slot, (u32*)count, (u32*)slot_row, (u32*)bloom, bloom_mask, (u32*)status));
+                                   (u64*)table, nslots, (u32*)row_slot, (u32*)extra, (u32*)bloom, bloom_mask, (u32*)status));
+}
+void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
+  DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));
 }
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s) {
   if (m) hipLaunchKernelGGL(k_gather_u32_nullable, dim3(grid_for(m)), dim3(QH_BLOCK), 0, s, (const u32*)inner, (const u32*)idx, (u32*)out, (u64)m);
