@@ -586,9 +586,11 @@ struct ProbeLaunch {
   const u32* count;      // build rows per slot (unused when start == nullptr)
   const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
-  u32* slot_of;          // out, per probe row: slot of its key (unique build keys: the build row itself), 0xFFFFFFFF = no match
-                         // / NULL key / rejected by the filter
-  u32* tile_total;       // out, per tile of 64 * QH_PROBE_R consecutive probe rows (one wavefront's share): number of pairs
+  u32* ent_slot;         // out, per tile of 64 * QH_PROBE_R consecutive probe rows (one wavefront's share): the matching rows,
+  u32* ent_row;          //      compacted in row order at [tile * TILE, tile * TILE + tile_nent[tile]): slot of the key (unique
+                         //      build keys: the build row itself) and probe row. Rows without a match write nothing.
+  u32* tile_nent;        // out, per tile: number of matching probe rows
+  u32* tile_total;       // out, per tile: number of (build, probe) pairs
   u32* visited;          // build-row bitmap to mark here (LeftSemi / LeftAnti without a residual filter) or nullptr
   u32* status;
   u32 nslots, bloom_mask;
@@ -596,8 +598,9 @@ struct ProbeLaunch {
 
 #define QH_PROBE_R 4   // probe rows per thread and tile
 // Probe pass 1 (hash_join.rs:218-275 for every probe batch at once): evaluate the fused scan filter and the key words
-// straight from the probe table's columns, look the key up, keep only the slot per row (4 B) and the pair count per tile.
-// Pass 2 (k_join_emit) turns slots into ordered (build row, probe row) pairs once the tile totals have been scanned.
+// straight from the probe table's columns, look the key up, keep (slot, probe row) of the matching rows only — compacted
+// per 256-row tile with ballot/popcount ranks — and the pair count per tile. Pass 2 (k_join_emit) turns the entries into
+// ordered (build row, probe row) pairs once the tile totals have been scanned.
 // Phases, each a branch-free pass over the thread's R rows so that their loads are in flight together (a lookup is a
 // chain of dependent random reads; R independent chains per thread and many waves per CU hide its latency):
 // key words -> filter bit -> home slot of the table -> (rarely) the rest of the probe sequence -> row count.
@@ -645,14 +648,19 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
         if (!L.start && sid[r] != 0xFFFFFFFFu) sid[r] = (u32)((eq ? st[r] : L.table[(size_t)sid[r] * (1 + P::W)]) - 2);
       }
     }
-    u32 total = 0;
+    u32 total = 0, nent = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const bool found = sid[r] != 0xFFFFFFFFu;
       const u32 c = L.start ? L.count[found ? sid[r] : 0u] : 1u;
       total += found ? c : 0u;
-      const i64 i = tile * TILE + r * 64 + lane;
-      if (i < a.nrows) L.slot_of[i] = sid[r];
+      const u64 m = qh_ballot(found);
+      if (found) {
+        const size_t pos = (size_t)tile * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+        L.ent_slot[pos] = sid[r];
+        L.ent_row[pos] = (u32)(tile * TILE + r * 64 + lane);
+      }
+      nent += (u32)__builtin_popcountll(m);
     }
     if (L.visited) {
 #pragma unroll
@@ -663,7 +671,7 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
         }
     }
     total = (u32)qh_wave_sum_u64(total);
-    if (lane == 0) L.tile_total[tile] = total;
+    if (lane == 0) { L.tile_total[tile] = total; L.tile_nent[tile] = nent; }
   }
   qh_report(L.status, err);
 }

@@ -139,9 +139,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   bool visited_done = false;
 
   // ---- probe. Pass 1 (JIT: fused scan filter + key words + lookup straight from the probe table's columns) leaves one
-  // slot per probe row and one pair count per 256-row tile; the tile counts are scanned; pass 2 writes the pairs in
+  // (slot, probe row) entry per MATCHING probe row and one pair count per 256-row tile; the tile counts are scanned; pass 2 writes the pairs in
   // probe-row order. LeftSemi / LeftAnti without a residual filter only need the visited bits: pass 1 sets them.
-  DevBuf slot_of((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
+  DevBuf ent_slot((P + 1) * 4), ent_row((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
   uint64_t M = 0;
   hipEventRecord(ctx->ev[2], s);
   const bool want_pairs = !(semi_anti && froot < 0);
@@ -152,10 +152,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     DevBuf strlit;
     fill_kargs(ctx, R, rkp.bind, ka, strlit);
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
-    DevBuf tile_tot((ntiles + 1) * 4), total(4);
+    DevBuf tile_tot((ntiles + 1) * 4), tile_nent((ntiles + 1) * 4), total(4);
     HProbeLaunch pl;
     pl.table = table; pl.bloom = bloom; pl.count = count; pl.start = start_ptr; pl.rows = rows_ptr;
-    pl.slot_of = slot_of.as<uint32_t>();
+    pl.ent_slot = ent_slot.as<uint32_t>();
+    pl.ent_row = ent_row.as<uint32_t>();
+    pl.tile_nent = tile_nent.as<uint32_t>();
     pl.tile_total = tile_tot.as<uint32_t>();
     pl.visited = (mark_in_probe && !want_pairs) ? visited.as<uint32_t>() : nullptr;
     pl.status = ctx->status.as<uint32_t>();
@@ -177,8 +179,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (want_pairs) {
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
-      if (pad_right) { cnt.alloc((P + 1) * 4); pair_off.alloc((P + 1) * 4); }
-      launch_join_emit(slot_of.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+      if (pad_right) {
+        cnt.alloc((P + 1) * 4);
+        pair_off.alloc((P + 1) * 4);
+        QHIP_HIP_CHECK(hipMemsetAsync(cnt.ptr, 0, cnt.bytes, s));   // pass 2 only visits matching probe rows
+      }
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
                        mark_in_probe ? visited.as<uint32_t>() : nullptr, s);
     }

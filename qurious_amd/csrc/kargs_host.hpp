@@ -41,13 +41,15 @@ struct HProbeLaunch {
   const uint32_t* count;
   const uint32_t* start;
   const uint32_t* rows;
-  uint32_t* slot_of;
+  uint32_t* ent_slot;
+  uint32_t* ent_row;
+  uint32_t* tile_nent;
   uint32_t* tile_total;
   uint32_t* visited;
   uint32_t* status;
   uint32_t nslots, bloom_mask;
 };
-static_assert(sizeof(HProbeLaunch) == 9 * 8 + 8, "ProbeLaunch layout");
+static_assert(sizeof(HProbeLaunch) == 11 * 8 + 8, "ProbeLaunch layout");
 constexpr int kProbeTileRows = 64 * 4;   // one wavefront's share: 64 * QH_PROBE_R consecutive probe rows
 
 }  // namespace qhip

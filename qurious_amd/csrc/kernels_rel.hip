@@ -278,44 +278,37 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table,
     if (table[(size_t)s * (1 + W)] >= QH_READY) count[s] += 1u;
 }
 
-// probe pass 2 (get_matches_indices + probe_hash_table's index vectors, hash_join.rs:70-107,177-216): turn the slot
-// per probe row that pass 1 (qk_join_probe, device/qhip_device.hpp) left behind into (build row, probe row) pairs —
-// probe-row major, build rows ascending (hash_join.rs:475-512 pins that order). A wavefront owns the same 64 * R
-// consecutive probe rows as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts. Unique build
-// keys (start == nullptr): pass 1 already resolved the slot to its one build row.
-__global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* slot_of, const u32* tile_off, const u32* count, const u32* start,
-                                                       const u32* rows, u64 np, u32* b_idx, u32* p_idx, u32* pair_off, u32* cnt_out,
-                                                       u32* visited) {
-  constexpr int R = QH_PROBE_R, TILE = 64 * R;
+// probe pass 2 (get_matches_indices + probe_hash_table's index vectors, hash_join.rs:70-107,177-216): turn the
+// (slot, probe row) entries that pass 1 (qk_join_probe, device/qhip_device.hpp) compacted per tile into (build row,
+// probe row) pairs — probe-row major, build rows ascending (hash_join.rs:475-512 pins that order). A wavefront owns the
+// same tile as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts. Unique build keys
+// (start == nullptr): the entry already holds the one build row. cnt_out / pair_off (Right / Full joins) receive the
+// pair count and first pair position of every MATCHING probe row (cnt_out is zero-filled by the caller).
+__global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* tile_nent, const u32* tile_off,
+                                                       const u32* count, const u32* start, const u32* rows, u64 np, u32* b_idx, u32* p_idx,
+                                                       u32* pair_off, u32* cnt_out, u32* visited) {
+  constexpr int TILE = 64 * QH_PROBE_R;
   const int lane = qh_lane();
   const u64 ntiles = (np + TILE - 1) / TILE;
   for (u64 tile = (u64)blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6); tile < ntiles; tile += (u64)gridDim.x * (QH_BLOCK / 64)) {
-    u32 sid[R], c[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u64 i = tile * TILE + r * 64 + lane;
-      sid[r] = i < np ? slot_of[i] : QH_NULL_IDX;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool found = sid[r] != QH_NULL_IDX;
-      c[r] = start ? count[found ? sid[r] : 0u] : 1u;
-      c[r] = found ? c[r] : 0u;
-    }
+    const u32 n = tile_nent[tile];
     u32 base = tile_off[tile];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u64 i = tile * TILE + r * 64 + lane;
-      const u32 incl = wave_incl_scan_u32(c[r]);
-      const u32 o = base + incl - c[r];
+    for (u32 j0 = 0; j0 < n; j0 += 64) {
+      const u32 j = j0 + lane;
+      const bool live = j < n;
+      const u32 sid = live ? ent_slot[tile * TILE + j] : 0u, p = live ? ent_row[tile * TILE + j] : 0u;
+      u32 c = start ? count[sid] : 1u;
+      c = live ? c : 0u;
+      const u32 incl = wave_incl_scan_u32(c);
+      const u32 o = base + incl - c;
       base += qh_readlane32(incl, 63);
-      if (pair_off && i < np) { pair_off[i] = o; cnt_out[i] = c[r]; }
-      if (c[r]) {
-        const u32 s0 = start ? start[sid[r]] : 0u;
-        for (u32 q = 0; q < c[r]; ++q) {
-          const u32 b = start ? rows[s0 + q] : sid[r];
+      if (live) {
+        if (pair_off) { pair_off[p] = o; cnt_out[p] = c; }
+        const u32 s0 = start ? start[sid] : 0u;
+        for (u32 q = 0; q < c; ++q) {
+          const u32 b = start ? rows[s0 + q] : sid;
           b_idx[o + q] = b;
-          p_idx[o + q] = (u32)i;
+          p_idx[o + q] = p;
           if (visited) atomicOr(&visited[b >> 5], 1u << (b & 31));
         }
       }
@@ -564,12 +557,13 @@ void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u64*)bound, nb, (u32*)pos);
 }
-void launch_join_emit(const uint32_t* slot_of, const uint32_t* tile_off, const uint32_t* count, const uint32_t* start, const uint32_t* rows,
-                      uint64_t np, uint32_t* b_idx, uint32_t* p_idx, uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, hipStream_t s) {
+void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* tile_nent, const uint32_t* tile_off, const uint32_t* count,
+                      const uint32_t* start, const uint32_t* rows, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, uint32_t* pair_off,
+                      uint32_t* cnt_out, uint32_t* visited, hipStream_t s) {
   if (!np) return;
-  hipLaunchKernelGGL(k_join_emit, dim3(grid_for(np, QH_BLOCK * QH_PROBE_R)), dim3(QH_BLOCK), 0, s, (const u32*)slot_of, (const u32*)tile_off,
-                     (const u32*)count, (const u32*)start, (const u32*)rows, (u64)np, (u32*)b_idx, (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out,
-                     (u32*)visited);
+  hipLaunchKernelGGL(k_join_emit, dim3(grid_for(np, QH_BLOCK * QH_PROBE_R)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
+                     (const u32*)tile_nent, (const u32*)tile_off, (const u32*)count, (const u32*)start, (const u32*)rows, (u64)np, (u32*)b_idx,
+                     (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;
