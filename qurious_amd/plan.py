@@ -150,9 +150,9 @@ class Filter(PhysicalPlan):
         return [self.input]
 
 
-def _aggregate_device(table: DeviceTable, predicate: Optional[PhysicalExpr], group_exprs: Sequence[PhysicalExpr],
-                      aggregate_exprs: Sequence[AggregateExpr], names: Sequence[str]) -> DeviceTable:
-    ctx = table.ctx
+def _lower_aggregate(predicate: Optional[PhysicalExpr], group_exprs: Sequence[PhysicalExpr],
+                     aggregate_exprs: Sequence[AggregateExpr], names: Sequence[str]):
+    """The POD description of an aggregation (expression array, roots, qhip_agg array, output names) for the C ABI."""
     ea = ExprArray()
     pred = ea.lower(predicate) if predicate is not None else -1
     groups = [ea.lower(g) for g in group_exprs]
@@ -164,9 +164,15 @@ def _aggregate_device(table: DeviceTable, predicate: Optional[PhysicalExpr], gro
         aggs[k].return_type = to_qhip_dtype(a._return_type())
     arr, n = ea.c_array()
     cnames = (C.c_char_p * max(1, len(names)))(*[s.encode() for s in names])
+    return (arr, n, pred, int32_array(groups), len(groups), aggs, len(aggregate_exprs), cnames, ea)
+
+
+def _aggregate_device(table: DeviceTable, predicate: Optional[PhysicalExpr], group_exprs: Sequence[PhysicalExpr],
+                      aggregate_exprs: Sequence[AggregateExpr], names: Sequence[str], lowered=None) -> DeviceTable:
+    ctx = table.ctx
+    arr, n, pred, groups, n_groups, aggs, n_aggs, cnames, _keep = lowered or _lower_aggregate(predicate, group_exprs, aggregate_exprs, names)
     out = C.c_void_p()
-    ctx.check(ctx.lib.qhip_hash_aggregate_execute(ctx.handle, table.handle, arr, n, pred, int32_array(groups), len(groups), aggs,
-                                                  len(aggregate_exprs), cnames, C.byref(out)))
+    ctx.check(ctx.lib.qhip_hash_aggregate_execute(ctx.handle, table.handle, arr, n, pred, groups, n_groups, aggs, n_aggs, cnames, C.byref(out)))
     return DeviceTable(ctx, out)
 
 
@@ -193,9 +199,14 @@ class HashAggregate(PhysicalPlan):
 
     def execute_device(self) -> DeviceTable:
         table, pred = self._source()
-        names = [f.name for f in self._schema] if self._schema is not None else \
-            [f"c{k}" for k in range(len(self.group_exprs) + len(self.aggregate_exprs))]
-        return _aggregate_device(table, pred, self.group_exprs, self.aggregate_exprs, names)
+        # plan nodes are immutable after construction (like the reference's): the lowered description is built once
+        cached = getattr(self, "_lowered", None)
+        if cached is None or cached[0] is not pred:
+            names = [f.name for f in self._schema] if self._schema is not None else \
+                [f"c{k}" for k in range(len(self.group_exprs) + len(self.aggregate_exprs))]
+            cached = (pred, _lower_aggregate(pred, self.group_exprs, self.aggregate_exprs, names))
+            self._lowered = cached
+        return _aggregate_device(table, pred, self.group_exprs, self.aggregate_exprs, None, cached[1])
 
     def children(self):
         return [self.input]
@@ -288,8 +299,7 @@ class HashJoinExec(PhysicalPlan):
         rt, rpred = self._side(self.right, fuse)
         return self._join_tables(lt, rt, lpred, rpred)
 
-    def _join_tables(self, lt: DeviceTable, rt: DeviceTable, lpred=None, rpred=None) -> DeviceTable:
-        ctx = lt.ctx
+    def _lower(self, lpred, rpred):
         le, re_, fe = ExprArray(), ExprArray(), ExprArray()
         on_l = [le.lower(l) for l, _ in self.on]
         on_r = [re_.lower(r) for _, r in self.on]
@@ -303,8 +313,18 @@ class HashJoinExec(PhysicalPlan):
         la, ln = le.c_array()
         ra, rn = re_.c_array()
         fa, fn = fe.c_array()
+        return (la, ln, ra, rn, int32_array(on_l), int32_array(on_r), len(self.on), fa, fn, froot, int32_array(fsides), int32_array(fcols),
+                len(fcols), lp, rp, (le, re_, fe))
+
+    def _join_tables(self, lt: DeviceTable, rt: DeviceTable, lpred=None, rpred=None) -> DeviceTable:
+        ctx = lt.ctx
+        # plan nodes are immutable after construction (like the reference's): the lowered description is built once
+        cached = getattr(self, "_lowered", None)
+        if cached is None or cached[0] is not lpred or cached[1] is not rpred:
+            cached = (lpred, rpred, self._lower(lpred, rpred))
+            self._lowered = cached
+        la, ln, ra, rn, on_l, on_r, n_on, fa, fn, froot, fsides, fcols, n_fcols, lp, rp, _keep = cached[2]
         out = C.c_void_p()
-        ctx.check(ctx.lib.qhip_hash_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), la, ln, ra, rn,
-                                                 int32_array(on_l), int32_array(on_r), len(self.on), fa, fn, froot,
-                                                 int32_array(fsides), int32_array(fcols), len(fcols), lp, rp, C.byref(out)))
+        ctx.check(ctx.lib.qhip_hash_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), la, ln, ra, rn, on_l, on_r, n_on,
+                                                 fa, fn, froot, fsides, fcols, n_fcols, lp, rp, C.byref(out)))
         return DeviceTable(ctx, out)
