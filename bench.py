@@ -285,6 +285,12 @@ def main():
                                   "(the reference executor is single-threaded)",
                         "seconds": cdt}
 
+    stream_ceiling = None
+    if rank == 0:
+        try:
+            stream_ceiling = ctx.measure_stream_read(4 << 30, 5)
+        except Exception as e:   # a measurement aid only: never fail the bench line over it
+            log(f"stream-read ceiling not measured: {e}")
     line = {
         "metric": "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X",
         "value": value,
@@ -304,7 +310,10 @@ def main():
                    "resident_bytes_per_gpu": resident, "parallelism": f"replicated-shards x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": stats["main_kernel_name"], "kernel_ms": mean_kernel_ms,
-                     "algorithmic_bytes_per_row": bpr},
+                     "algorithmic_bytes_per_row": bpr,
+                     # the achievable ceiling measured with a plain 16 B/lane streaming-read kernel, same run
+                     "stream_read_GBps": stream_ceiling,
+                     "frac_of_stream_read": (achieved / stream_ceiling) if stream_ceiling else None},
         "cpu_baseline": cpu_baseline,
         "device": ctx.device_name(),
         "setup_s": {"generate": t_gen, "upload_h2d": t_upload, "h2d_GBps": resident / t_upload / 1e9},

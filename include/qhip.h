@@ -293,6 +293,12 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
 
+/* ---------------------------------------------------------------- measurement aid (SURVEY §8d "achievable-copy ceiling") */
+/* Reads `bytes` of a scratch HBM buffer with a plain 16-byte-per-lane streaming kernel (`iters` timed launches after
+ * one warm-up) and returns the achieved read bandwidth in GB/s: the practical ceiling the filter+aggregate kernel's
+ * roofline fraction can be compared with, next to the 8 TB/s data-sheet peak. */
+int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double* gb_per_s);
+
 /* ---------------------------------------------------------------- synthetic TPC-H-shaped inputs */
 /* Counter-based generators (splitmix64, seed 0x515552494F555301) writing Arrow-layout host
  * buffers the caller allocated. Row i of every column depends only on (seed, column, i). */

@@ -122,6 +122,7 @@ def load_library() -> C.CDLL:
             "qhip_device_available": (C.c_int, []),
             "qhip_ctx_last_stats": (C.c_int, [vp, P(qhip_exec_stats)]),
             "qhip_ctx_synchronize": (C.c_int, [vp]),
+            "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
             "qhip_table_to_arrow": (C.c_int, [vp, vp, i64, vp, vp]),
@@ -177,6 +178,12 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.qhip_ctx_synchronize(self.handle))
+
+    def measure_stream_read(self, nbytes: int = 1 << 32, iters: int = 5) -> float:
+        """Achieved GB/s of a plain streaming-read kernel over `nbytes` of HBM (the practical bandwidth ceiling)."""
+        out = C.c_double(0.0)
+        self.check(self.lib.qhip_measure_stream_read(self.handle, int(nbytes), int(iters), C.byref(out)))
+        return out.value
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)

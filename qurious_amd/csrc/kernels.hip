@@ -53,6 +53,19 @@ __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u3
   }
 }
 
+// plain streaming read (16 B per lane, grid-stride): the achievable-bandwidth yardstick of bench.py
+__global__ __launch_bounds__(QH_BLOCK) void k_stream_read(const uint4* p, u64 n16, u32* sink) {
+  u32 acc = 0;
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n16; i += (u64)gridDim.x * QH_BLOCK) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u) *sink = acc;   // keeps the loads alive; practically never taken
+}
+void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(QH_BLOCK), 0, s, (const uint4*)p, (u64)(bytes / 16), sink);
+}
+
 static inline unsigned grid_for(uint64_t n, unsigned cap = 2048) {
   uint64_t g = (n + QH_BLOCK - 1) / QH_BLOCK;
   if (g < 1) g = 1;
