@@ -293,6 +293,18 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
 
+/* ---------------------------------------------------------------- sort / limit */
+/* Sort::execute (physical/plan/sort.rs:48-82): concatenates the input, orders it by the key expressions with arrow's
+ * lexsort semantics (per key: descending[k], nulls_first[k]; floats in IEEE total order; ties keep the input order,
+ * sort.rs:62-73) and returns ONE batch. limit >= 0 keeps only the first `limit` rows (Sort::new_with_limit, the
+ * planner's top-N pushdown planner/mod.rs:69-75); limit < 0 = no limit. */
+int qhip_sort_execute(qhip_ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int32_t n_exprs,
+                      const int32_t* key_roots, const int32_t* descending, const int32_t* nulls_first, int32_t n_keys,
+                      int64_t limit, qhip_table** out);
+/* Limit::execute (physical/plan/limit.rs:27-58): rows [skip, skip + fetch) of the batch list, batch structure kept
+ * (fetch < 0 = no fetch limit). */
+int qhip_limit_execute(qhip_ctx* ctx, const qhip_table* in, int64_t skip, int64_t fetch, qhip_table** out);
+
 /* ---------------------------------------------------------------- measurement aid (SURVEY §8d "achievable-copy ceiling") */
 /* Reads `bytes` of a scratch HBM buffer with a plain 16-byte-per-lane streaming kernel (`iters` timed launches after
  * one warm-up) and returns the achieved read bandwidth in GB/s: the practical ceiling the filter+aggregate kernel's

@@ -424,6 +424,85 @@ def _hash_join(node: "P.HashJoinExec") -> List[pa.RecordBatch]:
     return out
 
 
+# ---------------------------------------------------------------- sort / limit
+def _dense_rank(arr: pa.Array) -> np.ndarray:
+    """Rank of every non-null value in arrow-ord's sort order (arrow 53 `sort`/`lexsort_to_indices`: integers, dates and
+    decimals by value, floats by IEEE total order (`total_cmp`), Utf8 bytewise, false < true); NULL slots get 0."""
+    t = arr.type
+    n = len(arr)
+    valid = np.array([v is not None for v in arr.to_pylist()], dtype=bool) if arr.null_count else np.ones(n, dtype=bool)
+    if pa.types.is_floating(t):
+        bits = np.asarray(arr.cast(pa.float64()).fill_null(0.0).to_numpy(zero_copy_only=False), dtype=np.float64).view(np.int64)
+        keys = np.where(bits < 0, ~bits, bits | np.int64(-2**63)).view(np.uint64).astype(object)     # total order image
+    elif pa.types.is_string(t) or pa.types.is_large_string(t):
+        keys = np.array([(v.encode() if v is not None else b"") for v in arr.to_pylist()], dtype=object)
+    elif pa.types.is_decimal(t):
+        sc = t.scale
+        keys = np.array([(int(v.scaleb(sc)) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
+    elif pa.types.is_boolean(t):
+        keys = np.array([(int(v) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
+    elif pa.types.is_date(t):
+        keys = np.array([0 if v is None else v for v in arr.cast(pa.int32() if pa.types.is_date32(t) else pa.int64()).to_pylist()], dtype=object)
+    elif pa.types.is_null(t):
+        keys = np.zeros(n, dtype=object)
+    else:
+        keys = np.array([(v if v is not None else 0) for v in arr.to_pylist()], dtype=object)
+    order = sorted(set(keys[valid].tolist()))
+    rank_of = {k: r for r, k in enumerate(order)}
+    return np.array([rank_of[k] if ok else 0 for k, ok in zip(keys.tolist(), valid.tolist())], dtype=np.int64), valid
+
+
+def lexsort_to_indices(columns, limit: Optional[int] = None) -> np.ndarray:
+    """arrow_ord::sort::lexsort_to_indices restated: columns = [(array, descending, nulls_first)], most significant
+    first. `descending` reverses the values only; NULL placement follows nulls_first alone; equal rows keep no
+    particular order in arrow — the reference adds the row number as the last key (sort.rs:62-73), which the caller
+    passes like any other column."""
+    n = len(columns[0][0]) if columns else 0
+    keys = []
+    for arr, descending, nulls_first in columns:
+        rank, valid = _dense_rank(arr)
+        if descending:
+            rank = -rank
+        null_key = np.where(valid, 1, 0) if nulls_first else np.where(valid, 0, 1)
+        keys.append((null_key, np.where(valid, rank, 0)))
+    flat = []
+    for null_key, rank in reversed(keys):      # np.lexsort: last key is the primary one
+        flat.append(rank)
+        flat.append(null_key)
+    idx = np.lexsort(flat) if flat else np.arange(n)
+    return idx[:limit] if limit is not None else idx
+
+
+def _sort(node: "P.Sort") -> pa.RecordBatch:
+    schema = node.input.schema()
+    merged = _concat(schema, execute(node.input))                                   # sort.rs:49
+    cols = [(evaluate(e.expr, merged), e.options.descending, e.options.nulls_first) for e in node.exprs]   # sort.rs:50-60
+    cols.append((pa.array(np.arange(merged.num_rows, dtype=np.uint64)), False, False))   # sort.rs:62-73: stable tie-break
+    idx = lexsort_to_indices(cols, node.limit)                                      # sort.rs:75
+    return merged.take(pa.array(idx.astype(np.uint64)))                             # sort.rs:76-80
+
+
+def _limit(batches: List[pa.RecordBatch], fetch: Optional[int], skip: int) -> List[pa.RecordBatch]:
+    """limit.rs:27-58, including the empty slice it emits when the window closes exactly on a batch boundary"""
+    max_fetch = fetch if fetch is not None else (1 << 64) - 1
+    results, fetched = [], 0
+    for batch in batches:
+        rows = batch.num_rows
+        if rows <= skip:
+            skip -= rows
+            continue
+        new_batch = batch.slice(skip, rows - skip)
+        skip = 0
+        remaining = max_fetch - fetched
+        if new_batch.num_rows <= remaining:
+            results.append(new_batch)
+            fetched += new_batch.num_rows
+        else:
+            results.append(new_batch.slice(0, remaining))
+            break
+    return results
+
+
 # ---------------------------------------------------------------- plan walker
 def execute(node) -> List[pa.RecordBatch]:
     """PhysicalPlan::execute() of the reference, on the CPU."""
@@ -453,6 +532,10 @@ def execute(node) -> List[pa.RecordBatch]:
         return [_aggregate(batch, [0, batch.num_rows], node.group_exprs, node.aggregate_exprs, node.schema())]
     if isinstance(node, P.Filter):
         return [filter_batch(b, node.predicate) for b in execute(node.input)]       # filter.rs:29-43
+    if isinstance(node, P.Sort):
+        return [_sort(node)]                                                        # sort.rs:81: always one batch
+    if isinstance(node, P.Limit):
+        return _limit(execute(node.input), node.fetch, node.skip)
     raise OracleError(2, f"oracle: unsupported plan node {type(node).__name__}")
 
 

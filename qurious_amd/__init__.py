@@ -11,7 +11,7 @@ from .datatypes import JoinSide, JoinType, Operator, ScalarValue  # noqa: F401
 from .expr import (AvgAggregateExpr, BinaryExpr, CastExpr, Column, CountAggregateExpr, IsNotNull, IsNull,  # noqa: F401
                    Literal, MaxAggregateExpr, MinAggregateExpr, Negative, PhysicalExpr, SumAggregateExpr, avg_return_type)
 from .planner import DefaultQueryPlanner  # noqa: F401
-from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, MemoryTable, NoGroupingAggregate, PhysicalPlan,  # noqa: F401
-                   Scan, build_join_schema)
+from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NoGroupingAggregate,  # noqa: F401
+                   PhysicalPlan, PhysicalSortExpr, Scan, Sort, SortOptions, build_join_schema)
 
 __version__ = "0.1.0"

@@ -136,6 +136,8 @@ def load_library() -> C.CDLL:
                                                       P(C.c_char_p), P(vp)]),
             "qhip_hash_join_execute": (C.c_int, [vp, vp, vp, i32, P(qhip_expr), i32, P(qhip_expr), i32, P(i32), P(i32), i32,
                                                  P(qhip_expr), i32, i32, P(i32), P(i32), i32, i32, i32, P(vp)]),
+            "qhip_sort_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), P(i32), P(i32), i32, i64, P(vp)]),
+            "qhip_limit_execute": (C.c_int, [vp, vp, i64, i64, P(vp)]),
             "qhip_partition_by_key": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(vp)]),
             "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
             "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),

@@ -755,4 +755,66 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   out.bind = g.bind;
 }
 
+// ---------------------------------------------------------------- sort key images
+void plan_sort_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, SortKeysPlan& out) {
+  out = SortKeysPlan();
+  if (n > 32) fail(QHIP_UNSUPPORTED, "more than 32 sort keys");
+  ExprGen g(es, input);
+  std::ostringstream body;
+  int off = 0;
+  for (int k = 0; k < n; ++k) {
+    const ENode& nd = es.at(roots[k]);
+    SortKeyDesc kd;
+    kd.root = roots[k]; kd.type = nd.type; kd.nullable = nd.nullable; kd.word_off = off; kd.words = 1; kd.top_bits = 64; kd.column = -1;
+    std::string code;
+    g.emit(kd.root, code);
+    body << code;
+    const std::string v = g.val(kd.root), okx = g.ok(kd.root);
+    auto store = [&](int w, const std::string& image) {
+      body << "    img[" << off + w << "] = " << (kd.nullable ? okx + " ? " : std::string("")) << image << (kd.nullable ? " : 0ULL" : "") << ";\n";
+    };
+    const DType& t = nd.type;
+    if (t.id == QHIP_UTF8) {
+      if (nd.kind != QHIP_EXPR_COLUMN) fail(QHIP_UNSUPPORTED, "ORDER BY on a computed Utf8 expression is not accelerated");
+      kd.words = 0; kd.top_bits = 0; kd.column = nd.column;
+    } else if (t.id == QHIP_DECIMAL128) {
+      kd.words = 2;
+      store(0, "(u64)(u128)" + v);
+      store(1, "((u64)((u128)" + v + " >> 64) ^ 0x8000000000000000ULL)");
+    } else if (t.id == QHIP_BOOL) {
+      kd.top_bits = 1;
+      store(0, "(" + v + " ? 1ULL : 0ULL)");
+    } else if (dtype_is_float(t)) {
+      store(0, "qh_f64_ord((double)" + v + ")");
+    } else if (intlike(t)) {
+      const int b = dtype_width(t) * 8;
+      kd.top_bits = b;
+      if (signed_intlike(t)) {
+        if (b == 64) store(0, "((u64)(i64)" + v + " ^ 0x8000000000000000ULL)");
+        else store(0, "(((u64)(i64)" + v + " + " + std::to_string(1ULL << (b - 1)) + "ULL) & " + std::to_string((1ULL << b) - 1) + "ULL)");
+      } else {
+        store(0, "(u64)" + v);
+      }
+    } else if (t.id == QHIP_NULL) {
+      kd.top_bits = 1;
+      store(0, "0ULL");
+    } else {
+      fail(QHIP_UNSUPPORTED, "ORDER BY on " + dtype_name(t) + " is not supported");
+    }
+    if (kd.nullable) body << "    valid |= " << okx << " ? " << (1u << k) << "u : 0u;\n";
+    else body << "    valid |= " << (1u << k) << "u;\n";
+    off += kd.words;
+    out.keys.push_back(kd);
+  }
+  out.NW = off;
+  std::ostringstream s;
+  s << "struct P {\n  static constexpr int NW = " << out.NW << ";\n  static constexpr int NK = " << n << ";\n";
+  s << "  __device__ static __forceinline__ void images(const KArgs& a, const i64 i, u64* img, u32& valid, u32& err) {\n" << body.str() << "  }\n};\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_sort_keys(KArgs a, u64* img, u64* keyvalid, u32* status) { "
+       "qh_sort_keys_body<P>(a, img, keyvalid, status); }\n";
+  out.source = s.str();
+  out.kernel_name = "qk_sort_keys";
+  out.bind = g.bind;
+}
+
 }  // namespace qhip

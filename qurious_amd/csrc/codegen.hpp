@@ -102,4 +102,22 @@ struct KeysPlan {
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
                bool probe_kernel = false);
 
+// ---------------------------------------------------------------- sort keys (physical/plan/sort.rs:48-82)
+// Every sort key becomes an ORDER-PRESERVING unsigned image (ascending unsigned order of the image = ascending order of
+// the value under arrow's lexsort: integers biased, floats in IEEE total order, Decimal128 as two words) so that the
+// lexicographic sort is a sequence of stable LSD radix passes. Utf8 keys must be plain columns; their images are cut
+// from the column's bytes chunk by chunk at sort time (words = 0 here).
+struct SortKeyDesc {
+  int root; DType type; bool nullable;
+  int word_off, words;   // image words [word_off, word_off + words), least significant first
+  int top_bits;          // significant bits of the most significant word (radix passes needed)
+  int column;            // Utf8: the table column
+};
+struct SortKeysPlan {
+  int NW = 0;
+  std::vector<SortKeyDesc> keys;
+  KernelBindings bind; std::string source; std::string kernel_name;
+};
+void plan_sort_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, SortKeysPlan& out);
+
 }  // namespace qhip

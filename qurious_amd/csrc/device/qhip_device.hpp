@@ -702,3 +702,33 @@ __device__ __forceinline__ void qh_eval_keys_body(const KArgs& a, u64* keys, u64
   }
   qh_report(status, err);
 }
+
+// ------------------------------------------------------------------ expression -> sort key images (physical/plan/sort.rs:51-60)
+// img[w * nrows + i] = word w of row i's order-preserving key images (NULL rows: 0); keyvalid[k * nwords + j] = validity
+// bits of sort key k for rows 64j..64j+63.
+template <class P>
+__device__ __forceinline__ void qh_sort_keys_body(const KArgs& a, u64* img, u64* keyvalid, u32* status) {
+  const i64 nwords = (a.nrows + 63) / 64;
+  const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  u32 err = 0;
+  for (i64 j = wave_global; j < nwords; j += nwaves) {
+    const i64 i = j * 64 + lane;
+    const bool inb = i < a.nrows;
+    u64 w[P::NW > 0 ? P::NW : 1];
+    u32 valid = 0, e = 0;
+    P::images(a, inb ? i : a.nrows - 1, w, valid, e);
+    err |= inb ? e : 0u;
+    if (inb) {
+#pragma unroll
+      for (int k = 0; k < P::NW; ++k) img[(size_t)k * a.nrows + i] = w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < P::NK; ++k) {
+      const u64 m = qh_ballot(inb && ((valid >> k) & 1u));
+      if (lane == 0) keyvalid[(size_t)k * nwords + j] = m;
+    }
+  }
+  qh_report(status, err);
+}

@@ -26,7 +26,7 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
                               uint8_t* out_data, hipStream_t s);
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s);
 void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipStream_t s);
-void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s);
+void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first = 0);
 void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s);
 void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total, uint32_t* out, hipStream_t s);
 
@@ -34,6 +34,12 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
                               uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s);
+void launch_sort_gather_img(const uint64_t* img, const uint32_t* idx, uint64_t n, uint64_t flip, uint64_t* out, hipStream_t s);
+void launch_sort_gather_valid(const uint64_t* validwords, const uint32_t* idx, uint64_t n, bool nulls_first, uint64_t* out, hipStream_t s);
+void launch_sort_utf8_chunk(const int32_t* offsets, const uint8_t* data, const uint8_t* validity, const uint32_t* idx, uint64_t n, int chunk,
+                            uint64_t flip, uint64_t* out, hipStream_t s);
+void stable_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
+                           hipStream_t s);
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s);
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s);
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* tile_nent, const uint32_t* tile_off, const uint32_t* count,

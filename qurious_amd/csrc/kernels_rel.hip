@@ -346,6 +346,37 @@ __global__ __launch_bounds__(QH_BLOCK) void k_lower_bound_u32(const u32* a, u64 
   while (lo < hi) { const u64 mid = (lo + hi) >> 1; if ((u64)a[mid] < v) lo = mid + 1; else hi = mid; }
   pos[k] = (u32)lo;
 }
+// ================================================================ sort (physical/plan/sort.rs:48-82)
+// lexsort_to_indices as a sequence of stable LSD radix passes over order-preserving key images, least significant key
+// word first; the implicit last key of the reference (the row number, sort.rs:62-73) is the initial order of `idx`.
+__global__ __launch_bounds__(QH_BLOCK) void k_sort_gather_img(const u64* img, const u32* idx, u64 n, u64 flip, u64* out) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < n; k += (u64)gridDim.x * QH_BLOCK) out[k] = img[idx[k]] ^ flip;
+}
+// null placement pass: out[k] = 1 for the rows that go LAST in this key (nulls_first: the valid ones)
+__global__ __launch_bounds__(QH_BLOCK) void k_sort_gather_valid(const u64* validwords, const u32* idx, u64 n, u32 nulls_first, u64* out) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < n; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    const u32 v = (u32)((validwords[i >> 6] >> (i & 63)) & 1);
+    out[k] = nulls_first ? v : (v ^ 1u);
+  }
+}
+// Utf8 key: chunk c >= 0 -> bytes [8c, 8c+8) of the value, big-endian, zero-padded (unsigned compare of the chunk sequence
+// = bytewise compare up to trailing NULs); c < 0 -> the length (orders "ab" before "ab\0"). NULL values -> 0.
+__global__ __launch_bounds__(QH_BLOCK) void k_sort_utf8_chunk(const int* offsets, const u8* data, const u8* validity, const u32* idx, u64 n,
+                                                             int chunk, u64 flip, u64* out) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < n; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    u64 v = 0;
+    if (!validity || qh_bit(validity, i)) {
+      const int b = offsets[i], len = offsets[i + 1] - b;
+      if (chunk < 0) v = (u64)(u32)len;
+      else
+        for (int j = 0; j < 8; ++j) { const int p = chunk * 8 + j; v = (v << 8) | (p < len ? (u64)data[b + p] : 0ULL); }
+    }
+    out[k] = v ^ flip;
+  }
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -353,8 +384,8 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inn
     out[k] = i == QH_NULL_IDX ? QH_NULL_IDX : inner[i];
   }
 }
-__global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n) {
-  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (u32)i;
+__global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n, u32 first) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = first + (u32)i;
 }
 __global__ __launch_bounds__(QH_BLOCK) void k_fill_u32(u32* out, u64 n, u32 v) {
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = v;
@@ -520,8 +551,8 @@ void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipS
   if (n) hipLaunchKernelGGL(k_utf8_max_len, dim3(grid_for(n, QH_BLOCK, 1024)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (u64)n, (u32*)out);
 }
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, (u32*)p, v); }
-void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n);
+void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first) {
+  if (n) hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, first);
 }
 void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, v);
@@ -550,6 +581,18 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));
+}
+void launch_sort_gather_img(const uint64_t* img, const uint32_t* idx, uint64_t n, uint64_t flip, uint64_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sort_gather_img, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)img, (const u32*)idx, (u64)n, (u64)flip, (u64*)out);
+}
+void launch_sort_gather_valid(const uint64_t* validwords, const uint32_t* idx, uint64_t n, bool nulls_first, uint64_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sort_gather_valid, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)validwords, (const u32*)idx, (u64)n,
+                            nulls_first ? 1u : 0u, (u64*)out);
+}
+void launch_sort_utf8_chunk(const int32_t* offsets, const uint8_t* data, const uint8_t* validity, const uint32_t* idx, uint64_t n, int chunk,
+                            uint64_t flip, uint64_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sort_utf8_chunk, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (const u8*)data, (const u8*)validity,
+                            (const u32*)idx, (u64)n, chunk, (u64)flip, (u64*)out);
 }
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s) {
   if (m) hipLaunchKernelGGL(k_gather_u32_nullable, dim3(grid_for(m)), dim3(QH_BLOCK), 0, s, (const u32*)inner, (const u32*)idx, (u32*)out, (u64)m);
@@ -599,6 +642,15 @@ void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words
 // stable sort of (key, value) pairs on the low `bits` bits of the key (rocPRIM LSD radix sort): groups build rows by
 // hash-table slot / rows by partition id while keeping ascending row order inside a group
 void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
+                           hipStream_t s) {
+  if (!n) return;
+  size_t tmp_bytes = 0;
+  rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
+  DevBuf tmp(tmp_bytes);
+  rocprim::radix_sort_pairs(tmp.ptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
+}
+
+void stable_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
                            hipStream_t s) {
   if (!n) return;
   size_t tmp_bytes = 0;

@@ -225,6 +225,75 @@ class NoGroupingAggregate(HashAggregate):
         return None   # no_grouping.rs:63-65
 
 
+class SortOptions:
+    """arrow::compute::SortOptions { descending, nulls_first } (arrow-rs default: ascending, nulls first)"""
+
+    def __init__(self, descending: bool = False, nulls_first: bool = True):
+        self.descending, self.nulls_first = bool(descending), bool(nulls_first)
+
+
+class PhysicalSortExpr:
+    """physical/plan/sort.rs:12-21 (`PhyscialSortExpr` in the reference)"""
+
+    def __init__(self, expr: PhysicalExpr, options: SortOptions):
+        self.expr, self.options = expr, options
+
+
+class Sort(PhysicalPlan):
+    """physical/plan/sort.rs:23-86: lexsort of the concatenated input by the key expressions, ties in input order, one
+    output batch; `limit` keeps the first rows only (Sort::new_with_limit, the planner's top-N pushdown)."""
+
+    def __init__(self, exprs: Sequence[PhysicalSortExpr], input: PhysicalPlan, limit: Optional[int] = None):
+        self.exprs, self.input, self.limit = list(exprs), input, limit
+
+    @staticmethod
+    def new_with_limit(exprs: Sequence[PhysicalSortExpr], input: PhysicalPlan, limit: Optional[int]) -> "Sort":
+        return Sort(exprs, input, limit)
+
+    def schema(self) -> pa.Schema:
+        return self.input.schema()
+
+    def execute_device(self) -> DeviceTable:
+        table = self.input.execute_device()
+        ctx = table.ctx
+        cached = getattr(self, "_lowered", None)
+        if cached is None:
+            ea = ExprArray()
+            roots = [ea.lower(e.expr) for e in self.exprs]
+            arr, n = ea.c_array()
+            cached = (arr, n, int32_array(roots), int32_array([int(e.options.descending) for e in self.exprs]),
+                      int32_array([int(e.options.nulls_first) for e in self.exprs]), len(roots), ea)
+            self._lowered = cached
+        arr, n, roots, desc, nf, n_keys, _keep = cached
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_sort_execute(ctx.handle, table.handle, arr, n, roots, desc, nf, n_keys,
+                                            -1 if self.limit is None else int(self.limit), C.byref(out)))
+        return DeviceTable(ctx, out)
+
+    def children(self):
+        return self.input.children()   # sort.rs:83-85
+
+
+class Limit(PhysicalPlan):
+    """physical/plan/limit.rs:10-62: rows [skip, skip + fetch) of the input's batch list"""
+
+    def __init__(self, input: PhysicalPlan, fetch: Optional[int], skip: int):
+        self.input, self.fetch, self.skip = input, fetch, int(skip)
+
+    def schema(self) -> pa.Schema:
+        return self.input.schema()
+
+    def execute_device(self) -> DeviceTable:
+        table = self.input.execute_device()
+        ctx = table.ctx
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_limit_execute(ctx.handle, table.handle, self.skip, -1 if self.fetch is None else int(self.fetch), C.byref(out)))
+        return DeviceTable(ctx, out)
+
+    def children(self):
+        return self.input.children()   # limit.rs:59-61
+
+
 ColumnIndex = Tuple[int, JoinSide]
 
 

@@ -10,7 +10,8 @@ import pyarrow as pa
 from . import _ffi
 from .datatypes import JoinType
 from .expr import AggregateExpr, PhysicalExpr
-from .plan import Filter, HashAggregate, HashJoinExec, JoinFilter, MemoryTable, NoGroupingAggregate, PhysicalPlan, Scan
+from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NoGroupingAggregate, PhysicalPlan,
+                   PhysicalSortExpr, Scan, Sort, SortOptions)
 
 
 class DefaultQueryPlanner:
@@ -36,3 +37,19 @@ class DefaultQueryPlanner:
         if len(on) == 0:
             raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "join without equi-keys: NestedLoopJoinExec stays on the CPU path")
         return HashJoinExec.try_new(left, right, join_type, on, filter)
+
+    def physical_plan_sort(self, input: PhysicalPlan, exprs: Sequence[Tuple[PhysicalExpr, bool]], limit: Optional[int] = None) -> PhysicalPlan:
+        """planner/mod.rs:330-348: every ORDER BY expression (expr, asc) becomes SortOptions{descending: !asc,
+        nulls_first: true}"""
+        return Sort.new_with_limit([PhysicalSortExpr(e, SortOptions(descending=not asc, nulls_first=True)) for e, asc in exprs], input, limit)
+
+    def physical_plan_limit(self, input: PhysicalPlan, fetch: Optional[int], skip: int,
+                            sort_exprs: Optional[Sequence[Tuple[PhysicalExpr, bool]]] = None) -> PhysicalPlan:
+        """planner/mod.rs:67-83: LIMIT directly over ORDER BY (pass the ORDER BY's expressions as `sort_exprs` and its
+        input as `input`) sorts only the first skip + fetch rows (top-N), then applies the window; any other LIMIT is a
+        plain Limit node."""
+        if sort_exprs is not None and fetch is not None:
+            return Limit(self.physical_plan_sort(input, sort_exprs, fetch + skip), fetch, skip)
+        if sort_exprs is not None:
+            return Limit(self.physical_plan_sort(input, sort_exprs, None), fetch, skip)
+        return Limit(input, fetch, skip)

@@ -67,3 +67,20 @@ def q3(customer, orders, lineitem, join_cls=None):
                         pa.field("revenue", t4)])
     return HashAggregate(schema, j2, [Column("l_orderkey", 6), Column("o_orderdate", 4), Column("o_shippriority", 5)],
                          [SumAggregateExpr(revenue, t4)])
+
+
+def q3_top10(customer, orders, lineitem, join_cls=None):
+    """Q3 through its ORDER BY revenue DESC, o_orderdate LIMIT 10 (q3.slt:20-24), lowered like the reference's planner does
+    (planner/mod.rs:67-83): Limit(fetch 10) over Sort(top-N = 10) over the aggregate. (The reference also reorders the
+    select list with a Projection in between — SURVEY §8f rank 2; the columns here stay in aggregate order:
+    l_orderkey, o_orderdate, o_shippriority, revenue.)"""
+    from .planner import DefaultQueryPlanner
+    agg = q3(customer, orders, lineitem, join_cls)
+    return DefaultQueryPlanner().physical_plan_limit(agg, 10, 0, sort_exprs=[(Column("revenue", 3), False), (Column("o_orderdate", 1), True)])
+
+
+def q1_full_ordered(table: MemoryTable):
+    """Q1 through its ORDER BY l_returnflag, l_linestatus (q1.slt:19-21)"""
+    from .planner import DefaultQueryPlanner
+    return DefaultQueryPlanner().physical_plan_sort(q1_full(table), [(Column("l_returnflag", 0), True), (Column("l_linestatus", 1), True)])
+

@@ -35,6 +35,28 @@ def test_q3_sf001_matches_oracle(ctx, oracle):
     assert rows_of(got_j) == rows_of(want_j)
 
 
+def test_q3_order_by_revenue_limit_10(ctx, oracle, golden):
+    """Q3 to its last operator: top-10 by revenue DESC, o_orderdate (q3.slt:20-24), bit-exact and in the same order as the
+    oracle; the reference's SF0.01 golden pins the output type's scale (4 digits) and the ordering property."""
+    plan = queries.q3_top10(*_q3_tables(0.01))
+    got = plan.execute()
+    want = oracle.execute(plan)
+    assert [b.num_rows for b in got] == [b.num_rows for b in want] == [10]
+    assert rows_of(got) == rows_of(want)
+    rev = [r[3] for r in rows_of(got)]
+    assert rev == sorted(rev, reverse=True)
+    ref = golden["tpch_q3_sf001"]["rows"]
+    assert len(ref) == 10 and [r[1] for r in ref] == sorted((r[1] for r in ref), key=float, reverse=True)
+    assert all(len(r[1].split(".")[1]) == 4 for r in ref) and got[0].schema.field(3).type.scale == 4
+
+
+def test_q1_order_by_flags(ctx, oracle):
+    li = synth.lineitem(200_000, batch_rows=65_536)
+    plan = queries.q1_full_ordered(q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, li))
+    got, want = plan.execute(), oracle.execute(plan)
+    assert rows_of(got) == rows_of(want) and [r[:2] for r in rows_of(got)] == [("A", "F"), ("N", "F"), ("N", "O"), ("R", "F")]
+
+
 def test_partition_by_key_matches_mirror_and_roundtrips(ctx, oracle):
     rng = np.random.default_rng(31)
     n = 50_000
