@@ -103,7 +103,7 @@ typedef enum qhip_operator {
   QHIP_OP_ADD, QHIP_OP_SUB, QHIP_OP_MUL, QHIP_OP_DIV, QHIP_OP_MOD
 } qhip_operator;
 
-/* physical/expr/{column,literal,binary,cast,is_null,is_not_null,negative}.rs */
+/* physical/expr/{column,literal,binary,cast,is_null,is_not_null,negative,case,like}.rs */
 typedef enum qhip_expr_kind {
   QHIP_EXPR_COLUMN = 0,   /* column.rs:24-34   : `column` = index into the input schema */
   QHIP_EXPR_LITERAL = 1,  /* literal.rs:20-22  : ScalarValue broadcast; value in lit_* by dtype */
@@ -111,7 +111,11 @@ typedef enum qhip_expr_kind {
   QHIP_EXPR_CAST = 3,     /* cast.rs:33-37     : child `left`, target `dtype`, safe=false */
   QHIP_EXPR_IS_NULL = 4,  /* is_null.rs        : child `left` */
   QHIP_EXPR_IS_NOT_NULL = 5,
-  QHIP_EXPR_NEGATIVE = 6  /* negative.rs       : child `left` */
+  QHIP_EXPR_NEGATIVE = 6, /* negative.rs       : child `left` */
+  QHIP_EXPR_IF = 7,       /* case.rs:33-48     : zip(mask = `left`, truthy = `right`, falsy = `third`); CASE WHEN c1 THEN v1
+                           *                      WHEN c2 THEN v2 ELSE e END is lowered as IF(c1, v1, IF(c2, v2, e)) */
+  QHIP_EXPR_LIKE = 8      /* like.rs:28-43     : `left` LIKE `right` (a Utf8 literal pattern: % _ and \ escapes);
+                           *                      op != 0 = NOT LIKE */
 } qhip_expr_kind;
 
 /* One node of an expression tree stored as a flat array; children are indices
@@ -124,6 +128,7 @@ typedef struct qhip_expr {
   int32_t column;
   int32_t left;
   int32_t right;
+  int32_t third;        /* QHIP_EXPR_IF only (-1 otherwise) */
   qhip_dtype dtype;
   int32_t lit_is_null;
   uint64_t lit_lo;
@@ -292,6 +297,13 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
                            int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
+
+/* ---------------------------------------------------------------- projection */
+/* Projection::execute (physical/plan/projection.rs:27-46): one output column per expression, evaluated over every
+ * input batch (batch structure kept). A plain Column expression shares the input column's buffers; everything else is
+ * computed by ONE generated kernel for all expressions together. */
+int qhip_projection_execute(qhip_ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int32_t n_exprs,
+                            const int32_t* roots, int32_t n_out, const char* const* out_names, qhip_table** out);
 
 /* ---------------------------------------------------------------- sort / limit */
 /* Sort::execute (physical/plan/sort.rs:48-82): concatenates the input, orders it by the key expressions with arrow's

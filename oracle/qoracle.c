@@ -478,6 +478,71 @@ static int eval_binary(int op, const qo_col* l, const qo_col* r, int64_t n, qo_c
   return 0;
 }
 
+/* arrow_select::zip::zip(mask, truthy, falsy) as CaseExpr::evaluate uses it (physical/expr/case.rs:33-48): row i comes
+ * from `truthy` where the mask is valid and true, else from `falsy`; the two sides must have the same type. */
+static int eval_zip(const qo_col* mask, const qo_col* t, const qo_col* f, int64_t n, qo_col* out) {
+  if (mask->type.id != QHIP_BOOL) QO_FAIL(QHIP_INVALID_ARGUMENT, "Internal error: CASE WHEN must be boolean");
+  if (t->type.id != f->type.id || t->type.precision != f->type.precision || t->type.scale != f->type.scale)
+    QO_FAIL(QHIP_INVALID_ARGUMENT, "Invalid argument error: arguments need to have the same data type");
+  const uint8_t* mv = (const uint8_t*)mask->values;
+  const int with_valid = t->valid || f->valid || t->type.id == QHIP_NULL;
+  if (t->type.id == QHIP_UTF8) {
+    memset(out, 0, sizeof *out);
+    out->type = t->type; out->n = n; out->owned = 1;
+    out->offsets = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const qo_col* src = ((!mask->valid || mask->valid[i]) && mv[i]) ? t : f;
+      total += src->offsets[i + 1] - src->offsets[i];
+    }
+    out->data = (uint8_t*)malloc((size_t)(total + 1));
+    if (with_valid) out->valid = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const qo_col* src = ((!mask->valid || mask->valid[i]) && mv[i]) ? t : f;
+      const int len = src->offsets[i + 1] - src->offsets[i];
+      out->offsets[i] = (int32_t)pos;
+      if (len) memcpy(out->data + pos, src->data + src->offsets[i], (size_t)len);
+      pos += len;
+      if (with_valid) out->valid[i] = (uint8_t)(!src->valid || src->valid[i]);
+    }
+    out->offsets[n] = (int32_t)pos;
+    return 0;
+  }
+  int rc = col_alloc(out, t->type, n, with_valid);
+  if (rc) return rc;
+  const int w = type_width(t->type.id);
+  for (int64_t i = 0; i < n; ++i) {
+    const qo_col* src = ((!mask->valid || mask->valid[i]) && mv[i]) ? t : f;
+    if (w) memcpy((uint8_t*)out->values + (size_t)i * (size_t)w, (const uint8_t*)src->values + (size_t)i * (size_t)w, (size_t)w);
+    if (with_valid) out->valid[i] = (uint8_t)(t->type.id == QHIP_NULL ? 0 : (!src->valid || src->valid[i]));
+  }
+  return 0;
+}
+
+/* arrow_string::like::like (physical/expr/like.rs:28-43): `%` any sequence of characters, `_` exactly one character
+ * (a UTF-8 code point), backslash escapes the next pattern character. Recursive on purpose (the HIP matcher is an
+ * iterative backtracker: two independent formulations). */
+static int utf8_char_len(const uint8_t* s, int n) {
+  int k = 1;
+  while (k < n && (s[k] & 0xC0) == 0x80) ++k;
+  return k;
+}
+static int like_match(const uint8_t* s, int n, const uint8_t* p, int m) {
+  if (m == 0) return n == 0;
+  if (p[0] == '%') {
+    while (m > 1 && p[1] == '%') { ++p; --m; }
+    for (int k = 0;; k += utf8_char_len(s + k, n - k)) {
+      if (like_match(s + k, n - k, p + 1, m - 1)) return 1;
+      if (k >= n) return 0;
+    }
+  }
+  if (n == 0) return 0;
+  if (p[0] == '_') { const int c = utf8_char_len(s, n); return like_match(s + c, n - c, p + 1, m - 1); }
+  if (p[0] == '\\' && m >= 2) return s[0] == p[1] && like_match(s + 1, n - 1, p + 2, m - 2);
+  return s[0] == p[0] && like_match(s + 1, n - 1, p + 1, m - 1);
+}
+
 static int eval_node(const qhip_expr* ex, int n_exprs, int k, const qo_col* cols, int ncols, int64_t n, qo_col* out) {
   if (k < 0 || k >= n_exprs) QO_FAIL(QHIP_INVALID_ARGUMENT, "expression index out of range");
   const qhip_expr* e = &ex[k];
@@ -537,6 +602,39 @@ static int eval_node(const qhip_expr* ex, int n_exprs, int k, const qo_col* cols
         }
       }
       qo_col_free(&c);
+      return rc;
+    }
+    case QHIP_EXPR_IF: {
+      /* case.rs:36-46: every WHEN, THEN and the accumulated ELSE are evaluated over the whole batch, then zipped */
+      qo_col c, t, f;
+      int rc = eval_node(ex, n_exprs, e->third, cols, ncols, n, &f);
+      if (rc) return rc;
+      rc = eval_node(ex, n_exprs, e->left, cols, ncols, n, &c);
+      if (rc) { qo_col_free(&f); return rc; }
+      rc = eval_node(ex, n_exprs, e->right, cols, ncols, n, &t);
+      if (rc) { qo_col_free(&f); qo_col_free(&c); return rc; }
+      rc = eval_zip(&c, &t, &f, n, out);
+      qo_col_free(&c); qo_col_free(&t); qo_col_free(&f);
+      return rc;
+    }
+    case QHIP_EXPR_LIKE: {
+      qo_col x, p;
+      int rc = eval_node(ex, n_exprs, e->left, cols, ncols, n, &x);
+      if (rc) return rc;
+      rc = eval_node(ex, n_exprs, e->right, cols, ncols, n, &p);
+      if (rc) { qo_col_free(&x); return rc; }
+      if (x.type.id != QHIP_UTF8 || p.type.id != QHIP_UTF8) { qo_col_free(&x); qo_col_free(&p); QO_FAIL(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid string operation: LIKE on non-Utf8 operands"); }
+      qhip_dtype bt = {QHIP_BOOL, 0, 0};
+      rc = col_alloc(out, bt, n, x.valid != NULL || p.valid != NULL);
+      if (!rc)
+        for (int64_t i = 0; i < n; ++i) {
+          const int ok = (!x.valid || x.valid[i]) && (!p.valid || p.valid[i]);
+          if (out->valid) out->valid[i] = (uint8_t)ok;
+          if (!ok) continue;
+          const int m = like_match(x.data + x.offsets[i], x.offsets[i + 1] - x.offsets[i], p.data + p.offsets[i], p.offsets[i + 1] - p.offsets[i]);
+          ((uint8_t*)out->values)[i] = (uint8_t)(e->op ? !m : m);
+        }
+      qo_col_free(&x); qo_col_free(&p);
       return rc;
     }
   }

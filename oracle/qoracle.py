@@ -532,6 +532,13 @@ def execute(node) -> List[pa.RecordBatch]:
         return [_aggregate(batch, [0, batch.num_rows], node.group_exprs, node.aggregate_exprs, node.schema())]
     if isinstance(node, P.Filter):
         return [filter_batch(b, node.predicate) for b in execute(node.input)]       # filter.rs:29-43
+    if isinstance(node, P.Projection):                                              # projection.rs:27-46
+        out = []
+        for b in execute(node.input):
+            cols = [evaluate(e, b) for e in node.exprs]
+            schema = node.schema() if node.schema() is not None else pa.schema([pa.field(f"c{k}", c.type) for k, c in enumerate(cols)])
+            out.append(pa.RecordBatch.from_arrays(cols, schema=pa.schema([pa.field(f.name, c.type, True) for f, c in zip(schema, cols)])))
+        return out
     if isinstance(node, P.Sort):
         return [_sort(node)]                                                        # sort.rs:81: always one batch
     if isinstance(node, P.Limit):

@@ -8,10 +8,10 @@ ROCm runtime (/opt/rocm/lib); a later ``import torch`` then shares that runtime 
 from ._ffi import (ArrowError, Context, DeviceTable, HipError, InternalError, QuriousError, UnsupportedError,  # noqa: F401
                    get_context, load_library)
 from .datatypes import JoinSide, JoinType, Operator, ScalarValue  # noqa: F401
-from .expr import (AvgAggregateExpr, BinaryExpr, CastExpr, Column, CountAggregateExpr, IsNotNull, IsNull,  # noqa: F401
-                   Literal, MaxAggregateExpr, MinAggregateExpr, Negative, PhysicalExpr, SumAggregateExpr, avg_return_type)
+from .expr import (AvgAggregateExpr, BinaryExpr, CaseExpr, CastExpr, Column, CountAggregateExpr, IsNotNull, IsNull,  # noqa: F401
+                   Like, Literal, MaxAggregateExpr, MinAggregateExpr, Negative, PhysicalExpr, SumAggregateExpr, avg_return_type)
 from .planner import DefaultQueryPlanner  # noqa: F401
 from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NoGroupingAggregate,  # noqa: F401
-                   PhysicalPlan, PhysicalSortExpr, Scan, Sort, SortOptions, build_join_schema)
+                   PhysicalPlan, PhysicalSortExpr, Projection, Scan, Sort, SortOptions, build_join_schema)
 
 __version__ = "0.1.0"

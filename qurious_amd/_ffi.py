@@ -60,7 +60,7 @@ class qhip_dtype(C.Structure):
 class qhip_expr(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("op", C.c_int32), ("column", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
-        ("dtype", qhip_dtype), ("lit_is_null", C.c_int32),
+        ("third", C.c_int32), ("dtype", qhip_dtype), ("lit_is_null", C.c_int32),
         ("lit_lo", C.c_uint64), ("lit_hi", C.c_int64), ("lit_f64", C.c_double),
         ("lit_str", C.c_char_p), ("lit_len", C.c_int64),
     ]
@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
                                                       P(C.c_char_p), P(vp)]),
             "qhip_hash_join_execute": (C.c_int, [vp, vp, vp, i32, P(qhip_expr), i32, P(qhip_expr), i32, P(i32), P(i32), i32,
                                                  P(qhip_expr), i32, i32, P(i32), P(i32), i32, i32, i32, P(vp)]),
+            "qhip_projection_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, P(C.c_char_p), P(vp)]),
             "qhip_sort_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), P(i32), P(i32), i32, i64, P(vp)]),
             "qhip_limit_execute": (C.c_int, [vp, vp, i64, i64, P(vp)]),
             "qhip_partition_by_key": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(vp)]),

@@ -109,6 +109,15 @@ int ExprGen::lit_slot(const ENode& n) {
   return (int)bind.lit_lo.size() - 1;
 }
 
+int ExprGen::str_slot(const std::string& bytes) {
+  if (bind.lit_lo.size() >= 24) fail(QHIP_UNSUPPORTED, "more than 24 literals in one kernel");
+  bind.lit_lo.push_back(0);
+  bind.lit_hi.push_back(0);
+  bind.strlits += bytes;
+  bind.stroff.push_back((int)bind.strlits.size());
+  return (int)bind.lit_lo.size() - 1;
+}
+
 void ExprGen::emit(int k, std::string& out) {
   if (done_[(size_t)k]) return;
   const ENode& n = es_.at(k);
@@ -351,6 +360,33 @@ void ExprGen::emit(int k, std::string& out) {
     case QHIP_EXPR_IS_NOT_NULL: {
       emit(n.left, out);
       o << "    const bool " << v << " = " << (n.kind == QHIP_EXPR_IS_NULL ? "!" : "") << "(" << ok(n.left) << ");\n";
+      break;
+    }
+    case QHIP_EXPR_IF: {
+      // arrow zip(mask, truthy, falsy) (case.rs:44): a NULL or false mask selects the falsy side; both sides are evaluated
+      // for every row (like the reference's full-array evaluation, so their error flags are raised regardless of the mask)
+      emit(n.left, out); emit(n.right, out); emit(n.third, out);
+      const std::string sel = "s" + K;
+      o << "    const bool " << sel << " = " << ok(n.left) << " && " << val(n.left) << ";\n";
+      if (n.nullable) o << "    const bool " << nn << " = " << sel << " ? " << ok(n.right) << " : " << ok(n.third) << ";\n";
+      if (n.type.id == QHIP_UTF8) {
+        o << "    const u8* p" << K << " = " << sel << " ? " << ptr(n.right) << " : " << ptr(n.third) << ";\n";
+        o << "    const int l" << K << " = " << sel << " ? " << len(n.right) << " : " << len(n.third) << ";\n";
+      } else {
+        o << "    const " << ctype(n.type) << " " << v << " = " << sel << " ? " << val(n.right) << " : " << val(n.third) << ";\n";
+      }
+      break;
+    }
+    case QHIP_EXPR_LIKE: {
+      emit(n.left, out);
+      if (n.lit_null) {
+        o << "    const bool " << v << " = false;\n    const bool " << nn << " = false;\n";
+        break;
+      }
+      const int s = str_slot(n.s);
+      if (n.nullable) o << "    const bool " << nn << " = " << ok(n.left) << ";\n";
+      o << "    const bool " << v << " = " << (n.nullable ? nn + " && " : std::string("")) << (n.op ? "!" : "") << "qh_like(" << ptr(n.left) << ", "
+        << len(n.left) << ", a.strlit + a.stroff[" << s << "], a.stroff[" << s + 1 << "] - a.stroff[" << s << "]);\n";
       break;
     }
     case QHIP_EXPR_NEGATIVE: {
@@ -752,6 +788,43 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
          "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
   out.source = s.str();
   out.kernel_name = probe_kernel ? "qk_join_probe" : "qk_eval_keys";
+  out.bind = g.bind;
+}
+
+// ---------------------------------------------------------------- projection
+void plan_projection(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, ProjectionPlan& out) {
+  out = ProjectionPlan();
+  if (n > 24) fail(QHIP_UNSUPPORTED, "more than 24 computed projection expressions");
+  ExprGen g(es, input);
+  std::ostringstream body;
+  for (int k = 0; k < n; ++k) {
+    const ENode& nd = es.at(roots[k]);
+    ProjOutDesc od;
+    od.root = roots[k]; od.type = nd.type; od.nullable = nd.nullable;
+    std::string code;
+    g.emit(od.root, code);
+    body << code;
+    const std::string okx = g.ok(od.root);
+    if (nd.type.id == QHIP_UTF8 || nd.type.id == QHIP_NULL)
+      fail(QHIP_UNSUPPORTED, "projection of a computed " + dtype_name(nd.type) + " expression is not accelerated");
+    if (nd.type.id == QHIP_BOOL) {
+      body << "    { const u64 m = qh_ballot(inb && " << (od.nullable ? okx + " && " : std::string("")) << g.val(od.root) << "); if (lane == 0) ((u64*)o.v[" << k
+           << "])[j] = m; }\n";
+    } else {
+      const std::string T = ExprGen::ctype(nd.type);
+      body << "    if (inb) ((" << T << "*)o.v[" << k << "])[row] = " << (od.nullable ? okx + " ? " : std::string("")) << g.val(od.root)
+           << (od.nullable ? " : (" + T + ")0" : std::string("")) << ";\n";
+    }
+    if (od.nullable) body << "    { const u64 m = qh_ballot(inb && " << okx << "); if (lane == 0) o.n[" << k << "][j] = m; }\n";
+    out.outs.push_back(od);
+  }
+  std::ostringstream s;
+  s << "struct P {\n";
+  s << "  __device__ static __forceinline__ void row(const KArgs& a, const ProjOut& o, const i64 i, const i64 row, const bool inb, const i64 j, "
+       "const int lane, u32& err) {\n" << body.str() << "  }\n};\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_project(KArgs a, ProjOut o, u32* status) { qh_project_body<P>(a, o, status); }\n";
+  out.source = s.str();
+  out.kernel_name = "qk_project";
   out.bind = g.bind;
 }
 

@@ -42,6 +42,7 @@ class ExprGen {
  private:
   int col_slot(int table_col);
   int lit_slot(const ENode& n);
+  int str_slot(const std::string& bytes);   // a literal slot holding only string bytes (LIKE patterns)
   const ExprSet& es_;
   const std::vector<InputCol>& in_;
   std::vector<bool> done_;
@@ -101,6 +102,15 @@ struct KeysPlan {
 // probe_kernel: emit qk_join_probe (fused filter + key + lookup + ordered pair emit, qh_join_probe_body) instead of qk_eval_keys
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
                bool probe_kernel = false);
+
+// ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
+struct ProjOutDesc { int root; DType type; bool nullable; };
+struct ProjectionPlan {
+  std::vector<ProjOutDesc> outs;     // the computed outputs, in kernel slot order
+  KernelBindings bind; std::string source; std::string kernel_name;
+};
+// roots: the expressions to compute (plain columns are shared by the operator and never get here)
+void plan_projection(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, ProjectionPlan& out);
 
 // ---------------------------------------------------------------- sort keys (physical/plan/sort.rs:48-82)
 // Every sort key becomes an ORDER-PRESERVING unsigned image (ascending unsigned order of the image = ascending order of

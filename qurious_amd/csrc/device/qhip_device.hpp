@@ -96,6 +96,25 @@ __device__ __forceinline__ int qh_strcmp(const u8* a, int la, const u8* b, int l
   for (int k = 0; k < n; ++k) { int d = (int)a[k] - (int)b[k]; if (d) return d; }
   return la - lb;
 }
+// SQL LIKE (like.rs:28-43 -> arrow `like`): pat holds literal bytes, 0xFF = % (any sequence of characters), 0xFE = _ (one
+// character, i.e. one UTF-8 code point). Iterative wildcard match with backtracking to the last %.
+__device__ __forceinline__ int qh_next_char(const u8* s, int i, int n) {
+  ++i;
+  while (i < n && (s[i] & 0xC0) == 0x80) ++i;
+  return i;
+}
+__device__ __forceinline__ bool qh_like(const u8* s, int n, const u8* pat, int m) {
+  int i = 0, p = 0, star = -1, mark = 0;
+  while (i < n) {
+    if (p < m && pat[p] == 0xFE) { i = qh_next_char(s, i, n); ++p; }
+    else if (p < m && pat[p] == 0xFF) { star = p; mark = i; ++p; }
+    else if (p < m && pat[p] == s[i]) { ++i; ++p; }
+    else if (star >= 0) { p = star + 1; mark = qh_next_char(s, mark, n); i = mark; }
+    else return false;
+  }
+  while (p < m && pat[p] == 0xFF) ++p;
+  return p == m;
+}
 __device__ __forceinline__ bool qh_streq(const u8* a, int la, const u8* b, int lb) {
   if (la != lb) return false;
   for (int k = 0; k < la; ++k) if (a[k] != b[k]) return false;
@@ -729,6 +748,30 @@ __device__ __forceinline__ void qh_sort_keys_body(const KArgs& a, u64* img, u64*
       const u64 m = qh_ballot(inb && ((valid >> k) & 1u));
       if (lane == 0) keyvalid[(size_t)k * nwords + j] = m;
     }
+  }
+  qh_report(status, err);
+}
+
+// ------------------------------------------------------------------ expressions -> output columns (physical/plan/projection.rs:27-46)
+struct ProjOut {
+  void* v[QH_MAXC];   // per computed expression: values (fixed width) or value bits (Boolean), Arrow layout
+  u64* n[QH_MAXC];    // validity words of the nullable ones
+};
+// P::row evaluates every expression for row `i` (clamped to the table for the lanes beyond its end, `inb` false there)
+// and stores values at `row`, bit-packed outputs at word `j` through wavefront ballots.
+template <class P>
+__device__ __forceinline__ void qh_project_body(const KArgs& a, const ProjOut& o, u32* status) {
+  const i64 nwords = (a.nrows + 63) / 64;
+  const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  u32 err = 0;
+  for (i64 j = wave_global; j < nwords; j += nwaves) {
+    const i64 row = j * 64 + lane;
+    const bool inb = row < a.nrows;
+    u32 e = 0;
+    P::row(a, o, inb ? row : a.nrows - 1, row, inb, j, lane, e);
+    err |= inb ? e : 0u;
   }
   qh_report(status, err);
 }

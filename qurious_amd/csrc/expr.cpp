@@ -167,6 +167,18 @@ void fold_literal_cast(const ENode& src, const DType& to, ENode& out) {
   fail(QHIP_UNSUPPORTED, "literal cast " + dtype_name(from) + " -> " + dtype_name(to));
 }
 
+std::string canonical_like_pattern(const std::string& p) {
+  std::string out;
+  for (size_t k = 0; k < p.size(); ++k) {
+    const unsigned char c = (unsigned char)p[k];
+    if (c == '\\' && k + 1 < p.size()) out.push_back(p[++k]);   // escaped character stands for itself
+    else if (c == '%') out.push_back((char)0xFF);
+    else if (c == '_') out.push_back((char)0xFE);
+    else out.push_back((char)c);
+  }
+  return out;
+}
+
 static bool device_cast_supported(const DType& from, const DType& to) {
   if (from == to) return true;
   auto numeric = [](const DType& t) { return is_intlike(t) || dtype_is_float(t) || t.id == QHIP_DECIMAL128; };
@@ -186,7 +198,7 @@ void ExprSet::build(const qhip_expr* ex, int n, const std::vector<InputCol>& inp
     state[(size_t)k] = 1;
     const qhip_expr& e = ex[k];
     ENode nd;
-    nd.kind = e.kind; nd.op = e.op; nd.column = e.column; nd.left = e.left; nd.right = e.right;
+    nd.kind = e.kind; nd.op = e.op; nd.column = e.column; nd.left = e.left; nd.right = e.right; nd.third = e.third;
     switch (e.kind) {
       case QHIP_EXPR_COLUMN: {
         if (e.column < 0 || e.column >= (int)input.size())
@@ -283,6 +295,27 @@ void ExprSet::build(const qhip_expr* ex, int n, const std::vector<InputCol>& inp
           fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid arithmetic operation: !" + dtype_name(ch.type));
         nd.type = ch.type; nd.nullable = ch.nullable;
         nd.canon = "neg(" + ch.canon + ")";
+        break;
+      }
+      case QHIP_EXPR_IF: {
+        visit(e.left); visit(e.right); visit(e.third);
+        const ENode &c = nodes[(size_t)e.left], &t = nodes[(size_t)e.right], &f = nodes[(size_t)e.third];
+        if (c.type.id != QHIP_BOOL) fail(QHIP_INVALID_ARGUMENT, "Internal error: CASE WHEN must be boolean");
+        if (t.type != f.type)   // arrow zip (case.rs:44)
+          fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: arguments need to have the same data type: " + dtype_name(t.type) + " vs " + dtype_name(f.type));
+        nd.type = t.type; nd.nullable = t.nullable || f.nullable;
+        nd.canon = "if(" + c.canon + "," + t.canon + "," + f.canon + ")";
+        break;
+      }
+      case QHIP_EXPR_LIKE: {
+        visit(e.left); visit(e.right);
+        const ENode &x = nodes[(size_t)e.left], &pat = nodes[(size_t)e.right];
+        if (x.type.id != QHIP_UTF8 || pat.type.id != QHIP_UTF8)
+          fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid string operation: " + dtype_name(x.type) + " LIKE " + dtype_name(pat.type));
+        if (pat.kind != QHIP_EXPR_LITERAL) fail(QHIP_UNSUPPORTED, "LIKE with a non-literal pattern is not accelerated");
+        nd.type = DType(QHIP_BOOL); nd.nullable = x.nullable || pat.lit_null; nd.lit_null = pat.lit_null;
+        nd.s = canonical_like_pattern(pat.s);
+        nd.canon = std::string(e.op ? "nlike(" : "like(") + x.canon + "," + pat.canon + ")";
         break;
       }
       default:

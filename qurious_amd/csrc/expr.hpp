@@ -9,7 +9,7 @@
 namespace qhip {
 
 struct ENode {
-  int kind = 0, op = 0, column = -1, left = -1, right = -1;
+  int kind = 0, op = 0, column = -1, left = -1, right = -1, third = -1;
   DType type;
   bool nullable = false;   // can evaluate to NULL for some row
   // literal payload
@@ -40,5 +40,7 @@ struct ExprSet {
 void fold_literal_cast(const ENode& src, const DType& to, ENode& out);
 int32_t parse_date32(const std::string& s);   // "YYYY-MM-DD" -> days since epoch; throws QHIP_EXEC_ERROR
 i128 pow10_i128(int e);
+// LIKE pattern -> matcher tokens: literal bytes, 0xFF for %, 0xFE for _ (neither byte occurs in UTF-8); `\\x` -> x
+std::string canonical_like_pattern(const std::string& pattern);
 
 }  // namespace qhip

@@ -35,6 +35,12 @@ struct HAggLaunch {
 };
 static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
 
+struct HProjOut {
+  void* v[kMaxCols];
+  uint64_t* n[kMaxCols];
+};
+static_assert(sizeof(HProjOut) == 2 * 8 * 24, "ProjOut layout");
+
 struct HProbeLaunch {
   const uint64_t* table;
   const uint32_t* bloom;

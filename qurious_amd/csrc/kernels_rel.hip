@@ -377,6 +377,22 @@ __global__ __launch_bounds__(QH_BLOCK) void k_sort_utf8_chunk(const int* offsets
   }
 }
 
+// number of set bits among the first n bits of `words` (one atomic per workgroup)
+__global__ __launch_bounds__(QH_BLOCK) void k_count_bits(const u64* words, u64 n, u32* out) {
+  __shared__ u32 part[QH_BLOCK / 64];
+  const u64 nwords = (n + 63) / 64;
+  u32 c = 0;
+  for (u64 j = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; j < nwords; j += (u64)gridDim.x * QH_BLOCK) {
+    u64 w = words[j];
+    if (j == nwords - 1 && (n & 63)) w &= (1ULL << (n & 63)) - 1;
+    c += (u32)__popcll(w);
+  }
+  c = (u32)qh_wave_sum_u64(c);
+  if (qh_lane() == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < QH_BLOCK / 64; ++w) t += part[w]; if (t) atomicAdd(out, t); }
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -581,6 +597,9 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));
+}
+void launch_count_bits(const uint64_t* words, uint64_t nbits, uint32_t* out, hipStream_t s) {
+  if (nbits) hipLaunchKernelGGL(k_count_bits, dim3(grid_for((nbits + 63) / 64, QH_BLOCK, 256)), dim3(QH_BLOCK), 0, s, (const u64*)words, (u64)nbits, (u32*)out);
 }
 void launch_sort_gather_img(const uint64_t* img, const uint32_t* idx, uint64_t n, uint64_t flip, uint64_t* out, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_sort_gather_img, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)img, (const u32*)idx, (u64)n, (u64)flip, (u64*)out);

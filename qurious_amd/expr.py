@@ -12,7 +12,7 @@ from . import _ffi
 from .datatypes import Operator, ScalarValue, to_qhip_dtype
 
 # qhip_expr_kind
-K_COLUMN, K_LITERAL, K_BINARY, K_CAST, K_IS_NULL, K_IS_NOT_NULL, K_NEGATIVE = range(7)
+K_COLUMN, K_LITERAL, K_BINARY, K_CAST, K_IS_NULL, K_IS_NOT_NULL, K_NEGATIVE, K_IF, K_LIKE = range(9)
 # qhip_agg_kind
 AGG_SUM, AGG_AVG, AGG_COUNT, AGG_MIN, AGG_MAX = range(5)
 
@@ -122,6 +122,35 @@ class Negative(PhysicalExpr):
         return out.add(kind=K_NEGATIVE, left=self.expr._lower(out))
 
 
+class CaseExpr(PhysicalExpr):
+    """physical/expr/case.rs:13-48: searched CASE as nested zip(mask, truthy, falsy), folded from the ELSE branch up"""
+
+    def __init__(self, when_then: Sequence, else_expr: PhysicalExpr):
+        self.when_then, self.else_expr = [(w, t) for w, t in when_then], else_expr
+
+    def _lower(self, out):
+        acc = self.else_expr._lower(out)
+        for when, then in reversed(self.when_then):
+            acc = out.add(kind=K_IF, left=when._lower(out), right=then._lower(out), third=acc)
+        return acc
+
+    def __str__(self):
+        return "CASE" + "".join(f" WHEN {w} THEN {t}" for w, t in self.when_then) + f" ELSE {self.else_expr} END"
+
+
+class Like(PhysicalExpr):
+    """physical/expr/like.rs:14-43: arrow `like` / `nlike` (% any sequence, _ one character, backslash escapes)"""
+
+    def __init__(self, negated: bool, expr: PhysicalExpr, pattern: PhysicalExpr):
+        self.negated, self.expr, self.pattern = bool(negated), expr, pattern
+
+    def _lower(self, out):
+        return out.add(kind=K_LIKE, op=int(self.negated), left=self.expr._lower(out), right=self.pattern._lower(out))
+
+    def __str__(self):
+        return f"{self.expr} {'NOT LIKE' if self.negated else 'LIKE'} {self.pattern}"
+
+
 class ExprArray:
     """Flat qhip_expr array under construction."""
 
@@ -137,6 +166,7 @@ class ExprArray:
     def add(self, **kw) -> int:
         e = _ffi.qhip_expr()
         e.kind, e.op, e.column, e.left, e.right = kw.get("kind", 0), kw.get("op", 0), kw.get("column", -1), kw.get("left", -1), kw.get("right", -1)
+        e.third = kw.get("third", -1)
         if "dtype" in kw:
             e.dtype = kw["dtype"]
         e.lit_is_null = kw.get("lit_is_null", 0)

@@ -225,6 +225,35 @@ class NoGroupingAggregate(HashAggregate):
         return None   # no_grouping.rs:63-65
 
 
+class Projection(PhysicalPlan):
+    """physical/plan/projection.rs:10-51: one output column per expression, per input batch"""
+
+    def __init__(self, schema: pa.Schema, input: PhysicalPlan, exprs: Sequence[PhysicalExpr]):
+        self._schema, self.input, self.exprs = schema, input, list(exprs)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def execute_device(self) -> DeviceTable:
+        table = self.input.execute_device()
+        ctx = table.ctx
+        cached = getattr(self, "_lowered", None)
+        if cached is None:
+            ea = ExprArray()
+            roots = [ea.lower(e) for e in self.exprs]
+            arr, n = ea.c_array()
+            names = [f.name for f in self._schema] if self._schema is not None else [f"c{k}" for k in range(len(roots))]
+            cached = (arr, n, int32_array(roots), len(roots), (C.c_char_p * max(1, len(names)))(*[s.encode() for s in names]), ea)
+            self._lowered = cached
+        arr, n, roots, n_out, cnames, _keep = cached
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_projection_execute(ctx.handle, table.handle, arr, n, roots, n_out, cnames, C.byref(out)))
+        return DeviceTable(ctx, out)
+
+    def children(self):
+        return [self.input]
+
+
 class SortOptions:
     """arrow::compute::SortOptions { descending, nulls_first } (arrow-rs default: ascending, nulls first)"""
 
