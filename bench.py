@@ -61,7 +61,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     joins repartitioned by key with the RCCL exchange (qurious_amd/exchange.py) when world > 1."""
     from qurious_amd import exchange
     t0 = time.time()
-    c, o, l = synth.q3_tables(args.sf, rank, world)
+    c, o, l = synth.q3_tables_skewed(args.sf, args.skew, rank, world) if args.skew > 0 else synth.q3_tables(args.sf, rank, world)
     tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
             q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
     rows = [sum(b.num_rows for b in t.data) for t in tabs]
@@ -88,6 +88,17 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         rows_all = tot.tolist()
     else:
         rows_all = rows + [out.num_rows]
+    table_stats = None
+    if args.skew > 0 or os.environ.get("QHIP_AGG_STATS"):
+        # BASELINE configs[4]: LDS hash-table occupancy of the final aggregate (one extra, untimed, instrumented execution)
+        os.environ["QHIP_AGG_STATS"] = "1"
+        plan.execute_device()
+        st = ctx.last_stats()
+        os.environ.pop("QHIP_AGG_STATS", None)
+        table_stats = {"lds_table_slots_per_workgroup": st["lds_table_slots"], "lds_occupancy": st["lds_occupancy"],
+                       "lds_spilled": bool(st["lds_spilled"]), "hbm_table_slots": st["table_capacity"], "hbm_table_load": st["hbm_table_load"],
+                       "groups": st["groups"], "workgroups": st["workgroups"]}
+    xgmi = exchange.exchange_stats() if world > 1 else None
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -122,6 +133,12 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
                      "algorithmic_bytes": algo_bytes},
         "cpu_baseline": cpu_baseline, "device": ctx.device_name(),
     }
+    if args.skew > 0:
+        line["config"]["workload"] += f", join keys re-drawn from Zipf(s={args.skew}) (configs[4] shape)"
+    if table_stats:
+        line["aggregate_table"] = table_stats
+    if xgmi:
+        line["exchange"] = xgmi   # bytes this rank sent over xGMI and the time spent in the exchanges, per query
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
@@ -173,6 +190,7 @@ def main():
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
     ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full", "q3"])
     ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of the q3 workload (whole job, sliced over the ranks)")
+    ap.add_argument("--skew", type=float, default=0.0, help="q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
     ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU Q1 / Q3 measurements")

@@ -167,6 +167,12 @@ typedef struct qhip_exec_stats {
   int32_t retries;           /* hash-table growth retries */
   int32_t lds_table_slots;   /* LDS-staged table slots per workgroup */
   char main_kernel_name[64];
+  double lds_occupancy;      /* aggregate: mean fraction of a workgroup's LDS table in use when it is merged into the HBM
+                              * table (BASELINE configs[4] asks for it); collected only when QHIP_AGG_STATS=1 is set in the
+                              * environment (one extra atomic per workgroup), -1 otherwise */
+  double hbm_table_load;     /* groups / table_capacity of the attempt that succeeded */
+  int32_t lds_spilled;       /* 1 = some keys bypassed the LDS table (it was full around their home slot) */
+  int32_t workgroups;        /* grid size of the dominant kernel */
 } qhip_exec_stats;
 
 /* ---------------------------------------------------------------- context */

@@ -250,7 +250,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     L.l_nslots = l_nslots;
     L.status = ctx->status.as<uint32_t>();
     L.replicas = replicas;
-    L.pad = 0;
+    L.collect_stats = env_int("QHIP_AGG_STATS", 0) ? 1u : 0u;
     void* args[] = {&ka, &L};
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     if (N > 0)
@@ -358,6 +358,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.table_capacity = (int64_t)cap * replicas;
     ctx->stats.retries = retries;
     ctx->stats.lds_table_slots = (int32_t)l_nslots;
+    ctx->stats.workgroups = (int32_t)grid;
+    ctx->stats.lds_spilled = status[QS_LDS_SPILL] ? 1 : 0;
+    ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
+    ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)status[QS_LDS_USED] / ((double)grid * l_nslots) : -1.0;
     snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
   };
   const int cell0 = 1 + plan.W;

@@ -350,7 +350,8 @@ struct AggLaunch {
   u32 l_nslots;     // LDS slots per workgroup (power of two, 0 = no LDS level)
   u32* status;      // QS_WORDS words
   u32 replicas;     // workgroup b uses replica b % replicas (few groups: spreads the end-of-kernel merge of ~1000
-  u32 pad;          // workgroups over many cache lines instead of one slot per group; the host merges replicas)
+                    // workgroups over many cache lines instead of one slot per group; the host merges replicas)
+  u32 collect_stats;  // != 0: every workgroup adds its count of occupied LDS slots to status[QS_LDS_USED]
 };
 
 template <class P, class M>
@@ -537,9 +538,11 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   }
   // ---- merge this workgroup's LDS table into the HBM table
   __syncthreads();
+  u32 used = 0;
   for (u32 s = tid; s < L.l_nslots; s += QH_BLOCK) {
     u64* ls = ltable + (size_t)s * P::SLOT_WORDS;
     if (ls[0] == QH_READY) {
+      ++used;
       u64 key[W > 0 ? W : 1];
       u64 h = 0;
 #pragma unroll
@@ -549,6 +552,17 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       if (!gs) atomicOr(&L.status[QS_OVERFLOW], 1u);
       else P::slot_merge(gs, ls);
     }
+  }
+  if (L.collect_stats && L.l_nslots) {
+    // LDS-table occupancy (statistics runs only): one global atomic per workgroup
+    __syncthreads();
+    u32* total = (u32*)ltable;
+    if (tid == 0) *total = 0;
+    __syncthreads();
+    used = (u32)qh_wave_sum_u64(used);
+    if (lane == 0 && used) atomicAdd(total, used);
+    __syncthreads();
+    if (tid == 0 && *total) atomicAdd(&L.status[QS_LDS_USED], *total);
   }
 }
 

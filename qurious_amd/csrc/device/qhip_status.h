@@ -8,6 +8,7 @@ enum {
   QS_CAST_OVERFLOW = 3,  // cast with safe=false overflowed (cast.rs:15-18)
   QS_ARITH_OVERFLOW = 4, // checked arithmetic overflowed (integer MIN / -1)
   QS_LDS_SPILL = 5,      // informational: some keys bypassed the LDS-staged table
+  QS_LDS_USED = 6,       // value, not a flag: occupied LDS-table slots summed over the workgroups (statistics runs only)
   QS_MAXCOUNT = 7,       // value, not a flag: largest number of build rows sharing one join key
   QS_WORDS = 8
 };

@@ -31,7 +31,7 @@ struct HAggLaunch {
   uint32_t l_nslots;
   uint32_t* status;
   uint32_t replicas;
-  uint32_t pad;
+  uint32_t collect_stats;
 };
 static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
 

@@ -28,16 +28,31 @@ def _dist():
     return dist
 
 
+# bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
+_STATS = {"bytes_sent": 0, "bytes_received": 0, "seconds": 0.0, "exchanges": 0}
+
+
+def exchange_stats(reset: bool = True) -> dict:
+    """Totals since the last reset plus the derived GB/s per rank (to compare with 7 links x 153 GB/s of xGMI)."""
+    out = dict(_STATS)
+    out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
+    if reset:
+        _STATS.update(bytes_sent=0, bytes_received=0, seconds=0.0, exchanges=0)
+    return out
+
+
 def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None) -> List["torch.Tensor"]:
     """Variable-size all-to-all of uint8 tensors: send[r] goes to rank r, the result's entry r came from rank r.
     Built from grouped point-to-point sends/receives (``batch_isend_irecv``: one ncclGroup of ncclSend/ncclRecv on RCCL,
     plain pairs on gloo), sizes first. Works for CPU tensors over gloo and GPU tensors over RCCL alike."""
+    import time
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     assert len(send) == world
     dev = send[0].device
+    t_start = time.perf_counter()
     sizes_out = [torch.tensor([s.numel()], dtype=torch.int64, device=dev) for s in send]
     sizes_in = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     ops = []
@@ -65,6 +80,10 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None) -> List["torch.
             w.wait()
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
+    _STATS["bytes_sent"] += sum(int(t.numel()) for r, t in enumerate(send) if r != rank)
+    _STATS["bytes_received"] += sum(int(t.numel()) for r, t in enumerate(recv) if r != rank)
+    _STATS["seconds"] += time.perf_counter() - t_start
+    _STATS["exchanges"] += 1
     return recv
 
 

@@ -50,6 +50,28 @@ def test_q3_order_by_revenue_limit_10(ctx, oracle, golden):
     assert all(len(r[1].split(".")[1]) == 4 for r in ref) and got[0].schema.field(3).type.scale == 4
 
 
+def test_q3_skewed_keys_match_oracle_and_report_table_occupancy(ctx, oracle, monkeypatch):
+    """configs[4] shape: o_custkey / l_orderkey re-drawn from Zipf(1.1) — hot probe keys in both joins, hot groups in
+    the aggregate (the wave-resident hot-key cache and the LDS table both see them). Bit-exact vs the oracle; the
+    instrumented run reports the LDS hash-table occupancy BASELINE.json asks for."""
+    c, o, l = synth.q3_tables_skewed(0.02, 1.1, orders_per_batch=4096)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    plan = queries.q3(*tabs)
+    got = sorted(rows_of(plan.execute()))
+    want = sorted(rows_of(oracle.execute(plan)))
+    assert got == want and len(got) > 50
+    top = queries.q3_top10(*tabs)
+    assert rows_of(top.execute()) == rows_of(oracle.execute(top))
+    monkeypatch.setenv("QHIP_AGG_STATS", "1")
+    assert sorted(rows_of(plan.execute())) == want
+    st = ctx.last_stats()
+    assert st["groups"] == len(want) and st["lds_table_slots"] > 0 and 0.0 < st["lds_occupancy"] <= 1.0 and 0.0 < st["hbm_table_load"] <= 1.0
+    monkeypatch.delenv("QHIP_AGG_STATS")
+    plan.execute()
+    assert ctx.last_stats()["lds_occupancy"] == -1.0
+
+
 def test_q1_order_by_flags(ctx, oracle):
     li = synth.lineitem(200_000, batch_rows=65_536)
     plan = queries.q1_full_ordered(q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, li))
