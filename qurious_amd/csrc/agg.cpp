@@ -284,6 +284,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ++retries;
   }
 
+  const uint32_t lds_used = status[QS_LDS_USED];          // (the status words are reused by the output assembly below)
+  const bool lds_spilled = status[QS_LDS_SPILL] != 0;
   // ---- dense slots -> host (few groups) or kept on the device (many groups)
   DevBuf dense_keep;                                   // [counter | dense slots] when the output is assembled on the device
   const uint32_t dev_threshold = (uint32_t)env_int("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", 4096);
@@ -359,9 +361,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.retries = retries;
     ctx->stats.lds_table_slots = (int32_t)l_nslots;
     ctx->stats.workgroups = (int32_t)grid;
-    ctx->stats.lds_spilled = status[QS_LDS_SPILL] ? 1 : 0;
+    ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
-    ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)status[QS_LDS_USED] / ((double)grid * l_nslots) : -1.0;
+    ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
     snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
   };
   const int cell0 = 1 + plan.W;
