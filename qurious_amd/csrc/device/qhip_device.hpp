@@ -463,10 +463,11 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     }
     // (2) admit new keys while the cache has room and the data keeps showing duplicates inside a wave
     if (cache_on && nc < KC) {
+      int tile_misses = 0;
 #pragma unroll
       for (int r0 = 0; r0 < R; ++r0) {
         u64 act = qh_ballot(pend[r0]);
-        while (act != 0 && cache_on && nc < KC) {
+        while (act != 0 && cache_on && nc < KC && tile_misses < 4) {
           const int leader = __builtin_ctzll(act);
           u64 lk[W > 0 ? W : 1];
 #pragma unroll
@@ -482,9 +483,14 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
             cnt += (u32)__builtin_popcountll(qh_ballot(m));
           }
           if (cnt <= 1) {
-            // nobody shares this key inside the wave: high-cardinality data, caching would only cost compares
+            // Nobody shares this key inside the wave. Uniform high-cardinality data shows nothing but such keys and the
+            // cache is given up after a few tiles; a skewed distribution (Zipf: a long tail AND a few heavy keys) shows
+            // them between its heavy keys, so a wave that has already admitted a key keeps looking 8x longer. At most 4
+            // such misses per tile bound the cost of looking.
             act &= ~(1ULL << leader);
-            if (++singles >= 3) cache_on = false;
+            ++singles;
+            if (singles >= (nc > 0 ? 256 : 32)) cache_on = false;
+            if (++tile_misses >= 4) break;
             continue;
           }
 #pragma unroll
