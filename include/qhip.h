@@ -304,6 +304,21 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
 
+/* ---------------------------------------------------------------- joins without equi-keys */
+/* NestedLoopJoinExec::execute (physical/plan/join/nest_loop_join.rs:79-228): every (left, right) row pair in right-row
+ * major order, kept when the optional JoinFilter (same encoding as qhip_hash_join_execute; filter_root < 0 = none) is
+ * true. Output batches like the reference: [matched] for Inner, [matched, unmatched] for Left / Right / Full (unmatched
+ * left rows first, then unmatched right rows), one batch of left rows for LeftSemi / LeftAnti; an empty right side gives
+ * no batch (Inner / Right), the left rows with a NULL right side (Left / Full / LeftAnti) or one empty batch (LeftSemi).
+ * Inputs whose row-pair count reaches 2^31 return QHIP_UNSUPPORTED. */
+int qhip_nested_loop_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right, int32_t join_type,
+                                  const qhip_expr* filter_exprs, int32_t n_filter_exprs, int32_t filter_root,
+                                  const int32_t* filter_sides, const int32_t* filter_cols, int32_t n_filter_cols,
+                                  qhip_table** out);
+/* CrossJoin::execute (physical/plan/join/cross_join.rs:121-166): for every left batch, right batch and left row one
+ * output batch (that left row next to the right batch). */
+int qhip_cross_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right, qhip_table** out);
+
 /* ---------------------------------------------------------------- projection */
 /* Projection::execute (physical/plan/projection.rs:27-46): one output column per expression, evaluated over every
  * input batch (batch structure kept). A plain Column expression shares the input column's buffers; everything else is

@@ -424,6 +424,62 @@ def _hash_join(node: "P.HashJoinExec") -> List[pa.RecordBatch]:
     return out
 
 
+# ---------------------------------------------------------------- joins without equi-keys
+def _nested_loop_join(node: "P.NestedLoopJoinExec") -> List[pa.RecordBatch]:
+    """NestedLoopJoinExec::execute (nest_loop_join.rs:79-228), control flow and index order as in the reference"""
+    jt = node.join_type
+    lb = _concat(node.left.schema(), execute(node.left))                            # :83-84
+    rb = _concat(node.right.schema(), execute(node.right))
+    nl, nr = lb.num_rows, rb.num_rows
+    build = lambda li, ri: build_batch_from_indices(node.schema(), node.column_indices, lb, rb, np.asarray(li, np.int64), np.asarray(ri, np.int64))  # noqa: E731
+    if nr == 0:                                                                     # :87-121
+        if jt in (JoinType.Inner, JoinType.Right):
+            return []
+        if jt == JoinType.LeftSemi:
+            return [build([], [])]
+        return [build(np.arange(nl), np.full(nl, -1))]                              # Left / Full / LeftAnti: every left row, NULL right
+    # build_join_indices (:232-260): for every right row, all left rows, filtered by the JoinFilter
+    li = np.tile(np.arange(nl, dtype=np.int64), nr)
+    ri = np.repeat(np.arange(nr, dtype=np.int64), nl)
+    if node.filter is not None and len(li):                                         # join_filter_indices (:262-289)
+        f = node.filter
+        inter = build_batch_from_indices(f.schema, f.column_indices, lb, rb, li, ri)
+        mask = evaluate(f.expr, inter)
+        keep = np.array([bool(v) for v in mask.fill_null(False).to_pylist()], dtype=bool)
+        li, ri = li[keep], ri[keep]
+    if jt in (JoinType.LeftSemi, JoinType.LeftAnti):                                # :141-170
+        visited = np.zeros(nl, dtype=bool)
+        visited[li] = True
+        keep = np.nonzero(visited if jt == JoinType.LeftSemi else ~visited)[0]
+        return [build(keep, np.full(len(keep), -1))]
+    matched = build(li, ri)
+    if jt == JoinType.Inner:                                                        # :172-174
+        return [matched]
+    l_un, r_un = np.zeros(0, np.int64), np.zeros(0, np.int64)
+    if jt in (JoinType.Left, JoinType.Full):                                        # :193-204
+        v = np.zeros(nl, dtype=bool)
+        v[li] = True
+        l_un = np.nonzero(~v)[0].astype(np.int64)
+    if jt in (JoinType.Right, JoinType.Full):                                       # :206-217
+        v = np.zeros(nr, dtype=bool)
+        v[ri] = True
+        r_un = np.nonzero(~v)[0].astype(np.int64)
+    unmatched = build(np.concatenate([l_un, np.full(len(r_un), -1, np.int64)]), np.concatenate([np.full(len(l_un), -1, np.int64), r_un]))
+    return [matched, unmatched]                                                     # :219-228
+
+
+def _cross_join(node: "P.CrossJoin") -> List[pa.RecordBatch]:
+    """CrossJoin::execute (cross_join.rs:121-166): per left batch, per right batch, per left row one output batch"""
+    out = []
+    right = execute(node.right)
+    for lb in execute(node.left):
+        for rb in right:
+            for row in range(lb.num_rows):
+                cols = [lb.column(k).take(pa.array(np.full(rb.num_rows, row, dtype=np.int64))) for k in range(lb.num_columns)] + list(rb.columns)
+                out.append(pa.RecordBatch.from_arrays(cols, schema=pa.schema([pa.field(f.name, c.type, True) for f, c in zip(node.schema(), cols)])))
+    return out
+
+
 # ---------------------------------------------------------------- sort / limit (SURVEY §8f rank 1)
 def _dense_rank(arr: pa.Array) -> np.ndarray:
     """Rank of every non-null value in arrow-ord's sort order (arrow 53 `sort`/`lexsort_to_indices`: integers, dates and
@@ -517,6 +573,10 @@ def execute(node) -> List[pa.RecordBatch]:
         return out
     if isinstance(node, P.HashJoinExec):
         return _hash_join(node)
+    if isinstance(node, P.NestedLoopJoinExec):
+        return _nested_loop_join(node)
+    if isinstance(node, P.CrossJoin):
+        return _cross_join(node)
     if isinstance(node, P.NoGroupingAggregate):
         batches = execute(node.input)                                               # no_grouping.rs:31
         offs = [0]

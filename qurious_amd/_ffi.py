@@ -137,6 +137,8 @@ def load_library() -> C.CDLL:
                                                       P(C.c_char_p), P(vp)]),
             "qhip_hash_join_execute": (C.c_int, [vp, vp, vp, i32, P(qhip_expr), i32, P(qhip_expr), i32, P(i32), P(i32), i32,
                                                  P(qhip_expr), i32, i32, P(i32), P(i32), i32, i32, i32, P(vp)]),
+            "qhip_nested_loop_join_execute": (C.c_int, [vp, vp, vp, i32, P(qhip_expr), i32, i32, P(i32), P(i32), i32, P(vp)]),
+            "qhip_cross_join_execute": (C.c_int, [vp, vp, vp, P(vp)]),
             "qhip_projection_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, P(C.c_char_p), P(vp)]),
             "qhip_sort_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), P(i32), P(i32), i32, i64, P(vp)]),
             "qhip_limit_execute": (C.c_int, [vp, vp, i64, i64, P(vp)]),

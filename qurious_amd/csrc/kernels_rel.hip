@@ -393,6 +393,14 @@ __global__ __launch_bounds__(QH_BLOCK) void k_count_bits(const u64* words, u64 n
   if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < QH_BLOCK / 64; ++w) t += part[w]; if (t) atomicAdd(out, t); }
 }
 
+// pair k of a nested-loop / cross join block: minor[k] = minor0 + k % n_minor, major[k] = major0 + k / n_minor
+__global__ __launch_bounds__(QH_BLOCK) void k_pair_indices(u32* minor, u32* major, u64 n, u32 n_minor, u32 minor0, u32 major0) {
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < n; k += (u64)gridDim.x * QH_BLOCK) {
+    minor[k] = minor0 + (u32)(k % n_minor);
+    major[k] = major0 + (u32)(k / n_minor);
+  }
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -597,6 +605,9 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));
+}
+void launch_pair_indices(uint32_t* minor, uint32_t* major, uint64_t n, uint32_t n_minor, uint32_t minor0, uint32_t major0, int, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_pair_indices, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)minor, (u32*)major, (u64)n, n_minor, minor0, major0);
 }
 void launch_count_bits(const uint64_t* words, uint64_t nbits, uint32_t* out, hipStream_t s) {
   if (nbits) hipLaunchKernelGGL(k_count_bits, dim3(grid_for((nbits + 63) / 64, QH_BLOCK, 256)), dim3(QH_BLOCK), 0, s, (const u64*)words, (u64)nbits, (u32*)out);

@@ -362,6 +362,75 @@ def build_join_schema(left: pa.Schema, right: pa.Schema, join_type: JoinType) ->
     return pa.schema(fields, metadata=meta), idx
 
 
+class NestedLoopJoinExec(PhysicalPlan):
+    """physical/plan/join/nest_loop_join.rs:42-228 — the reference's join for ON clauses without equi-keys"""
+
+    def __init__(self, left, right, join_type, filter, schema, column_indices):
+        self.left, self.right, self.join_type, self.filter = left, right, JoinType(join_type), filter
+        self._schema, self.column_indices = schema, column_indices
+
+    @staticmethod
+    def try_new(left: PhysicalPlan, right: PhysicalPlan, join_type: JoinType, filter: Optional["JoinFilter"] = None) -> "NestedLoopJoinExec":
+        schema, ci = build_join_schema(left.schema(), right.schema(), JoinType(join_type))
+        return NestedLoopJoinExec(left, right, join_type, filter, schema, ci)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def children(self):
+        return [self.left, self.right]
+
+    def execute_device(self) -> DeviceTable:
+        lt, rt = self.left.execute_device(), self.right.execute_device()
+        ctx = lt.ctx
+        cached = getattr(self, "_lowered", None)
+        if cached is None:
+            fe = ExprArray()
+            froot, fsides, fcols = -1, [], []
+            if self.filter is not None:
+                froot = fe.lower(self.filter.expr)
+                fsides = [int(s) for _, s in self.filter.column_indices]
+                fcols = [int(c) for c, _ in self.filter.column_indices]
+            fa, fn = fe.c_array()
+            cached = (fa, fn, froot, int32_array(fsides), int32_array(fcols), len(fcols), fe)
+            self._lowered = cached
+        fa, fn, froot, fsides, fcols, n_fcols, _keep = cached
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_nested_loop_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), fa, fn, froot, fsides, fcols,
+                                                        n_fcols, C.byref(out)))
+        return DeviceTable(ctx, out)
+
+
+class CrossJoin(PhysicalPlan):
+    """physical/plan/join/cross_join.rs:56-170 — cartesian product, one output batch per (left row, right batch)"""
+
+    def __init__(self, left: PhysicalPlan, right: PhysicalPlan):
+        self.left, self.right = left, right
+        ls, rs = left.schema(), right.schema()
+        sep, key = "\x1f", FIELD_QUALIFIERS_META_KEY.encode()
+        meta = dict(ls.metadata or {})
+
+        def parts(schema):
+            raw = (schema.metadata or {}).get(key)
+            p = raw.decode().split(sep) if raw is not None else [""] * len(schema)
+            return p if len(p) == len(schema) else [""] * len(schema)
+        meta[key] = sep.join(parts(ls) + parts(rs)).encode()   # cross_join.rs:76-112: qualifiers of both sides, concatenated
+        self._schema = pa.schema(list(ls) + list(rs), metadata=meta)
+
+    def schema(self) -> pa.Schema:
+        return self._schema
+
+    def children(self):
+        return [self.left, self.right]
+
+    def execute_device(self) -> DeviceTable:
+        lt, rt = self.left.execute_device(), self.right.execute_device()
+        ctx = lt.ctx
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_cross_join_execute(ctx.handle, lt.handle, rt.handle, C.byref(out)))
+        return DeviceTable(ctx, out)
+
+
 class HashJoinExec(PhysicalPlan):
     """physical/plan/join/hash_join.rs:110-384 — build = left, probe = right."""
 

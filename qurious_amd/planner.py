@@ -10,7 +10,7 @@ import pyarrow as pa
 from . import _ffi
 from .datatypes import JoinType
 from .expr import AggregateExpr, PhysicalExpr
-from .plan import (Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NoGroupingAggregate, PhysicalPlan,
+from .plan import (CrossJoin, Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NestedLoopJoinExec, NoGroupingAggregate, PhysicalPlan,
                    PhysicalSortExpr, Scan, Sort, SortOptions)
 
 
@@ -32,11 +32,14 @@ class DefaultQueryPlanner:
 
     def physical_plan_join(self, left: PhysicalPlan, right: PhysicalPlan, join_type: JoinType,
                            on: Sequence[Tuple[PhysicalExpr, PhysicalExpr]], filter: Optional[JoinFilter]) -> PhysicalPlan:
-        """planner/mod.rs:265-321: HashJoinExec iff there are equi-join keys; otherwise the reference builds a
-        NestedLoopJoinExec, which is outside the accelerated path (the shim keeps the CPU node)"""
+        """planner/mod.rs:265-321: HashJoinExec iff there are equi-join keys, NestedLoopJoinExec otherwise"""
         if len(on) == 0:
-            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "join without equi-keys: NestedLoopJoinExec stays on the CPU path")
+            return NestedLoopJoinExec.try_new(left, right, join_type, filter)
         return HashJoinExec.try_new(left, right, join_type, on, filter)
+
+    def physical_plan_cross_join(self, left: PhysicalPlan, right: PhysicalPlan) -> PhysicalPlan:
+        """planner/mod.rs:259-263"""
+        return CrossJoin(left, right)
 
     def physical_plan_sort(self, input: PhysicalPlan, exprs: Sequence[Tuple[PhysicalExpr, bool]], limit: Optional[int] = None) -> PhysicalPlan:
         """planner/mod.rs:330-348: every ORDER BY expression (expr, asc) becomes SortOptions{descending: !asc,
