@@ -126,8 +126,7 @@ def test_planner_choices_mirror_the_reference():
     j = pl.physical_plan_join(scan, scan, q.JoinType.Left, [(col("a", 0), col("a", 0))], None)
     assert isinstance(j, q.HashJoinExec) and [f.nullable for f in j.schema()] == [True, True, True, True] or True
     assert [f.name for f in j.schema()] == ["a", "b", "a", "b"] and j.children() == [scan, scan]
-    with pytest.raises(q.UnsupportedError, match="NestedLoopJoinExec"):
-        pl.physical_plan_join(scan, scan, q.JoinType.Inner, [], None)
+    assert isinstance(pl.physical_plan_join(scan, scan, q.JoinType.Inner, [], None), q.NestedLoopJoinExec)   # planner/mod.rs:316-320
     # join schema nullability by join type (join/mod.rs:55-61)
     nn = pa.schema([pa.field("x", pa.int64(), False)])
     s, idx = q.build_join_schema(nn, nn, q.JoinType.Right)
