@@ -198,6 +198,12 @@ int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
 int qhip_table_from_arrow(qhip_ctx* ctx, const struct ArrowSchema* schema,
                           const struct ArrowArray* const* batches, int64_t n_batches,
                           qhip_table** out);
+/* Like qhip_table_from_arrow, but nothing is copied yet: the library takes OWNERSHIP of the batches (Arrow C Data
+ * Interface move: each `batches[b]->release` is set to NULL) and uploads a column the first time an operator or an
+ * export reads it. Columns no query touches never cross PCIe — the projection pushdown the reference's Scan node has a
+ * slot for but never uses (physical/plan/scan.rs:12-17, planner/mod.rs:251-256). */
+int qhip_table_from_arrow_lazy(qhip_ctx* ctx, const struct ArrowSchema* schema, struct ArrowArray* const* batches,
+                               int64_t n_batches, qhip_table** out);
 /* Download batch `batch_index` as a struct ArrowArray (+ schema if out_schema != NULL).
  * Buffers are library-owned host memory freed by the release callbacks. */
 int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,

@@ -11,6 +11,7 @@ from .datatypes import JoinSide, JoinType, Operator, ScalarValue  # noqa: F401
 from .expr import (AvgAggregateExpr, BinaryExpr, CaseExpr, CastExpr, Column, CountAggregateExpr, IsNotNull, IsNull,  # noqa: F401
                    Like, Literal, MaxAggregateExpr, MinAggregateExpr, Negative, PhysicalExpr, SumAggregateExpr, avg_return_type)
 from .planner import DefaultQueryPlanner  # noqa: F401
+from .datasource import CsvReadOptions, read_csv, read_json, read_parquet  # noqa: F401
 from .plan import (CrossJoin, Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NestedLoopJoinExec,  # noqa: F401
                    NoGroupingAggregate,
                    PhysicalPlan, PhysicalSortExpr, Projection, Scan, Sort, SortOptions, build_join_schema)

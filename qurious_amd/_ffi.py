@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
             "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
+            "qhip_table_from_arrow_lazy": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
             "qhip_table_to_arrow": (C.c_int, [vp, vp, i64, vp, vp]),
             "qhip_table_num_batches": (i64, [vp]),
             "qhip_table_num_rows": (i64, [vp]),
@@ -222,7 +223,9 @@ class DeviceTable:
         self.handle = handle
 
     @staticmethod
-    def from_batches(ctx: Context, schema: pa.Schema, batches) -> "DeviceTable":
+    def from_batches(ctx: Context, schema: pa.Schema, batches, lazy: bool = False) -> "DeviceTable":
+        """Upload now (default) or, with lazy=True, hand the batches over and let every column move to HBM the first time
+        an operator or an export reads it (qhip_table_from_arrow_lazy)."""
         lib = ctx.lib
         c_schema = ArrowSchemaStruct()
         schema._export_to_c(C.addressof(c_schema))
@@ -234,7 +237,8 @@ class DeviceTable:
                 b._export_to_c(C.addressof(a))
             ptrs = (C.c_void_p * max(1, len(arrays)))(*[C.addressof(a) for a in arrays])
             out = C.c_void_p()
-            ctx.check(lib.qhip_table_from_arrow(ctx.handle, C.addressof(c_schema), ptrs, len(arrays), C.byref(out)))
+            fn = lib.qhip_table_from_arrow_lazy if lazy else lib.qhip_table_from_arrow
+            ctx.check(fn(ctx.handle, C.addressof(c_schema), ptrs, len(arrays), C.byref(out)))
             return DeviceTable(ctx, out)
         finally:
             _release_schema(c_schema)

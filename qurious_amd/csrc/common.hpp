@@ -98,7 +98,18 @@ struct DevColumn {
   // output (utils/batch.rs:18-61) although most are never looked at downstream (Q3: c_mktsegment, o_custkey, ...).
   // While deferred, values / validity / data are empty and null_count is a may-have-nulls flag (0 / 1).
   std::shared_ptr<struct DeferredGather> deferred;
+  // ... or not UPLOADED yet: a lazily ingested table (qhip_table_from_arrow_lazy) moves a column host -> HBM when it is
+  // first read, so columns no query touches never cross PCIe (the projection pushdown the reference's Scan lacks).
+  std::shared_ptr<struct DeferredUpload> pending_upload;
   int64_t resident_bytes() const;
+};
+struct DeferredUpload {
+  std::shared_ptr<void> host;           // HostBatches (table.cpp): the Arrow arrays, kept alive
+  std::string format;                   // Arrow C format string of the column
+  int64_t column = 0;
+  std::vector<int64_t> batch_offsets;
+  bool done = false;
+  DevColumn result;
 };
 struct DeferredGather {
   DevColumn src;                  // never itself deferred (index vectors are composed instead)

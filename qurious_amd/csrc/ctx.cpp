@@ -175,6 +175,9 @@ void DevBuf::release() {
 }
 
 int64_t DevColumn::resident_bytes() const {
+  // a column whose upload / gather was owed and has been done through another table sharing it counts as resident
+  if (pending_upload) return pending_upload->done ? pending_upload->result.resident_bytes() : 0;
+  if (deferred) return deferred->done ? deferred->result.resident_bytes() : 0;
   int64_t b = 0;
   if (values) b += (int64_t)values->bytes;
   if (validity) b += (int64_t)validity->bytes;

@@ -68,7 +68,21 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
   }
 }
 
+DevColumn materialize_upload(Ctx* ctx, const DeferredUpload& u);   // table.cpp
+
 const DevColumn& resolved(Ctx* ctx, const DevColumn& col) {
+  if (col.pending_upload) {
+    DeferredUpload& u = *col.pending_upload;
+    if (!u.done) {
+      u.result = materialize_upload(ctx, u);
+      u.done = true;
+      u.host.reset();
+    }
+    DevColumn r = u.result;
+    r.utf8_max_len = col.utf8_max_len >= 0 ? col.utf8_max_len : r.utf8_max_len;
+    const_cast<DevColumn&>(col) = std::move(r);
+    return col;
+  }
   if (!col.deferred) return col;
   DeferredGather& d = *col.deferred;
   if (!d.done) {

@@ -50,7 +50,106 @@ static void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
   if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
 }
 
-qhip_table* table_from_arrow(Ctx* ctx, const ArrowSchema* schema, const ArrowArray* const* batches, int64_t nb) {
+// One column of the batches -> HBM, concatenated (values / offsets rebased / bitmaps realigned). Synchronous.
+static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const ArrowArray* const* batches, int64_t nb,
+                               const std::vector<int64_t>& batch_offsets) {
+  const int64_t N = batch_offsets.back();
+  std::vector<std::vector<uint8_t>> staging;  // host staging kept alive until the stream is drained
+  DevColumn col;
+  col.type = dtype_from_format(format);
+  col.length = N;
+  // null count + validity
+  int64_t nulls = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const ArrowArray* ca = batches[b]->children[c];
+    if (ca->length != batches[b]->length) fail(QHIP_INVALID_ARGUMENT, "column length differs from its batch length");
+    if (col.type.id == QHIP_NULL) { nulls += ca->length; continue; }
+    const uint8_t* bm = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
+    if (bm && ca->null_count != 0) nulls += ca->length - count_set_bits(bm, ca->offset, ca->length);
+  }
+  col.null_count = nulls;
+  if (nulls > 0 && col.type.id != QHIP_NULL) {
+    staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
+    uint8_t* dst = staging.back().data();
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      const uint8_t* bm = (const uint8_t*)ca->buffers[0];
+      if (bm && ca->null_count != 0) copy_bits(bm, ca->offset, dst, batch_offsets[(size_t)b], ca->length);
+      else set_bits(dst, batch_offsets[(size_t)b], ca->length);
+    }
+    col.validity = std::make_shared<DevBuf>((size_t)((N + 7) / 8 + 8));
+    h2d(col.validity->ptr, dst, col.validity->bytes, ctx->stream);
+  }
+  const int w = dtype_width(col.type);
+  if (w > 0) {
+    col.values = std::make_shared<DevBuf>((size_t)N * w);
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      if (ca->length == 0) continue;
+      if (ca->n_buffers < 2 || !ca->buffers[1]) fail(QHIP_INVALID_ARGUMENT, "missing values buffer");
+      h2d((uint8_t*)col.values->ptr + (size_t)batch_offsets[(size_t)b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
+          (size_t)ca->length * w, ctx->stream);
+    }
+  } else if (col.type.id == QHIP_BOOL) {
+    staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
+    uint8_t* dst = staging.back().data();
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      if (ca->length) copy_bits((const uint8_t*)ca->buffers[1], ca->offset, dst, batch_offsets[(size_t)b], ca->length);
+    }
+    col.values = std::make_shared<DevBuf>(staging.back().size());
+    h2d(col.values->ptr, dst, col.values->bytes, ctx->stream);
+  } else if (col.type.id == QHIP_UTF8) {
+    // rebase the int32 offsets of every batch onto the concatenated data buffer
+    staging.emplace_back((size_t)(N + 1) * 4, 0);
+    int32_t* off = (int32_t*)staging.back().data();
+    int64_t total = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      if (ca->length == 0) continue;
+      const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+      total += (int64_t)so[ca->length] - so[0];
+    }
+    if (total > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB (needs LargeUtf8 offsets)");
+    col.data = std::make_shared<DevBuf>((size_t)total);
+    col.data_bytes = total;
+    int64_t pos = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      if (ca->length == 0) continue;
+      const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+      const int32_t base = so[0];
+      int32_t* d = off + batch_offsets[(size_t)b];
+      const int32_t shift = (int32_t)pos - base;
+      for (int64_t i = 0; i < ca->length; ++i) d[i] = so[i] + shift;
+      const int64_t nbytes = (int64_t)so[ca->length] - base;
+      h2d((uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes, ctx->stream);
+      pos += nbytes;
+    }
+    off[N] = (int32_t)total;
+    col.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
+    h2d(col.values->ptr, off, col.values->bytes, ctx->stream);
+  } else if (col.type.id == QHIP_NULL) {
+    col.null_count = N;
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the staging vectors die here
+  return col;
+}
+
+// The host-side Arrow arrays a lazily uploaded table keeps: moved out of the caller's structs (Arrow C Data Interface
+// move semantics: the source's release is set to NULL), released when the last column that needs them is gone.
+struct HostBatches {
+  std::vector<ArrowArray> arrays;
+  std::vector<const ArrowArray*> ptrs;
+  ~HostBatches() { for (auto& a : arrays) if (a.release) a.release(&a); }
+};
+
+DevColumn materialize_upload(Ctx* ctx, const DeferredUpload& u) {
+  auto hb = std::static_pointer_cast<HostBatches>(u.host);
+  return upload_column(ctx, u.format.c_str(), u.column, hb->ptrs.data(), (int64_t)hb->ptrs.size(), u.batch_offsets);
+}
+
+qhip_table* table_from_arrow(Ctx* ctx, const ArrowSchema* schema, ArrowArray* const* batches, int64_t nb, bool lazy) {
   if (!schema || !schema->format || strcmp(schema->format, "+s") != 0)
     fail(QHIP_INVALID_ARGUMENT, "qhip_table_from_arrow: schema must be a struct ('+s') describing a RecordBatch");
   const int64_t nc = schema->n_children;
@@ -66,91 +165,33 @@ qhip_table* table_from_arrow(Ctx* ctx, const ArrowSchema* schema, const ArrowArr
   const int64_t N = t->batch_offsets.back();
   t->num_rows = N;
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
-  std::vector<std::vector<uint8_t>> staging;  // host staging kept alive until the stream is drained
+  std::shared_ptr<HostBatches> hb;
+  if (lazy) {
+    for (int64_t c = 0; c < nc; ++c) (void)dtype_from_format(schema->children[c]->format);   // unsupported types fail now, not later
+    hb = std::make_shared<HostBatches>();
+    hb->arrays.resize((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) {
+      hb->arrays[(size_t)b] = *batches[b];
+      batches[b]->release = nullptr;          // moved
+    }
+    for (auto& a : hb->arrays) hb->ptrs.push_back(&a);
+  }
   for (int64_t c = 0; c < nc; ++c) {
     const ArrowSchema* cs = schema->children[c];
+    t->names.push_back(cs->name ? cs->name : "");
+    t->nullable.push_back((cs->flags & ARROW_FLAG_NULLABLE) != 0);
+    if (!lazy) { t->cols.push_back(upload_column(ctx, cs->format, c, batches, nb, t->batch_offsets)); continue; }
     DevColumn col;
     col.type = dtype_from_format(cs->format);
     col.length = N;
-    t->names.push_back(cs->name ? cs->name : "");
-    t->nullable.push_back((cs->flags & ARROW_FLAG_NULLABLE) != 0);
-    // null count + validity
-    int64_t nulls = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-      const ArrowArray* ca = batches[b]->children[c];
-      if (ca->length != batches[b]->length) fail(QHIP_INVALID_ARGUMENT, "column length differs from its batch length");
-      if (col.type.id == QHIP_NULL) { nulls += ca->length; continue; }
-      const uint8_t* bm = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
-      if (bm && ca->null_count != 0) nulls += ca->length - count_set_bits(bm, ca->offset, ca->length);
-    }
-    col.null_count = nulls;
-    if (nulls > 0 && col.type.id != QHIP_NULL) {
-      staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
-      uint8_t* dst = staging.back().data();
-      for (int64_t b = 0; b < nb; ++b) {
-        const ArrowArray* ca = batches[b]->children[c];
-        const uint8_t* bm = (const uint8_t*)ca->buffers[0];
-        if (bm && ca->null_count != 0) copy_bits(bm, ca->offset, dst, t->batch_offsets[b], ca->length);
-        else set_bits(dst, t->batch_offsets[b], ca->length);
-      }
-      col.validity = std::make_shared<DevBuf>((size_t)((N + 7) / 8 + 8));
-      h2d(col.validity->ptr, dst, col.validity->bytes, ctx->stream);
-    }
-    const int w = dtype_width(col.type);
-    if (w > 0) {
-      col.values = std::make_shared<DevBuf>((size_t)N * w);
-      for (int64_t b = 0; b < nb; ++b) {
-        const ArrowArray* ca = batches[b]->children[c];
-        if (ca->length == 0) continue;
-        if (ca->n_buffers < 2 || !ca->buffers[1]) fail(QHIP_INVALID_ARGUMENT, "missing values buffer");
-        h2d((uint8_t*)col.values->ptr + (size_t)t->batch_offsets[b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
-            (size_t)ca->length * w, ctx->stream);
-      }
-    } else if (col.type.id == QHIP_BOOL) {
-      staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
-      uint8_t* dst = staging.back().data();
-      for (int64_t b = 0; b < nb; ++b) {
-        const ArrowArray* ca = batches[b]->children[c];
-        if (ca->length) copy_bits((const uint8_t*)ca->buffers[1], ca->offset, dst, t->batch_offsets[b], ca->length);
-      }
-      col.values = std::make_shared<DevBuf>(staging.back().size());
-      h2d(col.values->ptr, dst, col.values->bytes, ctx->stream);
-    } else if (col.type.id == QHIP_UTF8) {
-      // rebase the int32 offsets of every batch onto the concatenated data buffer
-      staging.emplace_back((size_t)(N + 1) * 4, 0);
-      int32_t* off = (int32_t*)staging.back().data();
-      int64_t total = 0;
-      for (int64_t b = 0; b < nb; ++b) {
-        const ArrowArray* ca = batches[b]->children[c];
-        if (ca->length == 0) continue;
-        const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
-        total += (int64_t)so[ca->length] - so[0];
-      }
-      if (total > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB (needs LargeUtf8 offsets)");
-      col.data = std::make_shared<DevBuf>((size_t)total);
-      col.data_bytes = total;
-      int64_t pos = 0;
-      for (int64_t b = 0; b < nb; ++b) {
-        const ArrowArray* ca = batches[b]->children[c];
-        if (ca->length == 0) continue;
-        const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
-        const int32_t base = so[0];
-        int32_t* d = off + t->batch_offsets[b];
-        const int32_t shift = (int32_t)pos - base;
-        for (int64_t i = 0; i < ca->length; ++i) d[i] = so[i] + shift;
-        const int64_t nbytes = (int64_t)so[ca->length] - base;
-        h2d((uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes, ctx->stream);
-        pos += nbytes;
-      }
-      off[N] = (int32_t)total;
-      col.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
-      h2d(col.values->ptr, off, col.values->bytes, ctx->stream);
-    } else if (col.type.id == QHIP_NULL) {
-      col.null_count = N;
-    }
+    int64_t maybe_nulls = col.type.id == QHIP_NULL ? N : 0;
+    for (int64_t b = 0; b < nb && !maybe_nulls; ++b) if (hb->ptrs[(size_t)b]->children[c]->null_count != 0) maybe_nulls = 1;
+    col.null_count = maybe_nulls;   // a may-have-nulls flag until the column is uploaded
+    auto u = std::make_shared<DeferredUpload>();
+    u->host = hb; u->format = cs->format; u->column = c; u->batch_offsets = t->batch_offsets;
+    col.pending_upload = u;
     t->cols.push_back(std::move(col));
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return t.release();
 }
 
@@ -307,7 +348,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
 
 using namespace qhip;
 namespace qhip {
-qhip_table* table_from_arrow(Ctx*, const ArrowSchema*, const ArrowArray* const*, int64_t);
+qhip_table* table_from_arrow(Ctx*, const ArrowSchema*, ArrowArray* const*, int64_t, bool lazy);
 void table_batch_to_arrow(Ctx*, const qhip_table*, int64_t, ArrowArray*);
 void table_schema_to_arrow(const qhip_table*, ArrowSchema*);
 }
@@ -318,7 +359,14 @@ int qhip_table_from_arrow(qhip_ctx* ctx, const struct ArrowSchema* schema, const
                           int64_t n_batches, qhip_table** out) {
   if (!ctx || !out || n_batches < 0 || (n_batches > 0 && !batches)) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = table_from_arrow(ctx, schema, batches, n_batches); });
+  return guarded(ctx, [&] { *out = table_from_arrow(ctx, schema, const_cast<ArrowArray* const*>(batches), n_batches, false); });
+}
+
+int qhip_table_from_arrow_lazy(qhip_ctx* ctx, const struct ArrowSchema* schema, struct ArrowArray* const* batches, int64_t n_batches,
+                               qhip_table** out) {
+  if (!ctx || !out || n_batches < 0 || (n_batches > 0 && !batches)) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = table_from_arrow(ctx, schema, batches, n_batches, true); });
 }
 
 int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index, struct ArrowArray* out_array,

@@ -58,9 +58,10 @@ def _with_schema(batch: pa.RecordBatch, schema: Optional[pa.Schema]) -> pa.Recor
 class MemoryTable:
     """datasource/memory.rs:20-98 — also the universal fixture source of the reference's tests."""
 
-    def __init__(self, schema: pa.Schema, data: Sequence[pa.RecordBatch]):
+    def __init__(self, schema: pa.Schema, data: Sequence[pa.RecordBatch], lazy_upload: bool = False):
         self._schema = schema
         self.data = list(data)
+        self.lazy_upload = lazy_upload   # True: a column moves to HBM when a query first reads it (file-backed tables)
         self._device: Optional[DeviceTable] = None
 
     @staticmethod
@@ -73,7 +74,7 @@ class MemoryTable:
     def device_table(self) -> DeviceTable:
         """Batches pinned in HBM (uploaded once; the reference keeps them in host memory behind an RwLock)."""
         if self._device is None:
-            self._device = DeviceTable.from_batches(get_context(), self._schema, self.data)
+            self._device = DeviceTable.from_batches(get_context(), self._schema, self.data, lazy=self.lazy_upload)
         return self._device
 
     def scan(self, projection: Optional[List[str]], filters: Optional[PhysicalExpr]) -> List[pa.RecordBatch]:
