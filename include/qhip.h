@@ -307,6 +307,14 @@ int qhip_plan_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nu
 int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
                            const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
                            int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
+/* The image kernel of qhip_sort_execute for the key expressions, and the kernel of qhip_projection_execute for the
+ * computed (non-Column) expressions among `roots`. */
+int qhip_plan_sort_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                               const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
+                               char* buf, size_t buflen, size_t* needed);
+int qhip_plan_projection_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                                const qhip_expr* exprs, int32_t n_exprs, const int32_t* roots, int32_t n_out,
+                                char* buf, size_t buflen, size_t* needed);
 const char* qhip_plan_last_error(void);
 int qhip_jit_compile_to_cache(const char* policy_source, const char* cache_dir, char* log, size_t log_len);
 

@@ -809,7 +809,7 @@ int64_t qo_adjust_right_indices(const uint64_t* bi, const uint32_t* pi, int64_t 
   return cnt;
 }
 
-/* ================================================================ accumulators (physical/expr/aggregate/*.rs) */
+/* ================================================================ accumulators (physical/expr/aggregate/{sum,avg,count,min,max}.rs) */
 typedef struct acc {
   int kind; qhip_dtype ret; qhip_dtype arg;
   int has_sum; i128 isum; double fsum; uint64_t count;   /* SumAccumulator / Avg accumulators */

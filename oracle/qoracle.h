@@ -61,7 +61,7 @@ uint64_t qo_hasher_finish(const qo_hasher* h);
 /* utils/array.rs:190-210 create_hashes: per-row hash of the key columns; returns 0 or an error code */
 int qo_create_hashes(const qo_col* cols, int ncols, int64_t nrows, uint64_t* out);
 
-/* physical/expr/*.rs evaluate(): column-at-a-time evaluation with full-length temporaries */
+/* physical/expr/{binary,cast,literal,column,case,like}.rs evaluate(): column-at-a-time evaluation with full-length temporaries */
 int qo_eval(const qhip_expr* exprs, int n_exprs, int root, const qo_col* batch_cols, int ncols, int64_t nrows, qo_col* out);
 
 /* filter_record_batch semantics (physical/plan/filter.rs:34): rows whose mask is valid AND true.

@@ -14,11 +14,36 @@ from .synth import LINEITEM_SCHEMA
 
 
 def catalog_sources():
+    """(name, policy source) of every generated kernel the benchmark queries launch — one of each kernel body of
+    csrc/device/qhip_device.hpp gets instantiated, so compiling the catalog is the compile check of the device templates."""
+    import pyarrow as pa
+
+    from . import expr as E
+    from .datatypes import Operator, ScalarValue
+    from .synth import CUSTOMER_SCHEMA, LINEITEM_Q3_SCHEMA, ORDERS_SCHEMA
     table = MemoryTable.try_new(LINEITEM_SCHEMA, [])
     out = []
     for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table))):
         scan = plan.input
-        out.append((name, planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
+        out.append((name + " filter+aggregate", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
+    # Q3: build-side key words (+ fused scan filter), fused probe kernels, the aggregate over the second join's output
+    tabs = (MemoryTable.try_new(CUSTOMER_SCHEMA, []), MemoryTable.try_new(ORDERS_SCHEMA, []), MemoryTable.try_new(LINEITEM_Q3_SCHEMA, []))
+    agg = queries.q3(*tabs)
+    j2 = agg.input
+    j1 = j2.left
+    out.append(("q3 customer keys+filter", planning.keys_source(CUSTOMER_SCHEMA, [j1.on[0][0]])))
+    out.append(("q3 orders probe", planning.probe_source(ORDERS_SCHEMA, [j1.on[0][1]], j1.right.filter)))
+    out.append(("q3 join-1 output keys", planning.keys_source(j1.schema(), [j2.on[0][0]])))
+    out.append(("q3 lineitem probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))
+    out.append(("q3 aggregate", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+    top = queries.q3_top10(*tabs)
+    out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
+    # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)
+    out.append(("filter mask", planning.filter_source(LINEITEM_SCHEMA, queries.q1_full(table).input.filter)))
+    like = E.Like(False, E.Column("l_returnflag", 1), E.Literal(ScalarValue.Utf8("A%")))
+    case = E.CaseExpr([(like, E.Column("l_extendedprice", 4))], E.CastExpr(E.Literal(ScalarValue.Int64(0)), pa.decimal128(15, 2)))
+    ratio = E.BinaryExpr(E.Column("l_extendedprice", 4), Operator.Div, E.Column("l_quantity", 3))
+    out.append(("projection CASE/LIKE", planning.projection_source(LINEITEM_SCHEMA, [E.Column("l_shipdate", 0), case, ratio])))
     return out
 
 

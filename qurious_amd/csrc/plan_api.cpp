@@ -72,4 +72,29 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }
 
+int qhip_plan_sort_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                               int32_t n_exprs, const int32_t* key_roots, int32_t n_keys, char* buf, size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    SortKeysPlan p;
+    plan_sort_keys(es, in, key_roots, n_keys, p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+int qhip_plan_projection_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                                int32_t n_exprs, const int32_t* roots, int32_t n_out, char* buf, size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    std::vector<int32_t> computed;
+    for (int k = 0; k < n_out; ++k)
+      if (roots[k] >= 0 && roots[k] < n_exprs && exprs[roots[k]].kind != QHIP_EXPR_COLUMN) computed.push_back(roots[k]);
+    ProjectionPlan p;
+    plan_projection(es, in, computed.data(), (int)computed.size(), p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
 }  // extern "C"

@@ -92,6 +92,30 @@ def probe_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: Opt
     return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot))
 
 
+def sort_keys_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], has_nulls: Optional[Sequence[bool]] = None) -> str:
+    """Source of the order-preserving key image kernel Sort launches (Utf8 keys have no generated part)."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_sort_keys_source
+    fn.restype = C.c_int
+    types, hn, n = _cols(schema, has_nulls)
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    arr, ne = ea.c_array()
+    return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)))
+
+
+def projection_source(schema: pa.Schema, exprs: Sequence[PhysicalExpr], has_nulls: Optional[Sequence[bool]] = None) -> str:
+    """Source of the kernel Projection launches for its computed (non-Column) expressions."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_projection_source
+    fn.restype = C.c_int
+    types, hn, n = _cols(schema, has_nulls)
+    ea = ExprArray()
+    roots = [ea.lower(e) for e in exprs]
+    arr, ne = ea.c_array()
+    return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)))
+
+
 def compile_to_cache(policy_source: str, cache_dir: str = KERNEL_CACHE_DIR) -> str:
     """hiprtc-compile (device templates + policy) for gfx950 into the kernel cache; returns the compiler log."""
     lib = _ffi.load_library()
