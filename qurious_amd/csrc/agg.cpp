@@ -228,6 +228,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // the same plan produced many groups last time: go straight to one table with room for them
     cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(1u << 16, pow2_ceil((uint64_t)plan.last_groups * 2)));
     replicas = 1;
+  } else if (plan.W > 0 && plan.last_groups > 0 && plan.last_groups * 16 < cap) {
+    // ... or very few (Q1: 4): 16 slots per expected group are plenty, and clearing + compacting the replicated table
+    // (both proportional to its size, both on the critical path of the call) shrink with it
+    cap = std::min<uint32_t>(cap, std::max<uint32_t>(64, pow2_ceil((uint64_t)plan.last_groups * 16)));
   }
   DevBuf gtable, dense;
   uint32_t status[QS_WORDS];
