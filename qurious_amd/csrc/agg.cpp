@@ -38,6 +38,38 @@ void HostColumn::set_null(int64_t i) {
   ++null_count;
 }
 
+// A host-assembled column -> HBM (synchronous; runs when a device operator first reads the column)
+DevColumn upload_host_column(Ctx* ctx, const DeferredUpload& u) {
+  HostColumn& hc = *std::static_pointer_cast<HostColumn>(u.host_col);
+  const int64_t nrows = hc.length;
+  DevColumn dc;
+  dc.type = hc.type; dc.length = nrows; dc.null_count = hc.null_count;
+  auto up = [&](const void* src, size_t n) {
+    auto b = std::make_shared<DevBuf>(n);
+    if (n) QHIP_HIP_CHECK(hipMemcpyAsync(b->ptr, src, n, hipMemcpyHostToDevice, ctx->stream));
+    return b;
+  };
+  if (hc.null_count > 0 && hc.type.id != QHIP_NULL) {
+    hc.validity.resize((size_t)((nrows + 7) / 8 + 8), 0);
+    dc.validity = up(hc.validity.data(), hc.validity.size());
+  }
+  if (hc.type.id == QHIP_UTF8) {
+    dc.values = up(hc.offsets.data(), hc.offsets.size() * 4);
+    dc.data = up(hc.data.data(), hc.data.size());
+    dc.data_bytes = (int64_t)hc.data.size();
+  } else if (hc.type.id == QHIP_BOOL) {
+    hc.values.resize((size_t)((nrows + 7) / 8 + 8), 0);
+    dc.values = up(hc.values.data(), hc.values.size());
+  } else if (hc.type.id != QHIP_NULL) {
+    dc.values = up(hc.values.data(), hc.values.size());
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the host vectors may go away with the DeferredUpload
+  return dc;
+}
+
+// A single-batch (or zero-batch) table from host columns. The columns STAY on the host (an aggregate's few result rows
+// are usually exported next, as the reference's results are host batches) and are uploaded when a device operator reads
+// them (Sort / Limit / Projection over an aggregate, a join over a subquery result).
 qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, const std::vector<bool>& nullable,
                             std::vector<HostColumn>& cols, int64_t nrows, bool zero_batches) {
   std::unique_ptr<qhip_table> t(new qhip_table());
@@ -49,31 +81,11 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
   if (!zero_batches) t->batch_offsets.push_back(nrows);
   for (auto& hc : cols) {
     DevColumn dc;
-    dc.type = hc.type; dc.length = nrows; dc.null_count = hc.null_count;
-    auto up = [&](const void* src, size_t n) {
-      // asynchronous upload: the bytes are moved into a staging vector owned by the table, so no synchronisation is needed
-      auto b = std::make_shared<DevBuf>(n);
-      if (n) {
-        auto stage = std::make_shared<std::vector<uint8_t>>((const uint8_t*)src, (const uint8_t*)src + n);
-        t->host_keepalive.push_back(stage);
-        QHIP_HIP_CHECK(hipMemcpyAsync(b->ptr, stage->data(), n, hipMemcpyHostToDevice, ctx->stream));
-      }
-      return b;
-    };
-    if (hc.null_count > 0 && hc.type.id != QHIP_NULL) {
-      hc.validity.resize((size_t)((nrows + 7) / 8 + 8), 0);
-      dc.validity = up(hc.validity.data(), hc.validity.size());
-    }
-    if (hc.type.id == QHIP_UTF8) {
-      dc.values = up(hc.offsets.data(), hc.offsets.size() * 4);
-      dc.data = up(hc.data.data(), hc.data.size());
-      dc.data_bytes = (int64_t)hc.data.size();
-    } else if (hc.type.id == QHIP_BOOL) {
-      hc.values.resize((size_t)((nrows + 7) / 8 + 8), 0);
-      dc.values = up(hc.values.data(), hc.values.size());
-    } else if (hc.type.id != QHIP_NULL) {
-      dc.values = up(hc.values.data(), hc.values.size());
-    }
+    dc.type = hc.type; dc.length = nrows; dc.null_count = hc.type.id == QHIP_NULL ? nrows : hc.null_count;
+    hc.length = nrows;
+    auto u = std::make_shared<DeferredUpload>();
+    u->host_col = std::make_shared<HostColumn>(std::move(hc));
+    dc.pending_upload = u;
     t->cols.push_back(std::move(dc));
   }
   return t.release();
@@ -317,19 +329,30 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
     if (replicas > 1 && G > 1) {
       // merge the replicas: same key words -> one slot; every cell is a commutative monoid (wrapping adds, max)
-      std::map<std::vector<uint64_t>, uint32_t> seen;
+      std::map<std::vector<uint64_t>, uint32_t> seen;   // only consulted once there are many distinct keys
       uint32_t out = 0;
       for (uint32_t g = 0; g < G; ++g) {
         uint64_t* src = &slots[(size_t)g * plan.slot_words];
-        std::vector<uint64_t> key(src + 1, src + 1 + plan.W);
-        auto it = seen.find(key);
-        if (it == seen.end()) {
-          seen.emplace(std::move(key), out);
+        uint32_t found = out;
+        if (out <= 16) {
+          for (uint32_t k = 0; k < out; ++k)
+            if (!memcmp(&slots[(size_t)k * plan.slot_words + 1], src + 1, (size_t)plan.W * 8)) { found = k; break; }
+          if (found == out && out == 16)   // growing past the linear-search regime: index what we have
+            for (uint32_t k = 0; k < out; ++k) {
+              const uint64_t* ks = &slots[(size_t)k * plan.slot_words + 1];
+              seen.emplace(std::vector<uint64_t>(ks, ks + plan.W), k);
+            }
+        } else {
+          auto it = seen.find(std::vector<uint64_t>(src + 1, src + 1 + plan.W));
+          if (it != seen.end()) found = it->second;
+        }
+        if (found == out) {
+          if (out >= 16) seen.emplace(std::vector<uint64_t>(src + 1, src + 1 + plan.W), out);
           if (out != g) memcpy(&slots[(size_t)out * plan.slot_words], src, (size_t)slot_bytes);
           ++out;
           continue;
         }
-        uint64_t* dst = &slots[(size_t)it->second * plan.slot_words] + 1 + plan.W;
+        uint64_t* dst = &slots[(size_t)found * plan.slot_words] + 1 + plan.W;
         const uint64_t* sc = src + 1 + plan.W;
         for (auto& cd : plan.cells) {
           switch (cd.kind) {

@@ -104,6 +104,8 @@ struct DevColumn {
   int64_t resident_bytes() const;
 };
 struct DeferredUpload {
+  std::shared_ptr<void> host_col;       // ... or a HostColumn an operator assembled (small results stay on the host until a
+                                        // device operator reads them; the reference's results are host batches anyway)
   std::shared_ptr<void> host;           // HostBatches (table.cpp): the Arrow arrays, kept alive
   std::string format;                   // Arrow C format string of the column
   int64_t column = 0;

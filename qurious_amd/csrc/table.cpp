@@ -144,7 +144,10 @@ struct HostBatches {
   ~HostBatches() { for (auto& a : arrays) if (a.release) a.release(&a); }
 };
 
+DevColumn upload_host_column(Ctx* ctx, const DeferredUpload& u);   // agg.cpp (HostColumn)
+
 DevColumn materialize_upload(Ctx* ctx, const DeferredUpload& u) {
+  if (u.host_col) return upload_host_column(ctx, u);
   auto hb = std::static_pointer_cast<HostBatches>(u.host);
   return upload_column(ctx, u.format.c_str(), u.column, hb->ptrs.data(), (int64_t)hb->ptrs.size(), u.batch_offsets);
 }
