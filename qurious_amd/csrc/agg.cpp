@@ -255,16 +255,44 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const uint32_t PRE = (uint32_t)std::min<size_t>(256, (ctx->pinned_bytes - 64 - 8) / (size_t)slot_bytes);
   uint32_t* status_pinned = (uint32_t*)ctx->pinned;
   uint64_t* pre_host = (uint64_t*)((uint8_t*)ctx->pinned + 64);
+  uint64_t* table_dev = nullptr;
+  uint64_t* dense_dev = nullptr;    // [counter | dense slots]
   for (;;) {
     const size_t table_bytes = (size_t)cap * replicas * slot_bytes;
-    gtable.alloc(table_bytes);
-    QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, table_bytes, ctx->stream));
-    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+    const uint32_t total_slots = cap * replicas;
+    // (a plan that produced many groups last time gets a dense buffer that should hold them all at once)
+    guess = plan.W == 0 ? 0 : std::min<uint32_t>(total_slots, std::max<uint32_t>(8192, plan.last_groups + plan.last_groups / 4));
+    // Small replicated attempt: a persistent arena [status | counter | table | dense slots] that the PREVIOUS call left
+    // zeroed, so the kernel launch is the first thing on the stream. (total_slots <= guess there: one compaction always
+    // suffices and the table is not needed again after it.)
+    const bool use_arena = plan.W > 0 && replicas > 1 && total_slots <= 8192 && table_bytes <= (1u << 20) && env_int("QHIP_AGG_NO_ARENA", 0) == 0;
+    uint32_t* status_dev = ctx->status.as<uint32_t>();
+    std::shared_ptr<DevBuf> arena;
+    const size_t zero_bytes = 128 + table_bytes;   // status (64) + counter (64) + table
+    if (use_arena) {
+      const size_t need = zero_bytes + (size_t)guess * slot_bytes + 64;
+      arena = std::static_pointer_cast<DevBuf>(plan.arena);
+      if (!arena || plan.arena_bytes != need) {
+        arena = std::make_shared<DevBuf>(need);
+        plan.arena = arena;
+        plan.arena_bytes = need;
+        plan.arena_clean = false;
+      }
+      if (!plan.arena_clean) QHIP_HIP_CHECK(hipMemsetAsync(arena->ptr, 0, zero_bytes, ctx->stream));
+      plan.arena_clean = false;
+      status_dev = arena->as<uint32_t>();
+      table_dev = (uint64_t*)(arena->as<uint8_t>() + 128);
+    } else {
+      gtable.alloc(table_bytes);
+      QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, table_bytes, ctx->stream));
+      QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+      table_dev = gtable.as<uint64_t>();
+    }
     HAggLaunch L;
-    L.gtable = gtable.as<uint64_t>();
+    L.gtable = table_dev;
     L.g_nslots = cap;
     L.l_nslots = l_nslots;
-    L.status = ctx->status.as<uint32_t>();
+    L.status = status_dev;
     L.replicas = replicas;
     L.collect_stats = env_int("QHIP_AGG_STATS", 0) ? 1u : 0u;
     void* args[] = {&ka, &L};
@@ -272,23 +300,40 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (N > 0)
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
-    QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     if (plan.W == 0) {
-      QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, gtable.ptr, (size_t)slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, table_dev, (size_t)slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
     } else {
       // speculative compaction right behind the kernel: [counter | dense slots]; the common case (few groups, no
       // overflow) then needs a single synchronisation for status + result
-      const uint32_t total_slots = cap * replicas;
-      // (a plan that produced many groups last time gets a buffer that should hold them all at once)
-      guess = std::min<uint32_t>(total_slots, std::max<uint32_t>(8192, plan.last_groups + plan.last_groups / 4));
-      dense.alloc((size_t)guess * slot_bytes + 8);
-      QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
-      launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
-      const uint32_t pre = std::min(PRE, guess);
-      QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, dense.ptr, 8 + (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (use_arena) {
+        // counter at +64 (zeroed with the arena), dense slots behind the table; the 8 bytes in front of the slots are a
+        // copy target only in the read-back below, so read counter and slots separately
+        dense_dev = (uint64_t*)(arena->as<uint8_t>() + zero_bytes) ;
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, (uint32_t*)(arena->as<uint8_t>() + 64), guess, ctx->stream);
+        const uint32_t pre = std::min(PRE, guess);
+        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, arena->as<uint8_t>() + 64, 8, hipMemcpyDeviceToHost, ctx->stream));
+        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      } else {
+        dense.alloc((size_t)guess * slot_bytes + 8);
+        QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
+        dense_dev = dense.as<uint64_t>();
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
+        const uint32_t pre = std::min(PRE, guess);
+        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, dense.ptr, 8 + (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      }
     }
-    mark("launched");
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (use_arena) {
+      // wait for the read-backs only; the arena is zeroed for the next call behind them
+      QHIP_HIP_CHECK(hipEventRecord(ctx->ev[2], ctx->stream));
+      QHIP_HIP_CHECK(hipMemsetAsync(arena->ptr, 0, zero_bytes, ctx->stream));
+      plan.arena_clean = true;
+      mark("launched");
+      QHIP_HIP_CHECK(hipEventSynchronize(ctx->ev[2]));
+    } else {
+      mark("launched");
+      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     memcpy(status, status_pinned, sizeof(status));
     mark("synchronised");
     QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
@@ -316,7 +361,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       guess = G;
       dense.alloc((size_t)guess * slot_bytes + 8);
       QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
-      launch_compact_slots(gtable.as<uint64_t>(), total_slots, plan.slot_words, dense.as<uint64_t>() + 1, dense.as<uint32_t>(), guess, ctx->stream);
+      dense_dev = dense.as<uint64_t>();
+      launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     if (replicas == 1 && G >= dev_threshold) {
@@ -325,7 +371,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       slots.assign(pre_host + 1, pre_host + 1 + (size_t)G * plan.slot_words);
     } else {
       slots.resize((size_t)G * plan.slot_words);
-      copy_sync(ctx->stream, slots.data(), dense.as<uint64_t>() + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
+      copy_sync(ctx->stream, slots.data(), dense_dev + 1, (size_t)G * slot_bytes, hipMemcpyDeviceToHost);
     }
     if (replicas > 1 && G > 1) {
       // merge the replicas: same key words -> one slot; every cell is a commutative monoid (wrapping adds, max)

@@ -2,6 +2,7 @@
 // templates of device/qhip_device.hpp are instantiated with.
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,11 @@ struct AggPlan {
   std::string source;          // policy struct + extern "C" kernel, to be appended to the device header
   std::string kernel_name;
   mutable uint32_t last_groups = 0;   // groups the plan produced the last time it ran (sizes the first table attempt)
+  // the small replicated first-attempt table of a plan that keeps producing few groups is kept between calls, zeroed at
+  // the END of a call (off the critical path): [status words | dense counter | table | dense slots]
+  mutable std::shared_ptr<void> arena;
+  mutable size_t arena_bytes = 0;
+  mutable bool arena_clean = false;
 };
 
 // group_roots / aggs refer to nodes of `es`; predicate_root < 0 = no filter

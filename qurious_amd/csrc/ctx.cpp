@@ -1,5 +1,6 @@
 // ctx.cpp — context lifecycle, dtype helpers, device buffers.
 #include <hip/hip_runtime_api.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -111,6 +112,10 @@ struct Pool {
   size_t cached = 0;
 };
 Pool g_pools[32];
+// Blocks are recycled without a synchronisation because everything of a context runs on its one stream (the next user of
+// a block is ordered after the previous one). That argument needs ONE stream per device: with a second live context on
+// the same device a block is returned to the pool only after the device is idle.
+std::atomic<int> g_live_contexts[32];
 size_t pool_cap_bytes() {
   static size_t cap = [] { const char* v = getenv("QHIP_POOL_MAX_GB"); return (size_t)(v && *v ? atof(v) : 64.0) * (1ULL << 30); }();
   return cap;
@@ -160,6 +165,7 @@ void DevBuf::alloc(size_t n) {
 }
 void DevBuf::release() {
   if (!ptr) return;
+  if (g_live_contexts[device & 31].load(std::memory_order_relaxed) > 1) (void)hipDeviceSynchronize();
   Pool& pool = g_pools[device & 31];
   bool kept = false;
   {
@@ -224,6 +230,7 @@ int qhip_ctx_create(int device_index, qhip_ctx** out) {
     c->device_name = pname + " (" + arch + ")";
     c->num_cus = prop.multiProcessorCount;
     QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    g_live_contexts[c->device & 31].fetch_add(1);
     for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
     c->status.alloc(QS_WORDS * sizeof(uint32_t));
     c->pinned_bytes = 256 * 1024;
@@ -242,7 +249,7 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   ctx->status.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); g_live_contexts[ctx->device & 31].fetch_sub(1); }
   delete ctx;
 }
 
