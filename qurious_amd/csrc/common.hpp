@@ -132,7 +132,6 @@ struct qhip_table {
   std::vector<qhip::DevColumn> cols;
   int64_t num_rows = 0;
   std::vector<int64_t> batch_offsets;     // size = num_batches + 1; batch b = rows [off[b], off[b+1])
-  std::vector<std::shared_ptr<std::vector<uint8_t>>> host_keepalive;   // staging of asynchronous host->HBM uploads
   int64_t num_batches() const { return (int64_t)batch_offsets.size() - 1; }
 };
 

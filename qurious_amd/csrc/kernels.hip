@@ -12,14 +12,6 @@ namespace qhip {
 // ---------------------------------------------------------------- group table -> dense slots
 // GroupAccumulator::output (physical/plan/aggregate/hash.rs:89-107): one output row per group. Group
 // order = slot order, i.e. unspecified, like the reference's HashMap iteration order (hash.rs:98).
-__global__ __launch_bounds__(QH_BLOCK) void k_count_ready(const u64* table, u32 nslots, int slot_words, u32* counter) {
-  u32 local = 0;
-  for (u32 s = blockIdx.x * QH_BLOCK + threadIdx.x; s < nslots; s += gridDim.x * QH_BLOCK)
-    local += table[(size_t)s * slot_words] == QH_READY ? 1u : 0u;
-  u64 total = qh_wave_sum_u64(local);
-  if (qh_lane() == 0 && total) atomicAdd(counter, (u32)total);
-}
-
 // Every wavefront owns a contiguous range of slots: it counts the ready ones (state words only), reserves its share of
 // the output with ONE atomic, then copies. (Atomics on one address cost ~10 ns each across the 8 XCDs: one per group
 // or even one per 64 slots would dominate the kernel.)
@@ -73,9 +65,6 @@ static inline unsigned grid_for(uint64_t n, unsigned cap = 2048) {
   return (unsigned)g;
 }
 
-void launch_count_ready(const uint64_t* table, uint32_t nslots, int slot_words, uint32_t* counter, hipStream_t s) {
-  hipLaunchKernelGGL(k_count_ready, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, slot_words, counter);
-}
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
                           uint32_t out_capacity, hipStream_t s) {
   // few, long-lived wavefronts: 64 .. 2048 of them, each with >= 256 slots

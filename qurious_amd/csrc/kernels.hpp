@@ -9,7 +9,6 @@ constexpr uint32_t kNullIdx = 0xFFFFFFFFu;   // NULL row index in u32 index vect
 
 // group table -> dense slot array (kernels.hip)
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned blocks, hipStream_t s);
-void launch_count_ready(const uint64_t* table, uint32_t nslots, int slot_words, uint32_t* counter, hipStream_t s);
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
                           uint32_t out_capacity, hipStream_t s);
 
