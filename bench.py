@@ -68,7 +68,11 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     log(f"generated SF{args.sf} slice {rows} rows in {time.time() - t0:.1f}s")
     for t in tabs:
         t.device_table()
-    plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if world > 1 else None)
+    if world > 1 and args.strategy == "broadcast":
+        # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
+        plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
+    else:
+        plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if world > 1 else None)
     for _ in range(args.warmup):
         out = plan.execute_device()
         log(f"warmup step: {out.num_rows} groups")
@@ -127,7 +131,8 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i128", "data": "synthetic",
         "config": {"workload": f"configs[3] q3: TPC-H Q3 SF{args.sf} customer|><|orders|><|lineitem + GROUP BY, HBM-resident, "
                                f"lineitem rows/s", "rows": {"customer": rows_all[0], "orders": rows_all[1], "lineitem": rows_all[2]},
-                   "groups": rows_all[3], "parallelism": f"hash-partitioned joins x{world}"},
+                   "groups": rows_all[3], "parallelism": (f"broadcast build sides, local probes, merged partial groups x{world}" if world > 1 and args.strategy == "broadcast"
+                                   else f"hash-partitioned joins x{world}")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "q3 pipeline (all kernels of one query, per GPU)", "kernel_ms": ms,
                      "algorithmic_bytes": algo_bytes},
@@ -190,6 +195,8 @@ def main():
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
     ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full", "q3"])
     ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of the q3 workload (whole job, sliced over the ranks)")
+    ap.add_argument("--strategy", default="broadcast", choices=["broadcast", "repartition"],
+                    help="q3 on several GPUs: all-gather the small build sides (default) or repartition both sides of every join by key")
     ap.add_argument("--skew", type=float, default=0.0, help="q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
     ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")

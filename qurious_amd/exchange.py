@@ -8,8 +8,16 @@ The reference has no exchange operator (it is a single process); this is the onl
     parts received from every peer --qhip_table_from_device + qhip_table_concat--> local join input
         --qhip_hash_join_execute--> local slice of the join result
 
-No collective is used for the aggregate after Q3's joins: its GROUP BY contains the join key, so groups are disjoint
-across ranks and the result is the union of the ranks' results.
+No collective is used for the aggregate after Q3's REPARTITIONED joins: its GROUP BY contains the join key, so groups are
+disjoint across ranks and the result is the union of the ranks' results.
+
+xGMI (7 links x ~153 GB/s) is ~30x slower per byte than HBM, so moving the big probe side is what limits scaling. The
+second strategy keeps it where it is (SURVEY §8e's option):
+
+    BroadcastHashJoinExec   the (small) build side of an Inner / Right join is ALL-GATHERED — every rank gets all of it —
+                            and each rank probes it with its own slice of the probe side (never exchanged);
+    DistributedHashAggregate  groups may then span ranks: every rank aggregates locally, the partial groups (few) are
+                            repartitioned by group key and merged (SUM of sums, SUM of counts, MIN of mins, MAX of maxes).
 """
 from __future__ import annotations
 
@@ -224,3 +232,92 @@ class DistributedHashJoinExec(HashJoinExec):
     def try_new(left, right, join_type, on, filter=None) -> "DistributedHashJoinExec":
         base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
         return DistributedHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)
+
+
+def all_gather_device_table(table: DeviceTable, schema, group=None) -> DeviceTable:
+    """Every rank ends up with the concatenation (rank order) of all ranks' tables."""
+    dist = _dist()
+    return exchange_device_tables([table] * dist.get_world_size(group), schema, group)
+
+
+class BroadcastHashJoinExec(HashJoinExec):
+    """HashJoinExec for a small build side: it is replicated with one all-gather and every rank joins it with its local
+    slice of the probe side, which never moves. Valid for the join types in which a result row belongs to exactly one
+    probe row or pair (Inner, Right); the others fall back to the repartitioned join. Inside a rank the reference's
+    output order holds; across ranks the result is the union."""
+
+    def execute_device(self) -> DeviceTable:
+        dist = _dist()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if world <= 1:
+            return HashJoinExec.execute_device(self)
+        if self.join_type not in (JoinType.Inner, JoinType.Right):
+            return DistributedHashJoinExec.execute_device(self)
+        build = all_gather_device_table(self.left.execute_device(), self.left.schema())
+        probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
+        return self._join_tables(build, probe, None, rpred)
+
+    _repartitioned = DistributedHashJoinExec.execute_device
+
+    @staticmethod
+    def try_new(left, right, join_type, on, filter=None) -> "BroadcastHashJoinExec":
+        base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
+        return BroadcastHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)
+
+
+def merge_aggregate_exprs(aggregate_exprs, n_groups: int):
+    """The aggregate list that merges partial results laid out as (group keys..., partials...): SUM -> SUM of the partial
+    sums, COUNT -> SUM of the partial counts, MIN / MAX -> MIN / MAX of the partials. AVG has no single-column partial."""
+    import pyarrow as pa
+    from .expr import AvgAggregateExpr, Column, CountAggregateExpr, MaxAggregateExpr, MinAggregateExpr, SumAggregateExpr
+    out = []
+    for k, a in enumerate(aggregate_exprs):
+        part = Column(f"partial{k}", n_groups + k)
+        if isinstance(a, AvgAggregateExpr):
+            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, "AVG cannot be merged from single-column partials: aggregate SUM and COUNT instead")
+        if isinstance(a, CountAggregateExpr):
+            out.append(SumAggregateExpr(part, pa.int64()))
+        elif isinstance(a, SumAggregateExpr):
+            out.append(SumAggregateExpr(part, a._return_type()))
+        elif isinstance(a, MinAggregateExpr):
+            out.append(MinAggregateExpr(part, a._return_type()))
+        elif isinstance(a, MaxAggregateExpr):
+            out.append(MaxAggregateExpr(part, a._return_type()))
+        else:
+            raise _ffi.UnsupportedError(_ffi.QHIP_UNSUPPORTED, f"no merge rule for {type(a).__name__}")
+    return out
+
+
+class DistributedHashAggregate(PhysicalPlan):
+    """HashAggregate whose input rows of one group may live on several ranks: local (partial) aggregation, the partial
+    groups repartitioned by the group key, then the merge aggregation. Afterwards every group is on exactly one rank."""
+
+    def __init__(self, schema, input: PhysicalPlan, group_exprs, aggregate_exprs):
+        from .plan import HashAggregate
+        self._schema, self.input = schema, input
+        self.group_exprs, self.aggregate_exprs = list(group_exprs), list(aggregate_exprs)
+        self.partial = HashAggregate(schema, input, group_exprs, aggregate_exprs)
+
+    def schema(self):
+        return self._schema
+
+    def children(self):
+        return [self.input]
+
+    def execute_device(self) -> DeviceTable:
+        from .expr import Column
+        from .plan import HashAggregate
+        dist = _dist()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        part = self.partial.execute_device()
+        if world <= 1:
+            return part
+        ng = len(self.group_exprs)
+        pschema = self._schema if self._schema is not None else None
+        keys = [Column(f"g{k}", k) for k in range(ng)]
+        if pschema is None:
+            raise _ffi.InternalError(_ffi.QHIP_INVALID_ARGUMENT, "DistributedHashAggregate needs its output schema (the partials travel)")
+        mine = exchange_device_tables(partition_by_key(part, keys, world), pschema)
+        merge = HashAggregate(pschema, DeviceSource(pschema, mine), keys, merge_aggregate_exprs(self.aggregate_exprs, ng))
+        return merge.execute_device()
+

@@ -44,7 +44,7 @@ def q1_full(table: MemoryTable) -> HashAggregate:
     return HashAggregate(schema, scan, [Column("l_returnflag", 1), Column("l_linestatus", 2)], aggs)
 
 
-def q3(customer, orders, lineitem, join_cls=None):
+def q3(customer, orders, lineitem, join_cls=None, agg_cls=None):
     """configs[3]: TPC-H Q3 (tests/tpch/q3.slt:2-24) up to the HashAggregate output, in the plan shape the reference's
     optimizer produces: filters pushed into the scans, build side = left child, no side swapping.
     customer / orders / lineitem are MemoryTables over synth.{CUSTOMER,ORDERS,LINEITEM_Q3}_SCHEMA."""
@@ -65,8 +65,8 @@ def q3(customer, orders, lineitem, join_cls=None):
     t4 = pa.decimal128(38, 4)
     schema = pa.schema([pa.field("l_orderkey", pa.int64()), pa.field("o_orderdate", pa.date32()), pa.field("o_shippriority", pa.int64()),
                         pa.field("revenue", t4)])
-    return HashAggregate(schema, j2, [Column("l_orderkey", 6), Column("o_orderdate", 4), Column("o_shippriority", 5)],
-                         [SumAggregateExpr(revenue, t4)])
+    return (agg_cls or HashAggregate)(schema, j2, [Column("l_orderkey", 6), Column("o_orderdate", 4), Column("o_shippriority", 5)],
+                                      [SumAggregateExpr(revenue, t4)])
 
 
 def q3_top10(customer, orders, lineitem, join_cls=None):

@@ -82,6 +82,72 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _agg_over(join_plan, aggs_of):
+    """GROUP BY lk over a join's output: SUM / COUNT / MIN / MAX of rv"""
+    schema = pa.schema([pa.field("lk", I64), pa.field("s", I64), pa.field("c", I64), pa.field("mn", I64), pa.field("mx", I64)])
+    return q.HashAggregate(schema, join_plan, [col("lk", 0)], aggs_of(col("rv", 3))), schema
+
+
+def _aggs(arg):
+    return [q.SumAggregateExpr(arg, I64), q.CountAggregateExpr(arg), q.MinAggregateExpr(arg, I64), q.MaxAggregateExpr(arg, I64)]
+
+
+def _worker_broadcast(rank, world, port, out_dir):
+    """broadcast strategy: the build side is all-gathered, the probe slice stays local, partial groups are repartitioned
+    by group key and merged (qurious_amd.exchange.BroadcastHashJoinExec / DistributedHashAggregate, with the oracle as the
+    local engine)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import qoracle
+    from qurious_amd.exchange import all_to_all_bytes, merge_aggregate_exprs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (ls, lb), (rs, rb) = _tables(seed=33, nl=300, nr=4000, nkeys=150)
+        cut = lambda b: b.slice(b.num_rows * rank // world, b.num_rows * (rank + 1) // world - b.num_rows * rank // world)   # noqa: E731
+        lmine, rmine = cut(lb), cut(rb)
+        # all-gather of the build side = an all-to-all that sends the same bytes to everybody
+        payload = torch.frombuffer(bytearray(_ipc(lmine)), dtype=torch.uint8)
+        build = pa.concat_batches([_unipc(bytes(t.numpy().tobytes())) for t in all_to_all_bytes([payload] * world)])
+        assert build.num_rows == lb.num_rows
+        join = q.HashJoinExec.try_new(table_scan(ls, [build]), table_scan(rs, [rmine]), JoinType.Inner, [(col("lk", 0), col("rk", 0))], None)
+        partial_plan, pschema = _agg_over(join, _aggs)
+        partial = pa.concat_batches(qoracle.execute(partial_plan))
+        pid = qoracle.partition_ids([partial.column(0)], world)
+        send = [torch.frombuffer(bytearray(_ipc(partial.filter(pa.array(pid == r)))), dtype=torch.uint8) for r in range(world)]
+        mine = pa.concat_batches([_unipc(bytes(t.numpy().tobytes())) for t in all_to_all_bytes(send)])
+        merge = q.HashAggregate(pschema, table_scan(pschema, [mine]), [col("lk", 0)], merge_aggregate_exprs(partial_plan.aggregate_exprs, 1))
+        local = rows_of(qoracle.execute(merge))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        if rank == 0:
+            full_join = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb]), JoinType.Inner, [(col("lk", 0), col("rk", 0))], None)
+            want = sorted(rows_of(qoracle.execute(_agg_over(full_join, _aggs)[0])))
+            got = sorted(r for part in gathered for r in part)
+            keys = [r[0] for r in got]
+            assert len(keys) == len(set(keys))            # after the merge every group lives on exactly one rank
+            assert got == want and len(want) > 50
+            open(os.path.join(out_dir, "ok_broadcast"), "w").write(str(len(want)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_join_and_partial_aggregate_merge_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_broadcast, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(open(tmp_path / "ok_broadcast").read()) > 50
+
+
+def test_merge_rules_of_partial_aggregates():
+    from qurious_amd.exchange import merge_aggregate_exprs
+    merged = merge_aggregate_exprs(_aggs(col("rv", 3)), 2)
+    assert [type(m).__name__ for m in merged] == ["SumAggregateExpr", "SumAggregateExpr", "MinAggregateExpr", "MaxAggregateExpr"]
+    assert [m.expression().index for m in merged] == [2, 3, 4, 5]
+    with pytest.raises(q.UnsupportedError, match="AVG"):
+        merge_aggregate_exprs([q.AvgAggregateExpr(col("rv", 3), I64, pa.float64())], 1)
+
+
 def test_exchange_join_world2_gloo(tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()

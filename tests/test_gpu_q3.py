@@ -72,6 +72,32 @@ def test_q3_skewed_keys_match_oracle_and_report_table_occupancy(ctx, oracle, mon
     assert ctx.last_stats()["lds_occupancy"] == -1.0
 
 
+def test_broadcast_strategy_pieces_on_one_gpu(ctx, oracle):
+    """What the broadcast strategy does on every rank, checked on one GPU: (1) with a single process the distributed nodes are
+    the plain operators; (2) partial aggregates of two input halves, concatenated and merged with merge_aggregate_exprs on
+    the device, equal the aggregate of the whole input — for SUM / COUNT / MIN / MAX over Q3's join output."""
+    tabs = _q3_tables(0.01)
+    plain = queries.q3(*tabs)
+    dist_plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
+    assert sorted(rows_of(dist_plan.execute())) == sorted(rows_of(plain.execute()))
+    j2 = plain.input
+    joined = j2.execute_device()
+    n = joined.num_rows
+    assert n > 100
+    dec = pa.decimal128(38, 4)
+    schema = pa.schema([pa.field("l_orderkey", I64), pa.field("rev", dec), pa.field("cnt", I64), pa.field("lo", pa.decimal128(15, 2)), pa.field("hi", pa.decimal128(15, 2))])
+    aggs = [plain.aggregate_exprs[0], q.CountAggregateExpr(col("l_discount", 9)), q.MinAggregateExpr(col("l_extendedprice", 8), pa.decimal128(15, 2)),
+            q.MaxAggregateExpr(col("l_extendedprice", 8), pa.decimal128(15, 2))]
+    keys = [col("l_orderkey", 6)]
+    src = exchange.DeviceSource(j2.schema(), joined)
+    whole = q.HashAggregate(schema, src, keys, aggs)
+    halves = [q.HashAggregate(schema, q.Limit(src, n // 2, 0), keys, aggs).execute_device(),
+              q.HashAggregate(schema, q.Limit(src, None, n // 2), keys, aggs).execute_device()]
+    both = exchange.concat_tables(halves)
+    merged = q.HashAggregate(schema, exchange.DeviceSource(schema, both), [col("l_orderkey", 0)], exchange.merge_aggregate_exprs(aggs, 1))
+    assert sorted(rows_of(merged.execute())) == sorted(rows_of(whole.execute())) == sorted(rows_of(oracle.execute(q.HashAggregate(schema, j2, keys, aggs))))
+
+
 def test_q1_order_by_flags(ctx, oracle):
     li = synth.lineitem(200_000, batch_rows=65_536)
     plan = queries.q1_full_ordered(q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, li))
