@@ -111,7 +111,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (ms * 1e-3) / 1e9 / world
     cpu_baseline = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         from oracle import qoracle
         sf_small = min(args.sf, 0.05)
         cs, os_, ls = synth.q3_tables(sf_small)
@@ -294,7 +294,7 @@ def main():
             traffic = None
 
     cpu_baseline = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run item (rank 0 at N = 1 only)
         from oracle import qoracle
         n = min(args.cpu_sample_rows, args.rows)
         sample = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, table.data[: max(1, n // args.batch_rows)])
