@@ -156,7 +156,10 @@ void ExprGen::emit(int k, std::string& out) {
         o << "    const int " << v << " = 0;\n";
       } else {
         field(ctype(n.type), v);
-        ld << "    " << (raw_ ? "" : "const " + ctype(n.type) + " ") << W << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
+        if (nt_ && !raw_ && n.type.id != QHIP_DECIMAL128)
+          ld << "    const " << ctype(n.type) << " " << v << " = __builtin_nontemporal_load(&((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "]);\n";
+        else
+          ld << "    " << (raw_ ? "" : "const " + ctype(n.type) + " ") << W << v << " = ((const " << ctype(n.type) << "*)a.c[" << S << "].v" << base_ << ")[" << idx_ << "];\n";
         if (raw_) o << "    const " << ctype(n.type) << " " << v << " = w." << v << ";\n";
       }
       if (n.nullable) {
@@ -767,6 +770,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
+  g.set_streaming_loads(probe_kernel && getenv("QHIP_PROBE_NO_NT") == nullptr);
   std::string code, all;
   if (predicate_root >= 0) {
     // scan filter fused into the key evaluation: a row the predicate rejects gets an invalid key, i.e. it is never

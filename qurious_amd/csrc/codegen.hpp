@@ -34,6 +34,9 @@ class ExprGen {
   // raw mode: column loads are collected into `load_code` (branch-free, writes fields of `Raw w`) and the expression code
   // only aliases those fields, so a kernel can issue the loads of several rows before any row's (branchy) computation
   void set_raw_mode(bool on) { raw_ = on; }
+  // fixed-width column values are read with streaming (non-temporal) loads: they are used once and should not push a
+  // kernel's random-access working set (join table, hash filter) out of L2
+  void set_streaming_loads(bool on) { nt_ = on; }
   void mark_utf8_key(int node, int words) { utf8_key_words_[node] = words; }
   bool raw_key_prefetched(int node) const { return raw_ && utf8_key_words_.count(node) > 0; }
   std::string raw_fields, load_code;
@@ -49,6 +52,7 @@ class ExprGen {
   std::vector<bool> done_;
   std::string base_ = "", idx_ = "i", row_ = "i";
   bool raw_ = false;
+  bool nt_ = false;
   std::map<int, int> utf8_key_words_;
 };
 
