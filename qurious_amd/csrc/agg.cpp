@@ -252,9 +252,122 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   uint32_t G = 0, guess = 0;
   std::vector<uint64_t> slots;
   // dense slots fetched together with the status words (one sync), through the context's page-locked scratch
-  const uint32_t PRE = (uint32_t)std::min<size_t>(256, (ctx->pinned_bytes - 64 - 8) / (size_t)slot_bytes);
+  const uint32_t PRE = (uint32_t)std::min<size_t>(256, (ctx->pinned_bytes - 64 - 8 - 1024) / (size_t)slot_bytes);
   uint32_t* status_pinned = (uint32_t*)ctx->pinned;
   uint64_t* pre_host = (uint64_t*)((uint8_t*)ctx->pinned + 64);
+  uint32_t* fin_pinned = (uint32_t*)((uint8_t*)ctx->pinned + ctx->pinned_bytes - 1024);   // [status words (8) | null counts (<= 248)]
+
+  // ---- output assembly on the device for many groups (k_agg_finalize): nothing but a few counters crosses PCIe.
+  // enqueue: allocate the output columns for up to `cap_rows` groups and launch; the number of groups is either known
+  // (g_dev == nullptr) or read by the kernel from the compaction counter (speculative launch right behind the compaction,
+  // so that a repeated many-group query needs ONE synchronisation). finish: after the stream has been synchronised.
+  struct DevFinal {
+    std::unique_ptr<qhip_table> out;
+    std::vector<FinCol> fc;
+    DevBuf fc_dev, nulls_dev;
+    std::vector<std::shared_ptr<DevBuf>> valid_bufs;
+    bool has_utf8 = false;
+  };
+  const int cell0 = 1 + plan.W;
+  auto enqueue_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t cap_rows, const uint32_t* g_dev) {
+    const int ncols = n_groups + n_aggs;
+    F.fc.assign((size_t)ncols, FinCol());
+    F.out.reset(new qhip_table());
+    F.out->ctx = ctx;
+    F.out->names = names;
+    F.out->nullable = nullable;
+    const size_t vwords = ((size_t)cap_rows + 63) / 64 + 1;
+    for (int k = 0; k < ncols; ++k) {
+      FinCol& f = F.fc[(size_t)k];
+      memset(&f, 0, sizeof f);
+      f.cnt_word = -1; f.key_index = -1; f.src_word = 0;
+      DevColumn col;
+      if (k < n_groups) {
+        const KeyDesc& kd = plan.keys[(size_t)k];
+        col.type = kd.type;
+        f.src_word = 1 + kd.word_off;
+        f.key_index = (plan.null_mask_word && kd.nullable) ? k : -1;
+        if (kd.type.id == QHIP_UTF8) { f.kind = F_KEY_UTF8_LEN; f.width = 4; f.pad = kd.words; F.has_utf8 = true; }
+        else if (kd.type.id == QHIP_DECIMAL128) { f.kind = F_KEY_DEC; f.width = 16; }
+        else { f.kind = F_KEY_FIXED; f.width = dtype_width(kd.type); }
+      } else {
+        const AggDesc& ad = plan.aggs[(size_t)(k - n_groups)];
+        col.type = ad.ret;
+        const int cntw = cell0 + plan.cells[(size_t)ad.count_cell].off;
+        f.src_word = ad.value_cell >= 0 ? cell0 + plan.cells[(size_t)ad.value_cell].off : 0;
+        f.width = dtype_width(ad.ret);
+        switch (ad.kind) {
+          case QHIP_AGG_COUNT: f.kind = F_COUNT; f.cnt_word = cntw; f.width = 8; break;
+          case QHIP_AGG_SUM: f.kind = ad.ret.id == QHIP_DECIMAL128 ? F_SUM128 : F_SUM64; f.cnt_word = cntw; break;
+          case QHIP_AGG_AVG:
+            f.cnt_word = cntw;
+            if (ad.ret.id == QHIP_FLOAT64) f.kind = F_AVG_F64;
+            else {
+              const DType& at = plan.args[(size_t)ad.arg].type;
+              if (ad.ret.scale < at.scale) fail(QHIP_EXEC_ERROR, "Internal error: Arithmetic Overflow in DecimalAvgAccumulator");
+              const i128 mul = pow10_i128(ad.ret.scale - at.scale), lim = pow10_i128(ad.ret.precision);
+              f.kind = F_AVG_DEC;
+              f.mul_lo = (uint64_t)(u128)mul; f.mul_hi = (uint64_t)((u128)mul >> 64);
+              f.lim_lo = (uint64_t)(u128)lim; f.lim_hi = (uint64_t)((u128)lim >> 64);
+            }
+            break;
+          default:
+            f.is_min = ad.kind == QHIP_AGG_MIN;
+            if (ad.ret.id == QHIP_DECIMAL128) f.kind = F_MM_DEC;
+            else if (ad.ret.id == QHIP_FLOAT64) f.kind = F_MM_F64;
+            else if (ad.ret.id == QHIP_FLOAT32) f.kind = F_MM_F32;
+            else { f.kind = F_MM_INT; f.is_signed = dtype_is_signed(ad.ret) || ad.ret.id == QHIP_DATE32 || ad.ret.id == QHIP_DATE64; }
+        }
+      }
+      col.values = std::make_shared<DevBuf>(f.kind == F_KEY_UTF8_LEN ? ((size_t)cap_rows + 1) * 4 : (size_t)cap_rows * f.width);
+      auto vb = std::make_shared<DevBuf>(vwords * 8);
+      f.out_values = col.values->ptr;
+      f.out_valid = vb->as<uint64_t>();
+      F.valid_bufs.push_back(vb);
+      F.out->cols.push_back(std::move(col));
+    }
+    F.fc_dev.alloc(F.fc.size() * sizeof(FinCol));
+    F.nulls_dev.alloc((size_t)ncols * 4);
+    QHIP_HIP_CHECK(hipMemcpyAsync(F.fc_dev.ptr, F.fc.data(), F.fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
+    QHIP_HIP_CHECK(hipMemsetAsync(F.nulls_dev.ptr, 0, (size_t)ncols * 4, ctx->stream));
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+    launch_agg_finalize(dense, cap_rows, g_dev, plan.slot_words, plan.null_mask_word ? 1 : 0, (const FinCol*)F.fc_dev.ptr, ncols,
+                        F.nulls_dev.as<uint32_t>(), ctx->status.as<uint32_t>(), ctx->stream);
+    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned + QS_WORDS, F.nulls_dev.ptr, (size_t)ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
+  };
+  // (call after the stream has been synchronised at least up to the read-backs above)
+  auto finish_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t groups) -> qhip_table* {
+    const int ncols = n_groups + n_aggs;
+    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (fin_pinned[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
+    F.out->num_rows = groups;
+    F.out->batch_offsets = {0, (int64_t)groups};
+    for (int k = 0; k < ncols; ++k) {
+      DevColumn& col = F.out->cols[(size_t)k];
+      col.length = groups;
+      col.null_count = fin_pinned[QS_WORDS + k];
+      if (col.null_count > 0) col.validity = F.valid_bufs[(size_t)k];
+      if (F.fc[(size_t)k].kind == F_KEY_UTF8_LEN) {
+        // lengths -> offsets (exclusive scan) -> bytes
+        uint32_t* off = col.values->as<uint32_t>();
+        DevBuf total(4);
+        exclusive_scan_u32(off, off, groups, total.as<uint32_t>(), ctx->stream);
+        uint32_t nbytes = 0;
+        copy_sync(ctx->stream, &nbytes, total.ptr, 4, hipMemcpyDeviceToHost);
+        QHIP_HIP_CHECK(hipMemcpyAsync(off + groups, total.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        col.data = std::make_shared<DevBuf>((size_t)nbytes);
+        col.data_bytes = nbytes;
+        launch_agg_utf8_key_bytes(dense, groups, plan.slot_words, F.fc[(size_t)k].src_word, off, col.data->as<uint8_t>(), ctx->stream);
+      }
+    }
+    if (F.has_utf8) QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the dense slots are released on return
+    return F.out.release();
+  };
+
+  const uint32_t dev_threshold = (uint32_t)env_int("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", 4096);
+  DevFinal spec;                    // speculative device-side assembly enqueued behind the compaction
+  bool spec_enqueued = false;
   uint64_t* table_dev = nullptr;
   uint64_t* dense_dev = nullptr;    // [counter | dense slots]
   for (;;) {
@@ -321,6 +434,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
         const uint32_t pre = std::min(PRE, guess);
         QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, dense.ptr, 8 + (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        // a plan that produced many groups last time will most likely do so again: assemble its output columns on the
+        // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all
+        bool utf8_key = false;
+        for (auto& kd : plan.keys) utf8_key = utf8_key || kd.type.id == QHIP_UTF8;
+        spec_enqueued = false;
+        if (replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0) {
+          spec = DevFinal();
+          enqueue_device_finalize(spec, dense_dev + 1, guess, dense.as<uint32_t>());
+          spec_enqueued = true;
+        }
       }
     }
     if (use_arena) {
@@ -349,7 +472,6 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const bool lds_spilled = status[QS_LDS_SPILL] != 0;
   // ---- dense slots -> host (few groups) or kept on the device (many groups)
   DevBuf dense_keep;                                   // [counter | dense slots] when the output is assembled on the device
-  const uint32_t dev_threshold = (uint32_t)env_int("QHIP_AGG_DEVICE_FINALIZE_MIN_GROUPS", 4096);
   if (plan.W == 0) {
     G = 1;
     slots.assign(pre_host, pre_host + plan.slot_words);
@@ -364,6 +486,25 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       dense_dev = dense.as<uint64_t>();
       launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
+      // the speculative device-side assembly is the result
+      plan.last_groups = G;
+      qhip_table* result = finish_device_finalize(spec, dense_dev + 1, G);
+      ctx->stats.main_kernel_ms = main_ms;
+      ctx->stats.total_device_ms = main_ms;
+      ctx->stats.rows_in = N;
+      ctx->stats.rows_out = G;
+      ctx->stats.groups = G;
+      ctx->stats.table_capacity = (int64_t)cap * replicas;
+      ctx->stats.retries = retries;
+      ctx->stats.lds_table_slots = (int32_t)l_nslots;
+      ctx->stats.workgroups = (int32_t)grid;
+      ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
+      ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
+      ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
+      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+      return result;
     }
     if (replicas == 1 && G >= dev_threshold) {
       dense_keep = std::move(dense);
@@ -439,100 +580,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
     snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
   };
-  const int cell0 = 1 + plan.W;
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe
-    const uint64_t* dense = dense_keep.as<uint64_t>() + 1;
-    const int ncols = n_groups + n_aggs;
-    std::vector<FinCol> fc((size_t)ncols);
-    std::unique_ptr<qhip_table> out(new qhip_table());
-    out->ctx = ctx;
-    out->names = names;
-    out->nullable = nullable;
-    out->num_rows = G;
-    out->batch_offsets = {0, (int64_t)G};
-    const size_t vwords = ((size_t)G + 63) / 64 + 1;
-    std::vector<std::shared_ptr<DevBuf>> valid_bufs;
-    for (int k = 0; k < ncols; ++k) {
-      FinCol& f = fc[(size_t)k];
-      memset(&f, 0, sizeof f);
-      f.cnt_word = -1; f.key_index = -1; f.src_word = 0;
-      DevColumn col;
-      col.length = G;
-      if (k < n_groups) {
-        const KeyDesc& kd = plan.keys[(size_t)k];
-        col.type = kd.type;
-        f.src_word = 1 + kd.word_off;
-        f.key_index = (plan.null_mask_word && kd.nullable) ? k : -1;
-        if (kd.type.id == QHIP_UTF8) { f.kind = F_KEY_UTF8_LEN; f.width = 4; f.pad = kd.words; }
-        else if (kd.type.id == QHIP_DECIMAL128) { f.kind = F_KEY_DEC; f.width = 16; }
-        else { f.kind = F_KEY_FIXED; f.width = dtype_width(kd.type); }
-      } else {
-        const AggDesc& ad = plan.aggs[(size_t)(k - n_groups)];
-        col.type = ad.ret;
-        const int cntw = cell0 + plan.cells[(size_t)ad.count_cell].off;
-        f.src_word = ad.value_cell >= 0 ? cell0 + plan.cells[(size_t)ad.value_cell].off : 0;
-        f.width = dtype_width(ad.ret);
-        switch (ad.kind) {
-          case QHIP_AGG_COUNT: f.kind = F_COUNT; f.cnt_word = cntw; f.width = 8; break;
-          case QHIP_AGG_SUM: f.kind = ad.ret.id == QHIP_DECIMAL128 ? F_SUM128 : F_SUM64; f.cnt_word = cntw; break;
-          case QHIP_AGG_AVG:
-            f.cnt_word = cntw;
-            if (ad.ret.id == QHIP_FLOAT64) f.kind = F_AVG_F64;
-            else {
-              const DType& at = plan.args[(size_t)ad.arg].type;
-              if (ad.ret.scale < at.scale) fail(QHIP_EXEC_ERROR, "Internal error: Arithmetic Overflow in DecimalAvgAccumulator");
-              const i128 mul = pow10_i128(ad.ret.scale - at.scale), lim = pow10_i128(ad.ret.precision);
-              f.kind = F_AVG_DEC;
-              f.mul_lo = (uint64_t)(u128)mul; f.mul_hi = (uint64_t)((u128)mul >> 64);
-              f.lim_lo = (uint64_t)(u128)lim; f.lim_hi = (uint64_t)((u128)lim >> 64);
-            }
-            break;
-          default:
-            f.is_min = ad.kind == QHIP_AGG_MIN;
-            if (ad.ret.id == QHIP_DECIMAL128) f.kind = F_MM_DEC;
-            else if (ad.ret.id == QHIP_FLOAT64) f.kind = F_MM_F64;
-            else if (ad.ret.id == QHIP_FLOAT32) f.kind = F_MM_F32;
-            else { f.kind = F_MM_INT; f.is_signed = dtype_is_signed(ad.ret) || ad.ret.id == QHIP_DATE32 || ad.ret.id == QHIP_DATE64; }
-        }
-      }
-      col.values = std::make_shared<DevBuf>(f.kind == F_KEY_UTF8_LEN ? ((size_t)G + 1) * 4 : (size_t)G * f.width);
-      auto vb = std::make_shared<DevBuf>(vwords * 8);
-      f.out_values = col.values->ptr;
-      f.out_valid = vb->as<uint64_t>();
-      valid_bufs.push_back(vb);
-      out->cols.push_back(std::move(col));
-    }
-    DevBuf fc_dev(fc.size() * sizeof(FinCol)), nulls_dev((size_t)ncols * 4);
-    QHIP_HIP_CHECK(hipMemcpyAsync(fc_dev.ptr, fc.data(), fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
-    QHIP_HIP_CHECK(hipMemsetAsync(nulls_dev.ptr, 0, (size_t)ncols * 4, ctx->stream));
-    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
-    launch_agg_finalize(dense, G, plan.slot_words, plan.null_mask_word ? 1 : 0, (const FinCol*)fc_dev.ptr, ncols, nulls_dev.as<uint32_t>(),
-                        ctx->status.as<uint32_t>(), ctx->stream);
-    std::vector<uint32_t> nulls((size_t)ncols);
-    QHIP_HIP_CHECK(hipMemcpyAsync(nulls.data(), nulls_dev.ptr, (size_t)ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
-    copy_sync(ctx->stream, status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost);
-    if (status[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
-    for (int k = 0; k < ncols; ++k) {
-      DevColumn& col = out->cols[(size_t)k];
-      col.null_count = nulls[(size_t)k];
-      if (col.null_count > 0) col.validity = valid_bufs[(size_t)k];
-      if (fc[(size_t)k].kind == F_KEY_UTF8_LEN) {
-        // lengths -> offsets (exclusive scan) -> bytes
-        uint32_t* off = col.values->as<uint32_t>();
-        DevBuf total(4);
-        exclusive_scan_u32(off, off, G, total.as<uint32_t>(), ctx->stream);
-        uint32_t nbytes = 0;
-        copy_sync(ctx->stream, &nbytes, total.ptr, 4, hipMemcpyDeviceToHost);
-        QHIP_HIP_CHECK(hipMemcpyAsync(off + G, total.ptr, 4, hipMemcpyDeviceToDevice, ctx->stream));
-        col.data = std::make_shared<DevBuf>((size_t)nbytes);
-        col.data_bytes = nbytes;
-        launch_agg_utf8_key_bytes(dense, G, plan.slot_words, fc[(size_t)k].src_word, off, col.data->as<uint8_t>(), ctx->stream);
-      }
-    }
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // dense_keep is released on return
+    DevFinal fin;
+    enqueue_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, nullptr);
+    qhip_table* result = finish_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G);
     set_stats();
-    return out.release();
+    return result;
   }
 
   // ---- few groups: assemble the output columns on the host (GroupAccumulator::output, hash.rs:89-107; accumulator evaluate())

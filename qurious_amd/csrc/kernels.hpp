@@ -73,8 +73,8 @@ struct FinCol {
   void* out_values;     // device
   uint64_t* out_valid;  // device, one ballot word per 64 groups
 };
-void launch_agg_finalize(const uint64_t* dense, uint32_t G, int slot_words, int null_mask_word, const FinCol* cols_dev, int ncols,
-                         uint32_t* null_counts, uint32_t* status, hipStream_t s);
+void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_dev,
+                         int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s);
 void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
                                hipStream_t s);
 }  // namespace qhip

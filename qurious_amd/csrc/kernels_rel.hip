@@ -446,8 +446,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64
 // Used when there are too many groups to finish on the host (Q3: ~10^5 groups at SF10).
 __device__ __forceinline__ double qh_ord_to_f64(u64 k) { return qh_ord_f64(k); }
 
-__global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32 G, int slot_words, int null_mask_word, const FinCol* cols,
-                                                          int ncols, u32* null_counts, u32* status) {
+__global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32 G_cap, const u32* g_dev, int slot_words, int null_mask_word,
+                                                          const FinCol* cols, int ncols, u32* null_counts, u32* status) {
+  // g_dev: the group count is still on the device (speculative launch behind the compaction); never beyond the capacity
+  const u32 G = g_dev ? (*g_dev < G_cap ? *g_dev : G_cap) : G_cap;
   const u64 nwords = ((u64)G + 63) / 64;
   const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
   const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
@@ -656,11 +658,11 @@ void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t npar
   DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n, QH_BLOCK * 16, 1024)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
 }
 
-void launch_agg_finalize(const uint64_t* dense, uint32_t G, int slot_words, int null_mask_word, const FinCol* cols_dev, int ncols,
-                         uint32_t* null_counts, uint32_t* status, hipStream_t s) {
-  if (!G) return;
-  hipLaunchKernelGGL(k_agg_finalize, dim3(grid_for(((uint64_t)G + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u64*)dense, G, slot_words,
-                     null_mask_word, cols_dev, ncols, (u32*)null_counts, (u32*)status);
+void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_dev,
+                         int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s) {
+  if (!G_cap) return;
+  hipLaunchKernelGGL(k_agg_finalize, dim3(grid_for(((uint64_t)G_cap + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u64*)dense, G_cap, (const u32*)g_dev,
+                     slot_words, null_mask_word, cols_dev, ncols, (u32*)null_counts, (u32*)status);
 }
 void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
                                hipStream_t s) {
