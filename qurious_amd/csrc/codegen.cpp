@@ -887,8 +887,8 @@ void plan_sort_keys(const ExprSet& es, const std::vector<InputCol>& input, const
   std::ostringstream s;
   s << "struct P {\n  static constexpr int NW = " << out.NW << ";\n  static constexpr int NK = " << n << ";\n";
   s << "  __device__ static __forceinline__ void images(const KArgs& a, const i64 i, u64* img, u32& valid, u32& err) {\n" << body.str() << "  }\n};\n";
-  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_sort_keys(KArgs a, u64* img, u64* keyvalid, u32* status) { "
-       "qh_sort_keys_body<P>(a, img, keyvalid, status); }\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_sort_keys(KArgs a, u64* img, u64* keyvalid, u64* diff, u32* status) { "
+       "qh_sort_keys_body<P>(a, img, keyvalid, diff, status); }\n";
   out.source = s.str();
   out.kernel_name = "qk_sort_keys";
   out.bind = g.bind;

@@ -49,22 +49,27 @@ qhip_table* sort_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, i
   launch_iota_u32(idx->as<uint32_t>(), N, s);
   if (N > 1 && n_keys > 0) {
     const uint64_t nwords = (N + 63) / 64;
-    DevBuf img((size_t)std::max(1, plan.NW) * N * 8), keyvalid((size_t)n_keys * nwords * 8 + 8);
+    DevBuf img((size_t)std::max(1, plan.NW) * N * 8), keyvalid((size_t)n_keys * nwords * 8 + 8), diff_dev((size_t)std::max(1, plan.NW) * 8);
+    std::vector<uint64_t> diff((size_t)std::max(1, plan.NW), ~0ULL);   // bits in which the rows differ, per image word
     {
       std::shared_ptr<Module> mod = get_module(ctx, plan.source, plan.kernel_name);
       HKArgs ka;
       DevBuf strlit;
       fill_kargs(ctx, in, plan.bind, ka, strlit);
       QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
+      QHIP_HIP_CHECK(hipMemsetAsync(diff_dev.ptr, 0, diff_dev.bytes, s));
       void* ip = img.ptr;
       void* vp = keyvalid.ptr;
+      void* dp = diff_dev.ptr;
       void* sp = ctx->status.ptr;
-      void* args[] = {&ka, &ip, &vp, &sp};
+      void* args[] = {&ka, &ip, &vp, &dp, &sp};
       const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
       uint32_t st[QS_WORDS];
+      if (plan.NW > 0) QHIP_HIP_CHECK(hipMemcpyAsync(diff.data(), diff_dev.ptr, (size_t)plan.NW * 8, hipMemcpyDeviceToHost, s));
       copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);
       check_status_words(st);
+      if (env_int("QHIP_SORT_FULL_PASSES", 0)) std::fill(diff.begin(), diff.end(), ~0ULL);
     }
     auto idx2 = std::make_shared<DevBuf>((N + 1) * 4);
     DevBuf key_a((N + 1) * 8), key_b((N + 1) * 8);
@@ -99,7 +104,11 @@ qhip_table* sort_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, i
         }
       } else {
         for (int w = 0; w < kd.words; ++w) {
-          const int bits = w == kd.words - 1 ? kd.top_bits : 64;
+          // only the bits in which some rows differ can change the order (NULL rows carry image 0: the XOR with row 0's
+          // image covers them); a word all rows agree on needs no pass at all
+          const uint64_t dw = diff[(size_t)(kd.word_off + w)];
+          if (dw == 0) continue;
+          const int bits = std::min(w == kd.words - 1 ? kd.top_bits : 64, 64 - __builtin_clzll(dw));
           const uint64_t mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1);
           launch_sort_gather_img(img.as<uint64_t>() + (size_t)(kd.word_off + w) * N, idx->as<uint32_t>(), N, desc ? mask : 0, key_a.as<uint64_t>(), s);
           pass(bits);
