@@ -102,6 +102,9 @@ std::shared_ptr<Module> get_module(Ctx* ctx, const std::string& policy_source, c
   auto m = std::make_shared<Module>();
   QHIP_HIP_CHECK(hipModuleLoadData(&m->mod, code.data()));
   QHIP_HIP_CHECK(hipModuleGetFunction(&m->fn, m->mod, kernel_name.c_str()));
+  // a long-lived context that keeps seeing new plans does not keep every code object loaded for ever: beyond 512 modules
+  // the in-memory cache starts over (callers hold shared_ptrs to what they are running; the disk cache still has the rest)
+  if (ctx->modules.size() >= 512) ctx->modules.clear();
   ctx->modules[policy_source] = m;
   ctx->stats.jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return m;
