@@ -246,6 +246,7 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ctx->modules.clear();
+  ctx->plan_cache.clear();
   ctx->status.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);

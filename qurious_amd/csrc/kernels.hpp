@@ -33,6 +33,7 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
                               uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s);
+void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s);
 void launch_pair_indices(uint32_t* minor, uint32_t* major, uint64_t n, uint32_t n_minor, uint32_t minor0, uint32_t major0, int unused, hipStream_t s);
 void launch_count_bits(const uint64_t* words, uint64_t nbits, uint32_t* out, hipStream_t s);
 void launch_sort_gather_img(const uint64_t* img, const uint32_t* idx, uint64_t n, uint64_t flip, uint64_t* out, hipStream_t s);

