@@ -14,8 +14,13 @@ Prints ONE JSON line on rank 0: value = rows/s of the whole job, plus
   roofline     — algorithmic bytes (25 B/row) / mean device time of the dominant kernel (HIP events on
                  the library's stream) vs the 8 TB/s HBM peak; `traffic` = PMC-measured HBM bytes per launch when a
                  profile summary for this round exists under profiles/ (else null)
+                 `stream_read_GBps` = a plain streaming-read kernel timed in the same run (the achievable ceiling)
   cpu_baseline — the CPU oracle's faithful-cost restatement of the reference executor (oracle/qoracle.c, 1 thread)
-                 timed on a bounded sample of the same workload on this box's host cores.
+                 timed on a bounded sample of the same workload on this box's host cores (single-GPU runs only).
+  extra        — (N = 1, default workload) the other single-GPU configurations: Q1's aggregate list and Q3 at SF10.
+
+Other workloads: --workload q1_full | q3 [--sf S] [--skew 1.1] ; q3 with N > 1 shards the tables over the ranks and joins
+them with --strategy broadcast (all-gather the small build sides, default) or repartition (all-to-all both sides by key).
 """
 import argparse
 import json
