@@ -1,5 +1,6 @@
 // ctx.cpp — context lifecycle, dtype helpers, device buffers.
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -288,7 +289,7 @@ int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double
     QHIP_HIP_CHECK(hipSetDevice(ctx->device));
     DevBuf buf((size_t)bytes), sink(4);
     QHIP_HIP_CHECK(hipMemsetAsync(buf.ptr, 1, (size_t)bytes, ctx->stream));
-    const unsigned blocks = (unsigned)ctx->num_cus * 8;
+    const unsigned blocks = (unsigned)ctx->num_cus * (unsigned)std::max(1, env_int("QHIP_STREAM_BLOCKS_PER_CU", 8));
     launch_stream_read(buf.ptr, (uint64_t)bytes, sink.as<uint32_t>(), blocks, ctx->stream);
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[2], ctx->stream));
     for (int k = 0; k < iters; ++k) launch_stream_read(buf.ptr, (uint64_t)bytes, sink.as<uint32_t>(), blocks, ctx->stream);
