@@ -353,8 +353,8 @@ int qhip_sort_execute(qhip_ctx* ctx, const qhip_table* in, const qhip_expr* expr
 int qhip_limit_execute(qhip_ctx* ctx, const qhip_table* in, int64_t skip, int64_t fetch, qhip_table** out);
 
 /* ---------------------------------------------------------------- measurement aid (SURVEY §8d "achievable-copy ceiling") */
-/* Reads `bytes` of a scratch HBM buffer with a plain 16-byte-per-lane streaming kernel (`iters` timed launches after
- * one warm-up) and returns the achieved read bandwidth in GB/s: the practical ceiling the filter+aggregate kernel's
+/* Reads `bytes` of a scratch HBM buffer with a plain 16-byte-per-lane streaming kernel (non-temporal loads, the fastest
+ * variant found on MI355X; `iters` timed launches after one warm-up) and returns the achieved read bandwidth in GB/s: the practical ceiling the filter+aggregate kernel's
  * roofline fraction can be compared with, next to the 8 TB/s data-sheet peak. */
 int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double* gb_per_s);
 

@@ -65,7 +65,7 @@ void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned 
   const char* uv = getenv("QHIP_STREAM_UNROLL");
   const char* nv = getenv("QHIP_STREAM_NT");
   const int U = uv ? atoi(uv) : 1;
-  const bool nt = nv && *nv == '1';
+  const bool nt = !(nv && *nv == '0');   // non-temporal loads by default: the fastest plain reader found (tools/stream_sweep.py)
 #define LAUNCH(UU, NN) hipLaunchKernelGGL((k_stream_read<UU, NN>), dim3(blocks), dim3(QH_BLOCK), 0, s, (const qh_v4u*)p, (u64)(bytes / 16), sink)
   if (U >= 8) { if (nt) LAUNCH(8, true); else LAUNCH(8, false); }
   else if (U >= 4) { if (nt) LAUNCH(4, true); else LAUNCH(4, false); }
