@@ -148,8 +148,17 @@ void ExprGen::emit(int k, std::string& out) {
           auto it = utf8_key_words_.find(k);
           if (it != utf8_key_words_.end()) {
             field("u64", "k" + K + "[" + std::to_string(it->second) + "]");
-            for (int w2 = 0; w2 < it->second; ++w2)
-              ld << "    w.k" << K << "[" << w2 << "] = *(const qh_u64_unaligned*)(a.c[" << S << "].d + w.b" << K << " + " << 8 * w2 << ");\n";
+            // key bytes: 8 at a time — or just as many as the column's longest value has (Q1's flags are 1 byte: a 1-byte
+            // load per row instead of 64 overlapping 8-byte windows per wavefront)
+            const int maxlen = in_[(size_t)n.column].utf8_max_len;
+            for (int w2 = 0; w2 < it->second; ++w2) {
+              const std::string at = "(a.c[" + S + "].d + w.b" + K + " + " + std::to_string(8 * w2) + ")";
+              const int left = maxlen >= 0 ? maxlen - 8 * w2 : 8;
+              if (it->second == 1 && left <= 1) ld << "    w.k" << K << "[0] = (u64)*(const u8*)" << at << ";\n";
+              else if (it->second == 1 && left <= 2) ld << "    w.k" << K << "[0] = (u64)*(const qh_u16_unaligned*)" << at << ";\n";
+              else if (it->second == 1 && left <= 4) ld << "    w.k" << K << "[0] = (u64)*(const qh_u32_unaligned*)" << at << ";\n";
+              else ld << "    w.k" << K << "[" << w2 << "] = *(const qh_u64_unaligned*)" << at << ";\n";
+            }
           }
           o << "    const int l" << K << " = w.l" << K << "; const u8* p" << K << " = a.c[" << S << "].d + w.b" << K << ";\n";
         } else {

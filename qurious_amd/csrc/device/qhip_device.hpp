@@ -67,6 +67,8 @@ __device__ __forceinline__ double qh_ord_f64(u64 k) { u64 b = (k >> 63) ? (k & 0
 // Branch-free: one unaligned 8-byte load (every Utf8 data buffer is allocated with >= 8 bytes of slack), masked to
 // the value's length; a loop of byte loads would put control flow between the loads of a tile's rows.
 typedef u64 __attribute__((aligned(1))) qh_u64_unaligned;
+typedef u32 __attribute__((aligned(1))) qh_u32_unaligned;
+typedef u16 __attribute__((aligned(1))) qh_u16_unaligned;
 __device__ __forceinline__ u64 qh_pack_str7(const u8* p, int len) {
   const u64 raw = *(const qh_u64_unaligned*)p;
   const int l = len > 7 ? 7 : len;
