@@ -172,8 +172,9 @@ def extra_single_gpu(args, ctx, table):
         km = sum(ks) / len(ks)
         out["q1_full"] = {"workload": f"configs[2] TPC-H Q1 (2 keys, 8 aggregates) over {args.rows} resident lineitem rows",
                           "rows_per_s": args.rows / dt, "ms_per_step": dt * 1e3, "kernel_ms": km,
-                          "roofline_GBps": args.rows * ALGO_BYTES_PER_ROW["q1_full"] / (km * 1e-3) / 1e9,
-                          "roofline_frac": args.rows * ALGO_BYTES_PER_ROW["q1_full"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          "kernel_bytes_per_row": min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78),
+                          "roofline_GBps": args.rows * min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78) / (km * 1e-3) / 1e9,
+                          "roofline_frac": args.rows * min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS}
         log(f"extra q1_full: kernel {km:.3f} ms")
         c, o, l = synth.q3_tables(10.0)
         tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
@@ -293,7 +294,9 @@ def main():
     total_rows = args.rows * world
     value = total_rows * args.steps / elapsed
     mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    bpr = ALGO_BYTES_PER_ROW[args.workload]
+    # SURVEY §8d's algorithmic bytes per row for the Arrow layout as uploaded — unless the kernel reads FEWER bytes (it
+    # skips the offsets of a Utf8 column whose every value is 1 byte long): the roofline is computed from what is read
+    bpr = min(ALGO_BYTES_PER_ROW[args.workload], stats.get("bytes_per_row_read") or ALGO_BYTES_PER_ROW[args.workload])
     achieved = args.rows * bpr / (mean_kernel_ms * 1e-3) / 1e9
     traffic = None
     prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -346,7 +349,7 @@ def main():
                    "resident_bytes_per_gpu": resident, "parallelism": f"replicated-shards x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": stats["main_kernel_name"], "kernel_ms": mean_kernel_ms,
-                     "algorithmic_bytes_per_row": bpr,
+                     "algorithmic_bytes_per_row": ALGO_BYTES_PER_ROW[args.workload], "kernel_bytes_per_row": bpr,
                      # the achievable ceiling measured with a plain 16 B/lane streaming-read kernel, same run
                      "stream_read_GBps": stream_ceiling,
                      "frac_of_stream_read": (achieved / stream_ceiling) if stream_ceiling else None},

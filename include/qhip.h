@@ -173,6 +173,9 @@ typedef struct qhip_exec_stats {
   double hbm_table_load;     /* groups / table_capacity of the attempt that succeeded */
   int32_t lds_spilled;       /* 1 = some keys bypassed the LDS table (it was full around their home slot) */
   int32_t workgroups;        /* grid size of the dominant kernel */
+  double bytes_per_row_read; /* aggregate: bytes of column data the fused kernel reads per input row (value, offset and data
+                              * buffers of the columns its expressions reference; the offsets of a Utf8 column whose every
+                              * value is 1 byte long are not read) — what a roofline figure must be computed from */
 } qhip_exec_stats;
 
 /* ---------------------------------------------------------------- context */

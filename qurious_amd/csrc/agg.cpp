@@ -163,7 +163,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   // typing and code generation; literal VALUES are part of the key because they are bound into the plan's KernelBindings
   std::string key = "agg|";
   auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
-  for (auto& ic : icols) { const int v[5] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len}; put(v, sizeof v); }
+  for (auto& ic : icols) { const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0}; put(v, sizeof v); }
   for (int k = 0; k < n_exprs; ++k) {
     qhip_expr e = exprs[k];
     const char* str = e.lit_str; const int64_t len = e.lit_len;
@@ -213,6 +213,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   mark("module + kargs");
 
   const int64_t N = in->num_rows;
+  // bytes of column data the kernel reads per row (for roofline figures)
+  double bytes_per_row = 0;
+  for (int c : plan.bind.cols) {
+    const DevColumn& dc = in->cols[(size_t)c];
+    const int w = dtype_width(dc.type);
+    if (w > 0) bytes_per_row += w;
+    else if (dc.type.id == QHIP_BOOL) bytes_per_row += 0.125;
+    else if (dc.type.id == QHIP_UTF8) bytes_per_row += icols[(size_t)c].utf8_fixed1 ? 1.0 : 4.0 + (N > 0 ? (double)dc.data_bytes / (double)N : 0.0);
+    if (dc.null_count > 0) bytes_per_row += 0.125;
+  }
   const int slot_bytes = plan.slot_words * 8;
   // LDS-staged table: as many slots as fit the per-workgroup LDS budget
   uint32_t l_nslots = 0;
@@ -499,6 +509,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       ctx->stats.table_capacity = (int64_t)cap * replicas;
       ctx->stats.retries = retries;
       ctx->stats.lds_table_slots = (int32_t)l_nslots;
+      ctx->stats.bytes_per_row_read = bytes_per_row;
       ctx->stats.workgroups = (int32_t)grid;
       ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
       ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
@@ -574,6 +585,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.table_capacity = (int64_t)cap * replicas;
     ctx->stats.retries = retries;
     ctx->stats.lds_table_slots = (int32_t)l_nslots;
+    ctx->stats.bytes_per_row_read = bytes_per_row;
     ctx->stats.workgroups = (int32_t)grid;
     ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;

@@ -139,7 +139,11 @@ void ExprGen::emit(int k, std::string& out) {
       auto field = [&](const std::string& type, const std::string& name) { if (raw_) raw_fields += "    " + type + " " + name + ";\n"; };
       if (n.type.id == QHIP_UTF8) {
         field("int", "b" + K); field("int", "l" + K);
-        {
+        if (in_[(size_t)n.column].utf8_fixed1) {
+          // every value is exactly one byte: offsets[i] == i, no offset loads, the data byte is addressed by row number
+          ld << "    " << (raw_ ? "" : "const int ") << W << "b" << K << " = (int)(" << row_ << ");\n";
+          ld << "    " << (raw_ ? "" : "const int ") << W << "l" << K << " = 1;\n";
+        } else {
           const std::string o0 = "((const int*)a.c[" + S + "].v" + base_ + ")[" + idx_ + "]", o1 = "((const int*)a.c[" + S + "].v" + base_ + ")[" + idx_ + " + 1]";
           ld << "    " << (raw_ ? "" : "const int ") << W << "b" << K << " = " << (nt_ ? "__builtin_nontemporal_load(&" + o0 + ")" : o0) << ";\n";
           ld << "    " << (raw_ ? "" : "const int ") << W << "l" << K << " = " << (nt_ ? "__builtin_nontemporal_load(&" + o1 + ")" : o1) << " - " << W << "b" << K << ";\n";
@@ -154,7 +158,7 @@ void ExprGen::emit(int k, std::string& out) {
             for (int w2 = 0; w2 < it->second; ++w2) {
               const std::string at = "(a.c[" + S + "].d + w.b" + K + " + " + std::to_string(8 * w2) + ")";
               const int left = maxlen >= 0 ? maxlen - 8 * w2 : 8;
-              if (it->second == 1 && left <= 1) ld << "    w.k" << K << "[0] = (u64)*(const u8*)" << at << ";\n";
+              if (it->second == 1 && left <= 1) ld << "    w.k" << K << "[0] = (u64)" << (nt_ ? "__builtin_nontemporal_load((const u8*)" + at + ")" : "*(const u8*)" + at) << ";\n";
               else if (it->second == 1 && left <= 2) ld << "    w.k" << K << "[0] = (u64)*(const qh_u16_unaligned*)" << at << ";\n";
               else if (it->second == 1 && left <= 4) ld << "    w.k" << K << "[0] = (u64)*(const qh_u32_unaligned*)" << at << ";\n";
               else ld << "    w.k" << K << "[" << w2 << "] = *(const qh_u64_unaligned*)" << at << ";\n";

@@ -26,6 +26,7 @@ struct InputCol {
   DType type;
   bool has_nulls = false;  // null_count > 0 in the table actually being executed
   int utf8_max_len = -1;   // longest value of a Utf8 column in bytes when known (sizes packed join / group keys)
+  bool utf8_fixed1 = false;   // every value of the Utf8 column is exactly 1 byte long: offsets[i] == i, nothing to load for them
 };
 
 struct ExprSet {

@@ -65,6 +65,9 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
       col.utf8_max_len = (int32_t)v;
     }
     icols[(size_t)e.column].utf8_max_len = col.utf8_max_len;
+    // longest value 1 byte and as many data bytes as rows: every value (NULL slots included) is exactly 1 byte, so the
+    // (rebased) offsets are 0, 1, 2, ... and a kernel can address the data bytes by row number — Q1's flag columns
+    icols[(size_t)e.column].utf8_fixed1 = col.utf8_max_len == 1 && col.data_bytes == col.length && getenv("QHIP_NO_FIXED1") == nullptr;
   }
 }
 

@@ -26,6 +26,8 @@ def main():
     for wl in ("q1_mini", "q1_full"):
         bench = json.loads(open(os.path.join(SRC, f"bench_{wl}.json")).read().strip().splitlines()[-1])
         rows = bench["config"]["rows_per_gpu"]
+        # bytes the kernel reads per row (the SURVEY §8d figure, or less when it skips the offsets of 1-byte Utf8 columns)
+        bpr = bench["roofline"].get("kernel_bytes_per_row", ALGO[wl])
         fetch, write = counter_rows(wl, "FETCH_SIZE"), counter_rows(wl, "WRITE_SIZE")
         # keep the launches over the full table (warm-up + timed + verification), drop the small CPU-sample launches
         big = max(int(r["Grid_Size"]) for r in fetch)
@@ -36,10 +38,11 @@ def main():
         us = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in fetch) / len(fetch) / 1e3
         hbm = fkb * 1024 * 2 + wkb * 1024
         summary[wl] = {
-            "rows": rows, "algorithmic_bytes": rows * ALGO[wl], "FETCH_SIZE_KB_raw": fkb, "WRITE_SIZE_KB_raw": wkb,
+            "rows": rows, "survey_bytes_per_row": ALGO[wl], "kernel_bytes_per_row": bpr, "algorithmic_bytes": rows * bpr,
+            "FETCH_SIZE_KB_raw": fkb, "WRITE_SIZE_KB_raw": wkb,
             "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md §HBM); WRITE_SIZE exact; "
                           "separate --pmc passes",
-            "hbm_bytes_per_launch": hbm, "traffic_over_algorithmic": hbm / (rows * ALGO[wl]), "kernel_us_under_pmc": us,
+            "hbm_bytes_per_launch": hbm, "traffic_over_algorithmic": hbm / (rows * bpr), "kernel_us_under_pmc": us,
             "launches": len(fetch),
             "command": "tools/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py "
                        "--workload ... --steps 3 --warmup 1)"}
