@@ -696,8 +696,12 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
             }
           } else {
             uint64_t o = is_min ? ~vc[0] : vc[0];
-            uint64_t raw = dtype_is_signed(t) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 ? (o ^ 0x8000000000000000ULL) : o;
-            memcpy(hc.values.data() + (size_t)g * dtype_width(t), &raw, (size_t)dtype_width(t));
+            const bool sgn = dtype_is_signed(t) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64;
+            uint64_t raw = sgn ? (o ^ 0x8000000000000000ULL) : o;
+            const int w = dtype_width(t);
+            // no non-null value seen (an all-zero cell): the seed of the column's OWN type (i32::MAX, not i64::MAX truncated)
+            if (vc[0] == 0 && sgn && w < 8) raw = is_min ? ((1ULL << (8 * w - 1)) - 1) : (1ULL << (8 * w - 1));
+            memcpy(hc.values.data() + (size_t)g * w, &raw, (size_t)w);
           }
           break;
         }

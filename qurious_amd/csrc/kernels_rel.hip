@@ -492,7 +492,14 @@ __global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32
           lo = (u64)(u128)q; hi = (u64)((u128)q >> 64);
           break;
         }
-        case F_MM_INT: { const u64 o = fc.is_min ? ~w0 : w0; lo = fc.is_signed ? (o ^ 0x8000000000000000ULL) : o; valid = live; break; }
+        case F_MM_INT: {
+          const u64 o = fc.is_min ? ~w0 : w0;
+          lo = fc.is_signed ? (o ^ 0x8000000000000000ULL) : o;
+          // no non-null value seen (all-zero cell): the seed of the column's own type (i32::MAX, not i64::MAX truncated)
+          if (w0 == 0 && fc.is_signed && fc.width < 8) lo = fc.is_min ? ((1ULL << (8 * fc.width - 1)) - 1) : (1ULL << (8 * fc.width - 1));
+          valid = live;
+          break;
+        }
         case F_MM_F64:
         case F_MM_F32: {
           // PrimitiveAccumulator seeded with NATIVE::MAX / MIN and PartialOrd merging (aggregate/mod.rs:60-84, min.rs:12-28)

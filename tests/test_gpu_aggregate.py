@@ -72,6 +72,25 @@ def test_null_torture_1m_rows(ctx, oracle):
     _same(agg, oracle)
 
 
+def test_min_max_of_all_null_groups_yield_the_types_own_seed(ctx, oracle):
+    """PrimitiveAccumulator is seeded with NATIVE::MAX / MIN (aggregate/mod.rs:60-84): a group whose values are all NULL
+    reports the seed of the column's own type — i32::MAX for MIN(Int32), not a truncated i64::MAX (found by tools/fuzz_plans.py)"""
+    k = pa.array([1, 1, 2, 2, 3], type=I64)
+    cols = {"k": k, "i32": pa.array([None, None, 5, -7, None], type=pa.int32()), "i16": pa.array([None, None, 5, -7, None], type=pa.int16()),
+            "d32": pa.array([None, None, 9000, 9001, None], type=pa.int32()).cast(pa.date32()), "i64": pa.array([None, None, 5, -7, None], type=I64)}
+    schema = pa.schema([pa.field(n, a.type, True) for n, a in cols.items()])
+    scan = table_scan(schema, [pa.RecordBatch.from_arrays(list(cols.values()), schema=schema)])
+    aggs = []
+    for idx, (name, arr) in enumerate(list(cols.items())[1:], start=1):
+        aggs += [q.MinAggregateExpr(col(name, idx), arr.type), q.MaxAggregateExpr(col(name, idx), arr.type)]
+    for plan in (q.HashAggregate(None, scan, [col("k", 0)], aggs),):
+        got = {r[0]: r[1:] for r in rows_of([b.cast(pa.schema([pa.field(f.name, pa.int32() if pa.types.is_date32(f.type) else f.type) for f in b.schema])) for b in plan.execute()])}
+        want = {r[0]: r[1:] for r in rows_of([b.cast(pa.schema([pa.field(f.name, pa.int32() if pa.types.is_date32(f.type) else f.type) for f in b.schema])) for b in oracle.execute(plan)])}
+        assert got == want
+        assert got[1] == (2**31 - 1, -2**31, 2**15 - 1, -2**15, 2**31 - 1, -2**31, 2**63 - 1, -2**63)
+        assert got[2] == (-7, 5, -7, 5, 9000, 9001, -7, 5)
+
+
 def test_group_by_int64_with_nulls_and_expr_keys(ctx, oracle):
     rng = np.random.default_rng(3)
     n = 20000
