@@ -88,13 +88,17 @@ def random_aggregate(rng, input_plan, schema, p):
             q.SumAggregateExpr(q.CaseExpr([(q.BinaryExpr(c("i"), Operator.Gt, q.Literal(S.Int32(0))), c("d"))], q.CastExpr(q.Literal(S.Int64(0)), DEC)), DEC)]
     aggs = [pool[int(k)] for k in rng.choice(len(pool), size=int(rng.integers(1, 5)), replace=False)]
     if not keys:
+        # documented divergence: ungrouped MIN / MAX of floats when a batch holds a NaN depends on the batch
+        # boundaries in the reference (that batch's contribution is discarded); not fuzzed
+        aggs = [a for a in aggs if not (isinstance(a, (q.MinAggregateExpr, q.MaxAggregateExpr)) and pa.types.is_floating(a._return_type()))] or [pool[1]]
         return q.NoGroupingAggregate(None, input_plan, aggs), True
     return q.HashAggregate(None, input_plan, [c(k) for k in keys], aggs), True
 
 
 def random_plan(rng):
-    nl, nr = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))
-    nkeys = int(rng.choice([3, 40, 2000]))
+    big = rng.random() < 0.2          # now and then: enough rows and groups for the device-side output assembly (>= 4096 groups)
+    nl, nr = (int(rng.integers(50_000, 200_000)), int(rng.integers(20_000, 100_000))) if big else (int(rng.integers(0, 3000)), int(rng.integers(0, 3000)))
+    nkeys = int(rng.choice([20_000, 60_000])) if big else int(rng.choice([3, 40, 2000]))
     ls, lb = make_table(rng, "l_", nl, nkeys)
     rs, rb = make_table(rng, "r_", nr, nkeys)
     kind = int(rng.integers(0, 5))
@@ -116,6 +120,8 @@ def random_plan(rng):
             fschema = pa.schema([pa.field("l_i", pa.int32()), pa.field("r_i", pa.int32())])
             jf = q.JoinFilter(q.BinaryExpr(q.Column("l_i", 0), Operator.LtEq, q.Column("r_i", 1)), [(ls.get_field_index("l_i"), JoinSide.Left), (rs.get_field_index("r_i"), JoinSide.Right)], fschema)
         left, right = scan_of(rng, ls, lb, "l_"), scan_of(rng, rs, rb, "r_")
+        if big and jt in (JoinType.Left, JoinType.Right, JoinType.Full, JoinType.Inner) and len(on) == 1 and "flag" in str(on[0][0]):
+            on = [(col(ls, "l_k"), col(rs, "r_k"))]   # a 3-value key over 10^5 x 10^5 rows would produce billions of pairs
         if kind == 4 and rng.random() < 0.5 and nl * nr < 2_000_000:
             plan = q.NestedLoopJoinExec.try_new(left, right, jt, jf)
         else:
