@@ -101,7 +101,7 @@ def random_plan(rng):
     nkeys = int(rng.choice([20_000, 60_000])) if big else int(rng.choice([3, 40, 2000]))
     ls, lb = make_table(rng, "l_", nl, nkeys)
     rs, rb = make_table(rng, "r_", nr, nkeys)
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 7))
     unordered = False
     if kind == 0:   # aggregate over a (possibly filtered, possibly lazily uploaded) scan
         plan, unordered = random_aggregate(rng, scan_of(rng, ls, lb, "l_", lazy=rng.random() < 0.3), ls, "l_")
@@ -111,6 +111,18 @@ def random_plan(rng):
             c = lambda name: col(ls, "l_" + name)   # noqa: E731
             plan = q.Projection(None, plan, [c("flag"), q.BinaryExpr(c("d"), Operator.Div, c("d")), q.Negative(c("i")), q.IsNull(c("s")),
                                               q.CaseExpr([(c("b"), c("f"))], q.Literal(S.Float64(0.5)))])
+    elif kind == 5:  # ORDER BY (several keys of every type, top-N) straight over a scan, then maybe a window
+        names = [str(x) for x in rng.choice(["d", "f", "s", "flag", "day", "i", "k", "b"], size=int(rng.integers(1, 4)), replace=False)]
+        keys = [q.PhysicalSortExpr(col(ls, "l_" + name), q.SortOptions(bool(rng.random() < 0.5), bool(rng.random() < 0.5))) for name in names]
+        plan = q.Sort(keys, scan_of(rng, ls, lb, "l_", lazy=rng.random() < 0.3), int(rng.integers(0, 200)) if rng.random() < 0.5 else None)
+        if rng.random() < 0.5:
+            plan = q.Limit(plan, int(rng.integers(0, 100)), int(rng.integers(0, 30)))
+    elif kind == 6:  # cross join of two small inputs, aggregated or as is
+        a = scan_of(rng, ls, [b.slice(0, min(b.num_rows, 40)) for b in lb[:2]], "l_")
+        b2 = scan_of(rng, rs, [b.slice(0, min(b.num_rows, 30)) for b in rb[:3]], "r_")
+        plan = q.CrossJoin(a, b2)
+        if rng.random() < 0.5:
+            plan, unordered = random_aggregate(rng, plan, plan.schema(), "l_")
     else:            # join, then something on top
         jt = JoinType(int(rng.integers(0, 6)))
         on_sets = [[("k", "k")], [("flag", "flag")], [("k", "k"), ("flag", "flag")], [("s", "s")], [("day", "day"), ("k", "k")]]
