@@ -58,6 +58,8 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+USE_DIST = False   # set by main(): a torch.distributed process group (RCCL) is up
+
 Q3_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}   # SURVEY §8(d) algorithmic bytes per row
 
 
@@ -73,11 +75,11 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     log(f"generated SF{args.sf} slice {rows} rows in {time.time() - t0:.1f}s")
     for t in tabs:
         t.device_table()
-    if world > 1 and args.strategy == "broadcast":
+    if USE_DIST and args.strategy == "broadcast":
         # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
         plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
     else:
-        plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if world > 1 else None)
+        plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if USE_DIST else None)
     for _ in range(args.warmup):
         out = plan.execute_device()
         log(f"warmup step: {out.num_rows} groups")
@@ -88,7 +90,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if USE_DIST:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -107,10 +109,9 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         table_stats = {"lds_table_slots_per_workgroup": st["lds_table_slots"], "lds_occupancy": st["lds_occupancy"],
                        "lds_spilled": bool(st["lds_spilled"]), "hbm_table_slots": st["table_capacity"], "hbm_table_load": st["hbm_table_load"],
                        "groups": st["groups"], "workgroups": st["workgroups"]}
-    xgmi = exchange.exchange_stats() if world > 1 else None
+    xgmi = exchange.exchange_stats() if USE_DIST else None
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     algo_bytes = rows_all[0] * Q3_BYTES["customer"] + rows_all[1] * Q3_BYTES["orders"] + rows_all[2] * Q3_BYTES["lineitem"]
     ms = elapsed / args.steps * 1e3
@@ -136,7 +137,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i128", "data": "synthetic",
         "config": {"workload": f"configs[3] q3: TPC-H Q3 SF{args.sf} customer|><|orders|><|lineitem + GROUP BY, HBM-resident, "
                                f"lineitem rows/s", "rows": {"customer": rows_all[0], "orders": rows_all[1], "lineitem": rows_all[2]},
-                   "groups": rows_all[3], "parallelism": (f"broadcast build sides, local probes, merged partial groups x{world}" if world > 1 and args.strategy == "broadcast"
+                   "groups": rows_all[3], "parallelism": (f"broadcast build sides, local probes, merged partial groups x{world}" if USE_DIST and args.strategy == "broadcast"
                                    else f"hash-partitioned joins x{world}")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "q3 pipeline (all kernels of one query, per GPU)", "kernel_ms": ms,
@@ -150,7 +151,7 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
     if xgmi:
         line["exchange"] = xgmi   # bytes this rank sent over xGMI and the time spent in the exchanges, per query
     print(json.dumps(line))
-    if world > 1:
+    if USE_DIST:
         dist.destroy_process_group()
 
 
@@ -225,11 +226,17 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # QHIP_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL process group, collectives, exchange operators) even
+    # with ONE rank — the rehearsal of the N > 1 launch that fits a one-GPU box (tests/test_gpu_q3.py runs it)
+    global USE_DIST
+    USE_DIST = world > 1 or os.environ.get("QHIP_BENCH_FORCE_DIST") == "1"
+    if USE_DIST:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if USE_DIST:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,7 +267,7 @@ def main():
     ctx.synchronize()   # the result table of the last step is ordered on libqhip's stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if USE_DIST:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -270,15 +277,14 @@ def main():
     # ---- verification of the whole-job result (outside the timed region)
     result = plan.execute()
     partial = result_key(result)
-    if world > 1:
+    if USE_DIST:
         gathered = [None] * world
         dist.all_gather_object(gathered, partial)
     else:
         gathered = [partial]
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     merged = {}
@@ -361,7 +367,7 @@ def main():
         # the other two single-GPU configurations of BASELINE.json, reported beside the headline (not part of `value`)
         line["extra"] = extra_single_gpu(args, ctx, table)
     print(json.dumps(line))
-    if world > 1:
+    if USE_DIST:
         dist.destroy_process_group()
 
 

@@ -290,6 +290,21 @@ typedef struct qhip_device_column {
 int qhip_table_from_device(qhip_ctx* ctx, const char* const* names, const qhip_device_column* cols,
                            int32_t n_cols, int64_t n_rows, qhip_table** out);
 
+/* Wire image of a table: ONE contiguous device buffer per (source, destination) pair, so that an exchange is one small
+ * metadata round plus one payload round whatever the number of columns. Sections in column order — values (or utf8
+ * offsets / Boolean bits), validity, utf8 data — each aligned to 16 bytes. The image has no header: both sides derive
+ * the layout from the schema and the table's metadata words
+ *     meta[0] = rows, meta[1] = image bytes, meta[2 + 2c] = null count of column c, meta[3 + 2c] = its utf8 data bytes
+ * (n_meta = 2 + 2 * columns), which travel in the metadata round.
+ * qhip_table_pack writes the image into caller-owned device memory (e.g. a torch tensor) and returns once it is complete.
+ * qhip_table_unpack_concat builds the concatenation, in the order given, of the tables n images describe (one batch per
+ * image); it has copied what it needs when it returns. No reference counterpart (the reference is a single process). */
+int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta);
+int qhip_table_pack(qhip_ctx* ctx, const qhip_table* t, void* device_dst, int64_t dst_bytes);
+int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols,
+                             const int64_t* metas /* n x (2 + 2 * n_cols) */, const void* const* device_images,
+                             int32_t n, qhip_table** out);
+
 /* ---------------------------------------------------------------- plan-only entry points (no GPU needed) */
 /* Return (snprintf-style; *needed = bytes incl. NUL) the policy source libqhip instantiates the kernel
  * templates of csrc/device/qhip_device.hpp with, for an input whose column c has type col_types[c] and

@@ -59,10 +59,72 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   }
 }
 
+// One destination column assembled from n source sections on the device (shared by qhip_table_concat and the unpacking of
+// the exchange's wire images): fixed-width values are D2D copies, bitmaps are appended bit-exactly at any bit position
+// (k_bits_append), Utf8 offsets are copied and rebased by the bytes already placed (every device Utf8 column's offsets
+// start at 0: uploads rebase them and every other column is a gather). Nothing goes through the host.
+struct ColumnSection {
+  int64_t rows = 0, null_count = 0, data_bytes = 0;
+  const void* values = nullptr;     // fixed-width values | int32 offsets (rows + 1) | Boolean bits
+  const void* validity = nullptr;   // bitmap or null (no NULLs in this section)
+  const void* data = nullptr;       // utf8 bytes
+};
+
+DevColumn assemble_column(Ctx* ctx, DType type, const std::vector<ColumnSection>& secs) {
+  hipStream_t s = ctx->stream;
+  DevColumn oc;
+  oc.type = type;
+  int64_t N = 0, nulls = 0, bytes = 0;
+  for (const auto& sc : secs) { N += sc.rows; nulls += sc.null_count; bytes += sc.data_bytes; }
+  oc.length = N;
+  oc.null_count = nulls;
+  if (type.id == QHIP_NULL) { oc.null_count = N; return oc; }
+  const int w = dtype_width(type);
+  auto bitmap = [&](bool values) {
+    auto b = std::make_shared<DevBuf>((size_t)((N + 63) / 64) * 8 + 8);
+    QHIP_HIP_CHECK(hipMemsetAsync(b->ptr, 0, b->bytes, s));
+    int64_t pos = 0;
+    for (const auto& sc : secs) {
+      const void* src = values ? sc.values : sc.validity;
+      if (values && !src && sc.rows) fail(QHIP_INVALID_ARGUMENT, "Boolean column section without a values buffer");
+      launch_bits_append(b->as<uint32_t>(), (uint64_t)pos, (const uint8_t*)src, (uint64_t)sc.rows, s);
+      pos += sc.rows;
+    }
+    return b;
+  };
+  if (nulls > 0) oc.validity = bitmap(false);
+  if (w > 0) {
+    oc.values = std::make_shared<DevBuf>((size_t)N * w);
+    int64_t pos = 0;
+    for (const auto& sc : secs) {
+      if (sc.rows) QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)oc.values->ptr + (size_t)pos * w, sc.values, (size_t)sc.rows * w, hipMemcpyDeviceToDevice, s));
+      pos += sc.rows;
+    }
+  } else if (type.id == QHIP_BOOL) {
+    oc.values = bitmap(true);
+  } else if (type.id == QHIP_UTF8) {
+    if (bytes > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB");
+    oc.values = std::make_shared<DevBuf>((size_t)(N + 1) * 4);
+    oc.data = std::make_shared<DevBuf>((size_t)bytes);
+    oc.data_bytes = bytes;
+    QHIP_HIP_CHECK(hipMemsetAsync(oc.values->ptr, 0, 4, s));   // N == 0, or leading empty sections: offsets[0] = 0
+    int64_t pos = 0, bpos = 0;
+    for (const auto& sc : secs) {
+      if (!sc.rows) continue;
+      // rows + 1 offsets: the last one lands on the next section's first slot, which that section rewrites with the same value
+      QHIP_HIP_CHECK(hipMemcpyAsync(oc.values->as<int32_t>() + pos, sc.values, (size_t)(sc.rows + 1) * 4, hipMemcpyDeviceToDevice, s));
+      launch_add_i32(oc.values->as<int32_t>() + pos, (uint64_t)sc.rows + 1, (int32_t)bpos, s);
+      if (sc.data_bytes) QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)oc.data->ptr + bpos, sc.data, (size_t)sc.data_bytes, hipMemcpyDeviceToDevice, s));
+      pos += sc.rows;
+      bpos += sc.data_bytes;
+    }
+  }
+  return oc;
+}
+
 qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   if (n <= 0) fail(QHIP_INVALID_ARGUMENT, "qhip_table_concat: no tables");
-  hipStream_t s = ctx->stream;
   const qhip_table* first = ts[0];
   std::unique_ptr<qhip_table> out(new qhip_table());
   out->ctx = ctx;
@@ -78,73 +140,130 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
   }
   out->num_rows = N;
   if (N >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
-  // concat by gathering through (table, row) -> the simple way that handles every layout incl. bitmaps: build for every
-  // source table an index vector and gather it into the destination range. Fixed-width columns use plain D2D copies.
   for (size_t c = 0; c < first->cols.size(); ++c) {
-    DevColumn oc;
-    oc.type = first->cols[c].type;
-    oc.length = N;
-    const int w = dtype_width(oc.type);
-    int64_t nulls = 0, bytes = 0;
+    std::vector<ColumnSection> secs((size_t)n);
     for (int k = 0; k < n; ++k) {
-      if (ts[k]->cols[c].type != oc.type) fail(QHIP_INVALID_ARGUMENT, "qhip_table_concat: column types differ");
-      nulls += ts[k]->cols[c].null_count;
-      bytes += ts[k]->cols[c].data_bytes;
+      const DevColumn& sc = ts[k]->cols[c];
+      if (sc.type != first->cols[c].type) fail(QHIP_INVALID_ARGUMENT, "qhip_table_concat: column types differ");
+      ColumnSection& o = secs[(size_t)k];
+      o.rows = sc.length;
+      o.null_count = sc.null_count;
+      o.data_bytes = sc.data_bytes;
+      o.values = sc.values ? sc.values->ptr : nullptr;
+      o.validity = sc.null_count > 0 && sc.validity ? sc.validity->ptr : nullptr;
+      o.data = sc.data ? sc.data->ptr : nullptr;
     }
-    oc.null_count = nulls;
-    if (oc.type.id == QHIP_NULL) { out->cols.push_back(oc); continue; }
-    if (w > 0) {
-      oc.values = std::make_shared<DevBuf>((size_t)N * w);
-      int64_t pos = 0;
-      for (int k = 0; k < n; ++k) {
-        const DevColumn& sc = ts[k]->cols[c];
-        if (sc.length) QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)oc.values->ptr + (size_t)pos * w, sc.values->ptr, (size_t)sc.length * w, hipMemcpyDeviceToDevice, s));
-        pos += sc.length;
-      }
-    }
-    // bitmaps (validity, Boolean values) and Utf8 go through the host: exchange outputs are concatenated once per query
-    auto concat_bits = [&](bool values) {
-      std::vector<uint8_t> host((size_t)((N + 7) / 8 + 8), 0);
-      int64_t pos = 0;
-      for (int k = 0; k < n; ++k) {
-        const DevColumn& sc = ts[k]->cols[c];
-        const std::shared_ptr<DevBuf>& src = values ? sc.values : sc.validity;
-        std::vector<uint8_t> tmp((size_t)((sc.length + 7) / 8 + 8), values ? 0 : 0xff);
-        if (src && sc.length) copy_sync(s, tmp.data(), src->ptr, (size_t)((sc.length + 7) / 8), hipMemcpyDeviceToHost);
-        for (int64_t i = 0; i < sc.length; ++i)
-          if ((tmp[(size_t)(i >> 3)] >> (i & 7)) & 1) host[(size_t)((pos + i) >> 3)] |= (uint8_t)(1u << ((pos + i) & 7));
-        pos += sc.length;
-      }
-      auto b = std::make_shared<DevBuf>(host.size());
-      copy_sync(s, b->ptr, host.data(), host.size(), hipMemcpyHostToDevice);
-      return b;
-    };
-    if (nulls > 0) oc.validity = concat_bits(false);
-    if (oc.type.id == QHIP_BOOL) oc.values = concat_bits(true);
-    if (oc.type.id == QHIP_UTF8) {
-      if (bytes > 0x7fffffffLL) fail(QHIP_UNSUPPORTED, "Utf8 column larger than 2 GiB");
-      std::vector<int32_t> off((size_t)N + 1, 0);
-      oc.data = std::make_shared<DevBuf>((size_t)bytes);
-      oc.data_bytes = bytes;
-      int64_t pos = 0, bpos = 0;
-      for (int k = 0; k < n; ++k) {
-        const DevColumn& sc = ts[k]->cols[c];
-        if (!sc.length) continue;
-        std::vector<int32_t> so((size_t)sc.length + 1);
-        copy_sync(s, so.data(), sc.values->ptr, so.size() * 4, hipMemcpyDeviceToHost);
-        for (int64_t i = 0; i < sc.length; ++i) off[(size_t)(pos + i)] = so[(size_t)i] - so[0] + (int32_t)bpos;
-        const int64_t nb = so[(size_t)sc.length] - so[0];
-        if (nb) QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)oc.data->ptr + bpos, (const uint8_t*)sc.data->ptr + so[0], (size_t)nb, hipMemcpyDeviceToDevice, s));
-        pos += sc.length;
-        bpos += nb;
-      }
-      off[(size_t)N] = (int32_t)bpos;
-      oc.values = std::make_shared<DevBuf>(off.size() * 4);
-      copy_sync(s, oc.values->ptr, off.data(), off.size() * 4, hipMemcpyHostToDevice);
-    }
-    out->cols.push_back(std::move(oc));
+    out->cols.push_back(assemble_column(ctx, first->cols[c].type, secs));
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(s));
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return out.release();
+}
+
+// ---- wire image of a table for the exchange: ONE contiguous buffer per (source, destination) pair, so an exchange is one
+// small metadata round plus one payload round whatever the number of columns. Sections in column order — values,
+// validity, utf8 data — each aligned to 16 bytes; both sides derive the layout from the schema and the table's metadata
+// words [rows, image bytes, (null_count, data_bytes) per column], so the image carries no header of its own.
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct WireColumn { size_t values_off = 0, values_bytes = 0, validity_off = 0, validity_bytes = 0, data_off = 0, data_bytes = 0; };
+
+size_t wire_layout(const std::vector<DType>& types, int64_t rows, const int64_t* col_meta, std::vector<WireColumn>& out) {
+  size_t pos = 0;
+  out.assign(types.size(), WireColumn());
+  for (size_t c = 0; c < types.size(); ++c) {
+    WireColumn& wc = out[c];
+    const int w = dtype_width(types[c]);
+    const int64_t nulls = col_meta[2 * c], dbytes = col_meta[2 * c + 1];
+    if (rows > 0 && types[c].id != QHIP_NULL) {
+      wc.values_bytes = w > 0 ? (size_t)rows * w : types[c].id == QHIP_BOOL ? (size_t)((rows + 7) / 8) : (size_t)(rows + 1) * 4;
+      wc.validity_bytes = nulls > 0 ? (size_t)((rows + 7) / 8) : 0;
+      wc.data_bytes = types[c].id == QHIP_UTF8 ? (size_t)dbytes : 0;
+    }
+    wc.values_off = pos; pos = align16(pos + wc.values_bytes);
+    wc.validity_off = pos; pos = align16(pos + wc.validity_bytes);
+    wc.data_off = pos; pos = align16(pos + wc.data_bytes);
+  }
+  return pos;
+}
+
+std::vector<DType> types_of(const qhip_table* t) {
+  std::vector<DType> out;
+  for (const auto& c : t->cols) out.push_back(c.type);
+  return out;
+}
+
+void table_wire_meta(Ctx* ctx, const qhip_table* t, int64_t* meta) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  resolve_all(ctx, t);   // every column travels; null counts are exact once gathered
+  meta[0] = t->num_rows;
+  for (size_t c = 0; c < t->cols.size(); ++c) {
+    meta[2 + 2 * c] = t->cols[c].validity ? t->cols[c].null_count : 0;
+    meta[3 + 2 * c] = t->cols[c].data_bytes;
+  }
+  std::vector<WireColumn> lay;
+  meta[1] = (int64_t)wire_layout(types_of(t), t->num_rows, meta + 2, lay);
+}
+
+void table_pack(Ctx* ctx, const qhip_table* t, void* dst, int64_t dst_bytes) {
+  std::vector<int64_t> meta(2 + 2 * t->cols.size());
+  table_wire_meta(ctx, t, meta.data());
+  if (dst_bytes < meta[1]) fail(QHIP_INVALID_ARGUMENT, "qhip_table_pack: destination smaller than the wire image");
+  std::vector<WireColumn> lay;
+  wire_layout(types_of(t), t->num_rows, meta.data() + 2, lay);
+  hipStream_t s = ctx->stream;
+  auto put = [&](size_t off, size_t nbytes, const std::shared_ptr<DevBuf>& src) {
+    if (!nbytes) return;
+    if (!src || src->bytes < nbytes) fail(QHIP_INVALID_ARGUMENT, "qhip_table_pack: column buffer missing or short");
+    QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)dst + off, src->ptr, nbytes, hipMemcpyDeviceToDevice, s));
+  };
+  for (size_t c = 0; c < t->cols.size(); ++c) {
+    put(lay[c].values_off, lay[c].values_bytes, t->cols[c].values);
+    put(lay[c].validity_off, lay[c].validity_bytes, t->cols[c].validity);
+    put(lay[c].data_off, lay[c].data_bytes, t->cols[c].data);
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(s));   // the transport reads the image on its own stream
+}
+
+qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int n_cols, const int64_t* metas,
+                                const void* const* images, int n) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  if (n <= 0 || n_cols < 0) fail(QHIP_INVALID_ARGUMENT, "qhip_table_unpack_concat: bad arguments");
+  std::vector<DType> types;
+  for (int c = 0; c < n_cols; ++c) types.push_back(DType(dtypes[c]));
+  const size_t M = 2 + 2 * (size_t)n_cols;
+  std::unique_ptr<qhip_table> out(new qhip_table());
+  out->ctx = ctx;
+  out->batch_offsets.push_back(0);
+  std::vector<std::vector<WireColumn>> lays((size_t)n);
+  int64_t N = 0;
+  for (int k = 0; k < n; ++k) {
+    const int64_t* m = metas + (size_t)k * M;
+    if (m[0] < 0 || (size_t)m[1] != wire_layout(types, m[0], m + 2, lays[(size_t)k]) || (m[1] > 0 && !images[k]))
+      fail(QHIP_INVALID_ARGUMENT, "qhip_table_unpack_concat: metadata does not describe the wire image");
+    N += m[0];
+    out->batch_offsets.push_back(N);   // one batch per peer, in rank order
+  }
+  if (N >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+  out->num_rows = N;
+  for (int c = 0; c < n_cols; ++c) {
+    std::vector<ColumnSection> secs((size_t)n);
+    for (int k = 0; k < n; ++k) {
+      const int64_t* m = metas + (size_t)k * M;
+      const WireColumn& wc = lays[(size_t)k][(size_t)c];
+      const uint8_t* base = (const uint8_t*)images[k];
+      ColumnSection& o = secs[(size_t)k];
+      o.rows = m[0];
+      o.null_count = types[(size_t)c].id == QHIP_NULL ? m[0] : m[2 + 2 * c];
+      o.data_bytes = (int64_t)wc.data_bytes;
+      o.values = wc.values_bytes ? base + wc.values_off : nullptr;
+      o.validity = wc.validity_bytes ? base + wc.validity_off : nullptr;
+      o.data = wc.data_bytes ? base + wc.data_off : nullptr;
+    }
+    out->cols.push_back(assemble_column(ctx, types[(size_t)c], secs));
+    out->names.push_back(names && names[c] ? names[c] : ("c" + std::to_string(c)));
+    out->nullable.push_back(true);
+  }
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the caller frees the images when this returns
   return out.release();
 }
 
@@ -202,6 +321,23 @@ int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n,
   if (!ctx || !tables || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
   return guarded(ctx, [&] { *out = table_concat(ctx, tables, n); });
+}
+
+int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta) {
+  if (!ctx || !t || !meta || n_meta != (int32_t)(2 + 2 * t->cols.size())) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] { table_wire_meta(ctx, t, meta); });
+}
+
+int qhip_table_pack(qhip_ctx* ctx, const qhip_table* t, void* device_dst, int64_t dst_bytes) {
+  if (!ctx || !t || (!device_dst && dst_bytes > 0)) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] { table_pack(ctx, t, device_dst, dst_bytes); });
+}
+
+int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols, const int64_t* metas,
+                             const void* const* device_images, int32_t n, qhip_table** out) {
+  if (!ctx || !metas || !device_images || !out || (n_cols > 0 && !dtypes)) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = table_unpack_concat(ctx, names, dtypes, n_cols, metas, device_images, n); });
 }
 
 int qhip_table_column_buffer(const qhip_table* t, int64_t col, int32_t which, void** device_ptr, int64_t* n_bytes) {

@@ -407,6 +407,29 @@ __global__ __launch_bounds__(QH_BLOCK) void k_add_i32(int* p, u64 n, int delta) 
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) p[i] += delta;
 }
 
+// Bitmap concatenation (validity / Boolean values of exchanged or concatenated tables): bits [0, nbits) of `src` (all ones
+// when src is null: a peer without NULLs ships no bitmap) are OR-ed into bits [dst_pos, dst_pos + nbits) of the zeroed
+// `dst`. One thread per destination word of the range; the sections of one destination are appended in stream order, so
+// the two boundary words shared with the neighbouring sections never race.
+__global__ __launch_bounds__(QH_BLOCK) void k_bits_append(u32* dst, u64 dst_pos, const unsigned char* src, u64 nbits) {
+  const u64 w = (dst_pos >> 5) + (u64)blockIdx.x * QH_BLOCK + threadIdx.x;
+  const u64 end = dst_pos + nbits;
+  if (w * 32 >= end) return;
+  const u64 lo = w * 32 > dst_pos ? w * 32 : dst_pos;
+  const u64 hi = w * 32 + 32 < end ? w * 32 + 32 : end;
+  const u32 cnt = (u32)(hi - lo);
+  const u32 mask = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+  u32 bits = mask;
+  if (src) {
+    const u64 sb = lo - dst_pos, b0 = sb >> 3, nbytes = (nbits + 7) >> 3;
+    u64 v = 0;
+    for (u32 j = 0; j < 5; ++j)
+      if (b0 + j < nbytes) v |= (u64)src[b0 + j] << (8 * j);
+    bits = (u32)(v >> (sb & 7)) & mask;
+  }
+  if (bits) dst[w] |= bits << (u32)(lo & 31);
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -623,6 +646,11 @@ void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint
 }
 void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s) {
   if (n && delta) hipLaunchKernelGGL(k_add_i32, dim3(grid_for(n, QH_BLOCK * 8, 1024)), dim3(QH_BLOCK), 0, s, (int*)p, (u64)n, (int)delta);
+}
+void launch_bits_append(uint32_t* dst, uint64_t dst_pos, const uint8_t* src, uint64_t nbits, hipStream_t s) {
+  if (!nbits) return;
+  const uint64_t words = ((dst_pos + nbits + 31) >> 5) - (dst_pos >> 5);
+  hipLaunchKernelGGL(k_bits_append, dim3((unsigned)((words + QH_BLOCK - 1) / QH_BLOCK)), dim3(QH_BLOCK), 0, s, (u32*)dst, (u64)dst_pos, (const unsigned char*)src, (u64)nbits);
 }
 void launch_pair_indices(uint32_t* minor, uint32_t* major, uint64_t n, uint32_t n_minor, uint32_t minor0, uint32_t major0, int, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_pair_indices, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)minor, (u32*)major, (u64)n, n_minor, minor0, major0);

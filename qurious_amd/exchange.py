@@ -36,6 +36,16 @@ def _dist():
     return dist
 
 
+def _exchange_world(dist) -> int:
+    """Ranks to exchange with; 0 = run the plain single-process operator. QHIP_EXCHANGE_FORCE=1 keeps the exchange steps
+    (partition, transport, rebuild, merge) in place for a ONE-rank group: the rehearsal that fits a one-GPU box."""
+    import os
+    if not dist.is_initialized():
+        return 0
+    world = dist.get_world_size()
+    return world if world > 1 or os.environ.get("QHIP_EXCHANGE_FORCE") == "1" else 0
+
+
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
 _STATS = {"bytes_sent": 0, "bytes_received": 0, "seconds": 0.0, "exchanges": 0}
 
@@ -49,10 +59,17 @@ def exchange_stats(reset: bool = True) -> dict:
     return out
 
 
-def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None) -> List["torch.Tensor"]:
+class _Received(list):
+    """the tensors received from every rank (a list), plus the metadata words that came with them (``.meta``)"""
+    meta: list = None
+
+
+def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None, meta: Optional[Sequence[Sequence[int]]] = None) -> List["torch.Tensor"]:
     """Variable-size all-to-all of uint8 tensors: send[r] goes to rank r, the result's entry r came from rank r.
-    Built from grouped point-to-point sends/receives (``batch_isend_irecv``: one ncclGroup of ncclSend/ncclRecv on RCCL,
-    plain pairs on gloo), sizes first. Works for CPU tensors over gloo and GPU tensors over RCCL alike."""
+    ``meta[r]`` (equal-length int lists, optional) rides with the size in the first round; the result's ``.meta[r]`` is
+    what rank r attached. Two rounds of grouped point-to-point sends/receives (``batch_isend_irecv``: one ncclGroup of
+    ncclSend/ncclRecv on RCCL — xGMI is point-to-point, every peer has its own link — plain pairs on gloo): sizes +
+    metadata, then payloads. Works for CPU tensors over gloo and GPU tensors over RCCL alike."""
     import time
     import torch
     dist = _dist()
@@ -61,19 +78,21 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None) -> List["torch.
     assert len(send) == world
     dev = send[0].device
     t_start = time.perf_counter()
-    sizes_out = [torch.tensor([s.numel()], dtype=torch.int64, device=dev) for s in send]
-    sizes_in = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    n_meta = len(meta[0]) if meta else 0
+    head_out = torch.tensor([[send[r].numel()] + (list(meta[r]) if meta else []) for r in range(world)], dtype=torch.int64).to(dev)
+    head_in = torch.zeros((world, 1 + n_meta), dtype=torch.int64, device=dev)
+    head_in[rank].copy_(head_out[rank])
     ops = []
     for r in range(world):
-        if r == rank:
-            sizes_in[r].copy_(sizes_out[r])
-            continue
-        ops.append(dist.P2POp(dist.isend, sizes_out[r], r, group))
-        ops.append(dist.P2POp(dist.irecv, sizes_in[r], r, group))
+        if r != rank:
+            ops.append(dist.P2POp(dist.isend, head_out[r], r, group))
+            ops.append(dist.P2POp(dist.irecv, head_in[r], r, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    recv = [torch.empty(int(sizes_in[r].item()), dtype=torch.uint8, device=dev) for r in range(world)]
+    heads = head_in.cpu().tolist()     # the one device -> host read of the exchange
+    recv = _Received(torch.empty(int(heads[r][0]), dtype=torch.uint8, device=dev) for r in range(world))
+    recv.meta = [h[1:] for h in heads]
     ops = []
     for r in range(world):
         if r == rank:
@@ -157,43 +176,41 @@ def _table_from_buffers(ctx, schema, rows: int, meta, bufs) -> DeviceTable:
     return DeviceTable(ctx, out)
 
 
-def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> DeviceTable:
-    """parts[r] is sent to rank r; returns the concatenation (in rank order) of what every rank sent to this one."""
+def pack_table(table: DeviceTable):
+    """(metadata words, uint8 device tensor): the wire image of `table` (qhip_table_pack, include/qhip.h)"""
     import torch
+    ctx = table.ctx
+    n_meta = 2 + 2 * table.num_columns
+    m = (C.c_int64 * n_meta)()
+    ctx.check(ctx.lib.qhip_table_wire_meta(ctx.handle, table.handle, m, n_meta))
+    img = torch.empty(int(m[1]), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    ctx.check(ctx.lib.qhip_table_pack(ctx.handle, table.handle, C.c_void_p(img.data_ptr() if img.numel() else None), img.numel()))
+    return list(m), img
+
+
+def unpack_concat(ctx, schema, metas, images) -> DeviceTable:
+    """The concatenation, in the order given, of the tables the wire images describe (qhip_table_unpack_concat)."""
+    ncols, n = len(schema), len(images)
+    metas_c = (C.c_int64 * ((2 + 2 * ncols) * n))(*[int(v) for m in metas for v in m])
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in images])
+    names = (C.c_char_p * max(1, ncols))(*[f.name.encode() for f in schema])
+    dtypes = (_ffi.qhip_dtype * max(1, ncols))(*[to_qhip_dtype(f.type) for f in schema])
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_table_unpack_concat(ctx.handle, names, dtypes, ncols, metas_c, ptrs, n, C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> DeviceTable:
+    """parts[r] is sent to rank r; returns the concatenation (in rank order) of what every rank sent to this one.
+
+    Every part travels as ONE wire image (all buffers of all columns in one allocation), so the exchange is two transport
+    rounds whatever the schema: the images' metadata words (which double as the sizes), then the images. The received
+    images are unpacked straight into the concatenated table."""
     dist = _dist()
-    world = dist.get_world_size(group)
-    assert len(parts) == world
-    ctx = parts[0].ctx
-    ncols = len(schema)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    ctx.synchronize()   # the parts were produced on libqhip's stream; RCCL reads them on torch's
-    # metadata: rows, then per column (null_count, data_bytes)
-    metas = []
-    for p in parts:
-        m = [p.num_rows]
-        for c in range(ncols):
-            n_null = C.c_int64(0)
-            # null counts are not exported separately: validity buffer present <=> nulls may exist; count recomputed by the receiver
-            bufs = _column_buffers(p, c)
-            m += [1 if bufs[1][1] else 0, bufs[2][1]]
-        metas.append(torch.tensor(m, dtype=torch.int64, device=dev).view(torch.uint8))
-    metas_in = [t.view(torch.int64).tolist() for t in all_to_all_bytes(metas, group)]
-    recv_bufs = [[[None, None, None] for _ in range(ncols)] for _ in range(world)]
-    for c in range(ncols):
-        for which in range(3):
-            send = []
-            for p in parts:
-                ptr, nb = _column_buffers(p, c)[which]
-                send.append(torch.as_tensor(_DevMem(ptr, nb), device=dev) if nb else torch.empty(0, dtype=torch.uint8, device=dev))
-            got = all_to_all_bytes(send, group)
-            for r in range(world):
-                recv_bufs[r][c][which] = got[r]
-    tables = []
-    for r in range(world):
-        rows = metas_in[r][0]
-        meta = [(rows if metas_in[r][1 + 2 * c] else 0, metas_in[r][2 + 2 * c]) for c in range(ncols)]
-        tables.append(_table_from_buffers(ctx, schema, rows, meta, recv_bufs[r]))
-    return concat_tables(tables)
+    assert len(parts) == dist.get_world_size(group)
+    packed = [pack_table(p) for p in parts]
+    got = all_to_all_bytes([img for _, img in packed], group, meta=[m for m, _ in packed])
+    return unpack_concat(parts[0].ctx, schema, got.meta, got)
 
 
 class DeviceSource(PhysicalPlan):
@@ -215,17 +232,13 @@ class DistributedHashJoinExec(HashJoinExec):
     (the north star asks for row-SET equality); inside a rank the reference's order holds."""
 
     def execute_device(self) -> DeviceTable:
-        dist = _dist()
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        if world <= 1:
+        world = _exchange_world(_dist())
+        if not world:
             return HashJoinExec.execute_device(self)
-        lt = self.left.execute_device()
-        rt = self.right.execute_device()
-        if world > 1:
-            lparts = partition_by_key(lt, [l for l, _ in self.on], world)
-            rparts = partition_by_key(rt, [r for _, r in self.on], world)
-            lt = exchange_device_tables(lparts, self.left.schema())
-            rt = exchange_device_tables(rparts, self.right.schema())
+        lparts = partition_by_key(self.left.execute_device(), [l for l, _ in self.on], world)
+        rparts = partition_by_key(self.right.execute_device(), [r for _, r in self.on], world)
+        lt = exchange_device_tables(lparts, self.left.schema())
+        rt = exchange_device_tables(rparts, self.right.schema())
         return self._join_tables(lt, rt)
 
     @staticmethod
@@ -236,8 +249,10 @@ class DistributedHashJoinExec(HashJoinExec):
 
 def all_gather_device_table(table: DeviceTable, schema, group=None) -> DeviceTable:
     """Every rank ends up with the concatenation (rank order) of all ranks' tables."""
-    dist = _dist()
-    return exchange_device_tables([table] * dist.get_world_size(group), schema, group)
+    world = _dist().get_world_size(group)
+    meta, img = pack_table(table)          # packed once, the same image goes to every peer
+    got = all_to_all_bytes([img] * world, group, meta=[meta] * world)
+    return unpack_concat(table.ctx, schema, got.meta, got)
 
 
 class BroadcastHashJoinExec(HashJoinExec):
@@ -247,9 +262,7 @@ class BroadcastHashJoinExec(HashJoinExec):
     output order holds; across ranks the result is the union."""
 
     def execute_device(self) -> DeviceTable:
-        dist = _dist()
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        if world <= 1:
+        if not _exchange_world(_dist()):
             return HashJoinExec.execute_device(self)
         if self.join_type not in (JoinType.Inner, JoinType.Right):
             return DistributedHashJoinExec.execute_device(self)
@@ -307,10 +320,9 @@ class DistributedHashAggregate(PhysicalPlan):
     def execute_device(self) -> DeviceTable:
         from .expr import Column
         from .plan import HashAggregate
-        dist = _dist()
-        world = dist.get_world_size() if dist.is_initialized() else 1
+        world = _exchange_world(_dist())
         part = self.partial.execute_device()
-        if world <= 1:
+        if not world:
             return part
         ng = len(self.group_exprs)
         pschema = self._schema if self._schema is not None else None

@@ -61,7 +61,9 @@ def _worker(rank, world, port, out_dir):
             mine = batch.slice(n * rank // world, n * (rank + 1) // world - n * rank // world)       # this rank's contiguous slice
             pid = qoracle.partition_ids([mine.column(key)], world)
             send = [torch.frombuffer(bytearray(_ipc(mine.filter(pa.array(pid == r)))), dtype=torch.uint8) for r in range(world)]
-            got = all_to_all_bytes(send)
+            # metadata words ride with the sizes in the first round (the wire images' layout words on the GPU path)
+            got = all_to_all_bytes(send, meta=[[rank, r, int(send[r].numel()) * 3] for r in range(world)])
+            assert got.meta == [[r, rank, int(got[r].numel()) * 3] for r in range(world)]
             parts = [_unipc(bytes(t.numpy().tobytes())) for t in got]
             sides.append((schema, pa.concat_batches(parts)))
         (ls2, lpart), (rs2, rpart) = sides

@@ -1,6 +1,7 @@
 """GPU parity: TPC-H Q3 pipeline (two hash joins + aggregate, everything device-resident between operators) and the
 single-GPU pieces of the multi-GPU exchange (partition by key, raw buffers, concat) vs the CPU oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -13,6 +14,7 @@ from .helpers import col, rows_of, table_scan
 
 pytestmark = pytest.mark.gpu
 I64 = pa.int64()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _q3_tables(sf):
@@ -142,6 +144,59 @@ def test_partition_by_key_matches_mirror_and_roundtrips(ctx, oracle):
         meta.append((part.num_rows if tens[1].numel() else 0, tens[2].numel()))
     rebuilt = exchange._table_from_buffers(ctx, schema, part.num_rows, meta, bufs)
     assert rows_of(rebuilt.to_batches()) == rows_of(part.to_batches())
+
+
+def test_wire_images_rebuild_the_concatenation(ctx, oracle):
+    """qhip_table_pack -> qhip_table_unpack_concat (what one exchange does with the parts it sends and receives): NULLs at
+    bit positions that are not byte-aligned, strings, booleans, decimals, empty parts and a part without any NULL"""
+    import decimal
+    rng = np.random.default_rng(77)
+    n = 10_007
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("d", pa.decimal128(15, 2)), pa.field("b", pa.bool_()),
+                        pa.field("i", pa.int32()), pa.field("z", pa.null())])
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(rng.integers(0, 5, n), type=I64),
+        pa.array(["v%d" % v if v % 7 else "" for v in rng.integers(0, 400, n)], type=pa.string(), mask=rng.random(n) < 0.2),
+        pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**8, 10**8, n)], type=pa.decimal128(15, 2), mask=rng.random(n) < 0.01),
+        pa.array(rng.random(n) < 0.5, type=pa.bool_(), mask=rng.random(n) < 0.3),
+        pa.array(rng.integers(-100, 100, n), type=pa.int32()),
+        pa.nulls(n)], schema=schema)
+    dev = table_scan(schema, [batch]).execute_device()
+    parts = exchange.partition_by_key(dev, [col("k", 0)], 16)        # 5 distinct keys -> most of the 16 parts are empty
+    assert sum(1 for p in parts if p.num_rows == 0) >= 11
+    packed = [exchange.pack_table(p) for p in parts]
+    for order in (list(range(16)), list(reversed(range(16)))):
+        back = exchange.unpack_concat(ctx, schema, [packed[k][0] for k in order], [packed[k][1] for k in order])
+        want = [r for k in order for r in rows_of(parts[k].to_batches())]
+        assert rows_of(back.to_batches()) == want and back.num_rows == n
+    # the device-side concat of tables is the same assembly
+    assert rows_of(exchange.concat_tables(parts).to_batches()) == [r for p in parts for r in rows_of(p.to_batches())]
+    # an image is rejected when its metadata does not describe it
+    bad = [list(packed[0][0])] + [m for m, _ in packed[1:]]
+    bad[0][1] += 16
+    with pytest.raises(q.InternalError, match="metadata"):
+        exchange.unpack_concat(ctx, schema, bad, [img for _, img in packed])
+
+
+def test_multi_rank_code_path_rehearsal_on_one_gpu():
+    """tools/exchange_rehearsal.py: a one-rank RCCL group with the exchange steps forced on — Q3 through both multi-GPU
+    strategies equals the plain plan and the oracle; then bench.py's N > 1 branch (process group, barrier, collectives)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REHEARSAL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    for extra in (["--rows", "3000000", "--no-extra", "--no-cpu-baseline"], ["--workload", "q3", "--sf", "0.2", "--no-cpu-baseline"],
+                  ["--workload", "q3", "--sf", "0.2", "--strategy", "repartition", "--no-cpu-baseline"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-4000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["value"] > 0 and line["n_gpus"] == 1
+        if "q3" in extra:
+            assert line["exchange"]["exchanges"] > 0
 
 
 def test_repartitioned_join_equals_plain_join(ctx, oracle):

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Rehearsal of the multi-GPU operators on ONE GPU: a one-rank RCCL process group with QHIP_EXCHANGE_FORCE=1 keeps every
+exchange step in place (partition by key -> wire images -> transport rounds -> unpack + concat -> join / merge), so the
+code a multi-GPU launch runs is executed — and checked against the plain single-process plan and the CPU oracle — on the
+one-GPU box the tests get. (What it cannot show is the transport between two different GPUs; the world_size-2 gloo tests
+in tests/test_distributed_cpu.py cover the protocol of the rounds.)
+
+    python tools/exchange_rehearsal.py [--sf 0.2]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import qurious_amd as q  # noqa: E402
+from qurious_amd import exchange, queries, synth  # noqa: E402
+
+
+def rows_of(batches):
+    out = []
+    for b in batches:
+        out.extend(zip(*[c.to_pylist() for c in b.columns]))
+    return sorted(out, key=repr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=0.2)
+    args = ap.parse_args()
+    os.environ["QHIP_EXCHANGE_FORCE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    ctx = q.get_context()
+    import torch
+    import torch.distributed as dist
+    from oracle import qoracle
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+    try:
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)                      # RCCL itself, beside libqhip's HIP runtime in one process
+        assert t.tolist() == [1.0] * 4
+        c, o, l = synth.q3_tables(args.sf)
+        tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+                q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+        plain = queries.q3(*tabs)
+        want = rows_of(plain.execute())
+        assert want == rows_of(qoracle.execute(plain)) and len(want) > 100
+        for name, plan in (("repartition", queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)),
+                           ("broadcast", queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
+            exchange.exchange_stats()
+            got = rows_of(plan.execute_device().to_batches())
+            st = exchange.exchange_stats()
+            assert st["exchanges"] >= 3, st     # the exchange steps really ran
+            assert got == want, f"{name}: distributed plan differs from the single-process plan"
+            print(f"[rehearsal] {name}: {len(got)} groups equal to the plain plan and the oracle; {st['exchanges']} exchanges")
+        # a join output with NULLs and strings through the exchange (Full join: both sides padded)
+        import numpy as np
+        import pyarrow as pa
+        rng = np.random.default_rng(5)
+        ls = pa.schema([pa.field("lk", pa.int64()), pa.field("ls", pa.string()), pa.field("lb", pa.bool_())])
+        rs = pa.schema([pa.field("rk", pa.int64()), pa.field("rd", pa.decimal128(15, 2))])
+        n = 30_000
+        lb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 4000, n), type=pa.int64(), mask=rng.random(n) < 0.05),
+                                         pa.array(["s%d" % v for v in rng.integers(0, 50, n)], mask=rng.random(n) < 0.1),
+                                         pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1)], schema=ls)
+        import decimal
+        rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 4000, n), type=pa.int64(), mask=rng.random(n) < 0.05),
+                                         pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**6, 10**6, n)], type=pa.decimal128(15, 2))], schema=rs)
+        L = q.Scan(ls, q.MemoryTable.try_new(ls, [lb.slice(0, 10_000), lb.slice(10_000)]), None, None)
+        R = q.Scan(rs, q.MemoryTable.try_new(rs, [rb]), None, None)
+        on = [(q.Column("lk", 0), q.Column("rk", 0))]
+        for jt in (q.JoinType.Inner, q.JoinType.Full, q.JoinType.LeftAnti):
+            plain = q.HashJoinExec.try_new(L, R, jt, on, None)
+            d = exchange.DistributedHashJoinExec.try_new(L, R, jt, on, None)
+            assert rows_of(d.execute_device().to_batches()) == rows_of(plain.execute()) == rows_of(qoracle.execute(plain)), jt
+        print("[rehearsal] Inner / Full / LeftAnti joins with NULL keys, strings and booleans through the exchange: equal")
+    finally:
+        dist.destroy_process_group()
+    print("REHEARSAL OK")
+
+
+if __name__ == "__main__":
+    main()
