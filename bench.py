@@ -80,6 +80,8 @@ def bench_q3(args, ctx, rank, world, barrier, dist, torch):
         plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
     else:
         plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if USE_DIST else None)
+    if USE_DIST:
+        exchange.prune_exchange_columns(plan)   # the exchanges move only the columns the plan above them reads
     for _ in range(args.warmup):
         out = plan.execute_device()
         log(f"warmup step: {out.num_rows} groups")

@@ -300,6 +300,11 @@ int qhip_table_from_device(qhip_ctx* ctx, const char* const* names, const qhip_d
  * qhip_table_unpack_concat builds the concatenation, in the order given, of the tables n images describe (one batch per
  * image); it has copied what it needs when it returns. No reference counterpart (the reference is a single process). */
 int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta);
+/* Projection pushdown through the exchange: a view of `t` in which column c is kept (keep[c] != 0, buffers shared) or
+ * replaced by a NULL-typed column of the same length — zero bytes on the wire, column positions unchanged. A column the
+ * plan above the exchange never reads is neither gathered nor sent (the reference's join gathers every column,
+ * utils/batch.rs:18-61; on one GPU the deferred gathers already avoid that). */
+int qhip_table_keep_columns(qhip_ctx* ctx, const qhip_table* t, const int32_t* keep, int32_t n_cols, qhip_table** out);
 int qhip_table_pack(qhip_ctx* ctx, const qhip_table* t, void* device_dst, int64_t dst_bytes);
 int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols,
                              const int64_t* metas /* n x (2 + 2 * n_cols) */, const void* const* device_images,

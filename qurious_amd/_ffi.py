@@ -148,6 +148,7 @@ def load_library() -> C.CDLL:
             "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
             "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),
             "qhip_table_wire_meta": (C.c_int, [vp, vp, P(i64), i32]),
+            "qhip_table_keep_columns": (C.c_int, [vp, vp, P(i32), i32, P(vp)]),
             "qhip_table_pack": (C.c_int, [vp, vp, vp, i64]),
             "qhip_table_unpack_concat": (C.c_int, [vp, P(C.c_char_p), P(qhip_dtype), i32, P(i64), P(vp), i32, P(vp)]),
             "qhip_synth_lineitem": (C.c_int, [i64, i64] + [vp] * 9),

@@ -267,6 +267,28 @@ qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_d
   return out.release();
 }
 
+// Projection pushdown through the exchange: the columns no ancestor of the exchange reads become NULL-typed columns (no
+// buffers, zero bytes on the wire) at the same positions, so column indices downstream stay valid; the kept columns share
+// their buffers — and their deferred state, so a dropped column's pending gather or upload never happens.
+qhip_table* table_keep_columns(Ctx* ctx, const qhip_table* in, const int32_t* keep) {
+  std::unique_ptr<qhip_table> out(new qhip_table());
+  out->ctx = ctx;
+  out->names = in->names;
+  out->nullable = in->nullable;
+  out->num_rows = in->num_rows;
+  out->batch_offsets = in->batch_offsets;
+  for (size_t c = 0; c < in->cols.size(); ++c) {
+    if (keep[c]) { out->cols.push_back(in->cols[c]); continue; }
+    DevColumn nc;
+    nc.type = DType{QHIP_NULL, 0, 0};
+    nc.length = in->num_rows;
+    nc.null_count = in->num_rows;
+    out->cols.push_back(std::move(nc));
+    out->nullable[c] = true;
+  }
+  return out.release();
+}
+
 qhip_table* table_from_device(Ctx* ctx, const char* const* names, const qhip_device_column* cols, int n_cols, int64_t n_rows) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -321,6 +343,12 @@ int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n,
   if (!ctx || !tables || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
   return guarded(ctx, [&] { *out = table_concat(ctx, tables, n); });
+}
+
+int qhip_table_keep_columns(qhip_ctx* ctx, const qhip_table* t, const int32_t* keep, int32_t n_cols, qhip_table** out) {
+  if (!ctx || !t || !keep || !out || n_cols != (int32_t)t->cols.size()) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = table_keep_columns(ctx, t, keep); });
 }
 
 int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta) {

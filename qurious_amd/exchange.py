@@ -47,7 +47,7 @@ def _exchange_world(dist) -> int:
 
 
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
-_STATS = {"bytes_sent": 0, "bytes_received": 0, "seconds": 0.0, "exchanges": 0}
+_STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0}
 
 
 def exchange_stats(reset: bool = True) -> dict:
@@ -55,7 +55,7 @@ def exchange_stats(reset: bool = True) -> dict:
     out = dict(_STATS)
     out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
     if reset:
-        _STATS.update(bytes_sent=0, bytes_received=0, seconds=0.0, exchanges=0)
+        _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0)
     return out
 
 
@@ -110,6 +110,7 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None, meta: Optional[
     _STATS["bytes_sent"] += sum(int(t.numel()) for r, t in enumerate(send) if r != rank)
     _STATS["bytes_received"] += sum(int(t.numel()) for r, t in enumerate(recv) if r != rank)
     _STATS["seconds"] += time.perf_counter() - t_start
+    _STATS["bytes_packed"] += sum(int(t.numel()) for t in send)     # incl. the part that stays on this rank
     _STATS["exchanges"] += 1
     return recv
 
@@ -213,6 +214,84 @@ def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> 
     return unpack_concat(parts[0].ctx, schema, got.meta, got)
 
 
+def keep_columns(table: DeviceTable, keep: Optional[Sequence[bool]]) -> DeviceTable:
+    """`table` with the columns not in `keep` replaced by NULL-typed placeholders (qhip_table_keep_columns); None = all"""
+    if keep is None or all(keep):
+        return table
+    ctx = table.ctx
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_table_keep_columns(ctx.handle, table.handle, int32_array([1 if k else 0 for k in keep]), len(keep), C.byref(out)))
+    return DeviceTable(ctx, out)
+
+
+def referenced_columns(exprs: Sequence[PhysicalExpr]) -> set:
+    """input-schema indices of the Column nodes inside the expressions"""
+    from .expr import K_COLUMN
+    ea = ExprArray()
+    for e in exprs:
+        ea.lower(e)
+    return {int(n.column) for n in ea.nodes if n.kind == K_COLUMN}
+
+
+def prune_exchange_columns(plan: PhysicalPlan, needed: Optional[set] = None) -> PhysicalPlan:
+    """Projection pushdown through the exchanges: walk the plan from the root and tell every distributed join which of its
+    output columns something above it reads (`needed`; None = all of them, as for the root). Its exchanges then move only
+    those, the join keys and the residual filter's columns. Returns `plan` (annotated in place; plans stay valid without)."""
+    from .plan import Filter, HashAggregate, Limit, Projection, Scan, Sort
+    if isinstance(plan, DistributedHashAggregate):
+        prune_exchange_columns(plan.partial, None)
+    elif isinstance(plan, HashAggregate):
+        prune_exchange_columns(plan.input, referenced_columns(list(plan.group_exprs) + [a.expression() for a in plan.aggregate_exprs]))
+    elif isinstance(plan, Projection):
+        prune_exchange_columns(plan.input, referenced_columns(plan.exprs))
+    elif isinstance(plan, Filter):
+        prune_exchange_columns(plan.input, None if needed is None else needed | referenced_columns([plan.predicate]))
+    elif isinstance(plan, Sort):
+        prune_exchange_columns(plan.input, None if needed is None else needed | referenced_columns([e.expr for e in plan.exprs]))
+    elif isinstance(plan, Limit):
+        prune_exchange_columns(plan.input, needed)
+    elif isinstance(plan, HashJoinExec):
+        plan._needed = None if needed is None else set(needed)
+        sides = plan._needed_per_side()
+        prune_exchange_columns(plan.left, sides[0])
+        prune_exchange_columns(plan.right, sides[1])
+    elif not isinstance(plan, Scan):
+        for child in plan.children() or []:
+            prune_exchange_columns(child, None)
+    return plan
+
+
+def _needed_per_side(join: HashJoinExec):
+    """(left, right) input columns a join with `_needed` output columns reads: those, its keys, its residual filter's"""
+    needed = getattr(join, "_needed", None)
+    if needed is None:
+        return None, None
+    left = referenced_columns([l for l, _ in join.on])
+    right = referenced_columns([r for _, r in join.on])
+    for k, (index, side) in enumerate(join.column_indices):
+        if k in needed:
+            (left if int(side) == 0 else right).add(int(index))
+    if join.filter is not None:
+        for index, side in join.filter.column_indices:
+            (left if int(side) == 0 else right).add(int(index))
+    return left, right
+
+
+HashJoinExec._needed_per_side = _needed_per_side
+
+
+def _wire_schema(schema, needed: Optional[set]):
+    """the schema the wire images are unpacked with: dropped columns are NULL-typed on both sides"""
+    import pyarrow as pa
+    if needed is None:
+        return schema
+    return pa.schema([f if c in needed else pa.field(f.name, pa.null()) for c, f in enumerate(schema)])
+
+
+def _keep_mask(n_cols: int, needed: Optional[set]):
+    return None if needed is None else [c in needed for c in range(n_cols)]
+
+
 class DeviceSource(PhysicalPlan):
     """A plan leaf over an already device-resident table (used to feed exchanged tables to HashJoinExec)."""
 
@@ -235,10 +314,13 @@ class DistributedHashJoinExec(HashJoinExec):
         world = _exchange_world(_dist())
         if not world:
             return HashJoinExec.execute_device(self)
-        lparts = partition_by_key(self.left.execute_device(), [l for l, _ in self.on], world)
-        rparts = partition_by_key(self.right.execute_device(), [r for _, r in self.on], world)
-        lt = exchange_device_tables(lparts, self.left.schema())
-        rt = exchange_device_tables(rparts, self.right.schema())
+        ls, rs = self.left.schema(), self.right.schema()
+        lneed, rneed = self._needed_per_side()
+        # columns nothing above this join reads are dropped BEFORE the partitioning: never gathered, never sent
+        lparts = partition_by_key(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), [l for l, _ in self.on], world)
+        rparts = partition_by_key(keep_columns(self.right.execute_device(), _keep_mask(len(rs), rneed)), [r for _, r in self.on], world)
+        lt = exchange_device_tables(lparts, _wire_schema(ls, lneed))
+        rt = exchange_device_tables(rparts, _wire_schema(rs, rneed))
         return self._join_tables(lt, rt)
 
     @staticmethod
@@ -266,7 +348,9 @@ class BroadcastHashJoinExec(HashJoinExec):
             return HashJoinExec.execute_device(self)
         if self.join_type not in (JoinType.Inner, JoinType.Right):
             return DistributedHashJoinExec.execute_device(self)
-        build = all_gather_device_table(self.left.execute_device(), self.left.schema())
+        ls = self.left.schema()
+        lneed, _ = self._needed_per_side()
+        build = all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
         probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
         return self._join_tables(build, probe, None, rpred)
 

@@ -167,3 +167,28 @@ def test_partition_rule_is_deterministic_and_balanced():
     nulls = pa.array([None, None, 5], type=I64)
     p = qoracle.partition_ids([nulls], 4)
     assert p[0] == p[1]
+
+
+def test_exchange_column_pruning_analysis_on_q3():
+    """prune_exchange_columns: every distributed join learns which output columns the plan above it reads; its exchanges
+    carry those, its keys and nothing else (Q3: 4 of customer+orders' 7 columns, 3 of lineitem's 4)"""
+    from qurious_amd import exchange, queries, synth
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, []), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, []),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, []))
+    plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
+    assert exchange.prune_exchange_columns(plan) is plan
+    j2 = plan.partial.input
+    j1 = j2.left
+    names2 = [f.name for f in j2.schema()]
+    assert sorted(names2[c] for c in j2._needed) == ["l_discount", "l_extendedprice", "l_orderkey", "o_orderdate", "o_shippriority"]
+    l2, r2 = j2._needed_per_side()
+    assert sorted(j1.schema().field(c).name for c in l2) == ["o_orderdate", "o_orderkey", "o_shippriority"]
+    assert sorted(synth.LINEITEM_Q3_SCHEMA.field(c).name for c in r2) == ["l_discount", "l_extendedprice", "l_orderkey"]
+    l1, r1 = j1._needed_per_side()
+    assert [synth.CUSTOMER_SCHEMA.field(c).name for c in l1] == ["c_custkey"]           # c_mktsegment is only the scan filter's
+    assert sorted(synth.ORDERS_SCHEMA.field(c).name for c in r1) == ["o_custkey", "o_orderdate", "o_orderkey", "o_shippriority"]
+    wire = exchange._wire_schema(synth.CUSTOMER_SCHEMA, l1)
+    assert [str(f.type) for f in wire] == ["int64", "null"]
+    # an un-annotated plan keeps everything
+    plain = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)
+    assert plain.input._needed_per_side() == (None, None)

@@ -48,14 +48,21 @@ def main():
         plain = queries.q3(*tabs)
         want = rows_of(plain.execute())
         assert want == rows_of(qoracle.execute(plain)) and len(want) > 100
-        for name, plan in (("repartition", queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)),
-                           ("broadcast", queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
-            exchange.exchange_stats()
-            got = rows_of(plan.execute_device().to_batches())
-            st = exchange.exchange_stats()
-            assert st["exchanges"] >= 3, st     # the exchange steps really ran
-            assert got == want, f"{name}: distributed plan differs from the single-process plan"
-            print(f"[rehearsal] {name}: {len(got)} groups equal to the plain plan and the oracle; {st['exchanges']} exchanges")
+        wire = {}
+        for prune in (False, True):
+            for name, plan in (("repartition", queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)),
+                               ("broadcast", queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
+                if prune:
+                    exchange.prune_exchange_columns(plan)
+                exchange.exchange_stats()
+                got = rows_of(plan.execute_device().to_batches())
+                st = exchange.exchange_stats()
+                assert st["exchanges"] >= 3, st     # the exchange steps really ran
+                assert got == want, f"{name}: distributed plan differs from the single-process plan"
+                wire[(name, prune)] = st["bytes_packed"]
+                print(f"[rehearsal] {name}{' (pruned columns)' if prune else ''}: {len(got)} groups equal to the plain plan and the oracle; "
+                      f"{st['exchanges']} exchanges, {st['bytes_packed'] / 1e6:.1f} MB of wire images")
+        assert wire[("repartition", True)] < wire[("repartition", False)] and wire[("broadcast", True)] < wire[("broadcast", False)]
         # a join output with NULLs and strings through the exchange (Full join: both sides padded)
         import numpy as np
         import pyarrow as pa
