@@ -197,7 +197,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     names.push_back(out_names && out_names[k] ? out_names[k] : ("col" + std::to_string(k)));
     nullable.push_back(true);
   }
-  const bool zero_batches_in = in->num_batches() == 0;
+  const bool zero_batches_in = in->no_batches();
   if (n_groups > 0 && zero_batches_in) {
     // hash.rs:146-148: no input batches -> no output batches
     std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));

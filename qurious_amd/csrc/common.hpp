@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/qhip.h"
@@ -125,14 +126,32 @@ struct DeferredGather {
 }  // namespace qhip
 
 // C handle types
+namespace qhip {
+// Batch boundaries an operator computed on the device and nobody has read yet (qhip_table::offsets() reads them)
+struct PendingOffsets {
+  std::shared_ptr<DevBuf> pos;     // n uint32 output positions: where input batch b's first output row is
+  size_t n = 0;
+  bool skip_empty = false;         // hash join (hash_join.rs:363-372): only non-empty probe batches produce a batch
+  bool tail = false;               // ... and a final batch (unmatched / semi rows), possibly empty
+  int64_t total_rows = 0;
+};
+}  // namespace qhip
 struct qhip_table {
   qhip::Ctx* ctx = nullptr;
   std::vector<std::string> names;
   std::vector<bool> nullable;             // schema-level nullability flag
   std::vector<qhip::DevColumn> cols;
   int64_t num_rows = 0;
-  std::vector<int64_t> batch_offsets;     // size = num_batches + 1; batch b = rows [off[b], off[b+1])
-  int64_t num_batches() const { return (int64_t)batch_offsets.size() - 1; }
+  // size = num_batches + 1; batch b = rows [off[b], off[b+1]). WRITE through this member when building a table; READ an
+  // input's boundaries through offsets(): a hash join leaves them on the device (pending_offsets) until somebody asks —
+  // a parent join's build side or an aggregate never does, which saves them a host round trip (Q3: two per query).
+  mutable std::vector<int64_t> batch_offsets;
+  mutable std::shared_ptr<qhip::PendingOffsets> pending_offsets;
+  const std::vector<int64_t>& offsets() const;      // relops.cpp
+  const uint64_t* device_offsets() const;           // relops.cpp: offsets() as uint64 on the device, uploaded once per table
+  mutable std::shared_ptr<qhip::DevBuf> offsets_dev;
+  int64_t num_batches() const { return (int64_t)offsets().size() - 1; }
+  bool no_batches() const { return !pending_offsets && batch_offsets.size() <= 1; }   // the empty Vec<RecordBatch>
 };
 
 namespace qhip {
@@ -150,6 +169,7 @@ struct Ctx {
   mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 — read when the stats are asked for
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
+  std::unordered_set<uint64_t> join_dup_builds;   // build sides (key policy x row count) seen with duplicate keys: no speculation
   void* pinned = nullptr;            // small page-locked scratch for status / result read-backs (truly asynchronous D2H)
   size_t pinned_bytes = 0;
   std::string cache_dir;

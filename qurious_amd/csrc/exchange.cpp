@@ -135,7 +135,7 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
   for (int k = 0; k < n; ++k) resolve_all(ctx, ts[k]);
   for (int k = 0; k < n; ++k) {
     if (ts[k]->cols.size() != first->cols.size()) fail(QHIP_INVALID_ARGUMENT, "qhip_table_concat: schemas differ");
-    for (int64_t b = 0; b < ts[k]->num_batches(); ++b) out->batch_offsets.push_back(N + ts[k]->batch_offsets[(size_t)b + 1]);
+    for (int64_t b = 0; b < ts[k]->num_batches(); ++b) out->batch_offsets.push_back(N + ts[k]->offsets()[(size_t)b + 1]);
     N += ts[k]->num_rows;
   }
   out->num_rows = N;
@@ -276,7 +276,7 @@ qhip_table* table_keep_columns(Ctx* ctx, const qhip_table* in, const int32_t* ke
   out->names = in->names;
   out->nullable = in->nullable;
   out->num_rows = in->num_rows;
-  out->batch_offsets = in->batch_offsets;
+  out->batch_offsets = in->offsets();
   for (size_t c = 0; c < in->cols.size(); ++c) {
     if (keep[c]) { out->cols.push_back(in->cols[c]); continue; }
     DevColumn nc;

@@ -32,7 +32,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
     // projection only: the column buffers are shared, nothing is copied (RecordBatch::project, memory.rs:79-88)
     for (int c : cols) out->cols.push_back(in->cols[(size_t)c]);
     out->num_rows = in->num_rows;
-    out->batch_offsets = in->batch_offsets;
+    out->batch_offsets = in->offsets();
     return out.release();
   }
   if (root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "predicate index out of range");
@@ -48,20 +48,21 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
   for (int c : cols) out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
   hipEventRecord(ctx->ev[1], ctx->stream);
   // output batch boundaries = kept rows before each input batch start
-  const size_t nb1 = in->batch_offsets.size();
+  const size_t nb1 = in->offsets().size();
   out->num_rows = m;
   if (in->num_rows == 0) {
     out->batch_offsets.assign(nb1, 0);
   } else {
-    std::vector<uint64_t> rows(in->batch_offsets.begin(), in->batch_offsets.end());
-    DevBuf drows(nb1 * 8), dpos(nb1 * 4);
-    QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, ctx->stream));
-    launch_mask_prefix_at(mask.as<uint64_t>(), wave.as<uint32_t>(), drows.as<uint64_t>(), (uint32_t)nb1, (uint64_t)in->num_rows, m,
-                          dpos.as<uint32_t>(), ctx->stream);
-    std::vector<uint32_t> pos(nb1);
-    QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    out->batch_offsets.assign(pos.begin(), pos.end());
+    // kept rows before every input batch start, computed on the device and left there until somebody asks
+    // (qhip_table::offsets()): an aggregate or a join's build side above this filter never does
+    auto pend = std::make_shared<PendingOffsets>();
+    pend->pos = std::make_shared<DevBuf>(nb1 * 4);
+    pend->n = nb1;
+    launch_mask_prefix_at(mask.as<uint64_t>(), wave.as<uint32_t>(), in->device_offsets(), (uint32_t)nb1, (uint64_t)in->num_rows, m,
+                          pend->pos->as<uint32_t>(), ctx->stream);
+    out->batch_offsets.clear();
+    out->pending_offsets = pend;
+    if (env_int("QHIP_EAGER_OFFSETS", 0) != 0) (void)out->offsets();
   }
   ctx->stats_timing_pending = 1;   // ev0..ev1, read by qhip_ctx_last_stats
   ctx->stats.rows_in = in->num_rows;

@@ -34,6 +34,12 @@ uint32_t pow2_ceil32(uint64_t x) {
 }
 int log2u(uint32_t x) { int b = 0; while ((1u << b) < x) ++b; return b; }
 
+uint64_t fnv1a64(const std::string& str) {
+  uint64_t h = 1469598103934665603ULL;
+  for (unsigned char c : str) { h ^= c; h *= 1099511628211ULL; }
+  return h;
+}
+
 uint32_t read_u32(hipStream_t s, const void* dev) {
   uint32_t v = 0;
   copy_sync(s, &v, dev, 4, hipMemcpyDeviceToHost);
@@ -105,17 +111,31 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
                            bloom_bits - 1, ctx->status.as<uint32_t>(), s);
   uint32_t max_count = 0;
-  {
-    uint32_t st[QS_WORDS];
-    copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);   // key evaluation of both sides + build
-    check_status_words(st);
-    if (st[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
-    max_count = st[QS_MAXCOUNT];
+  // read-backs land in the context's page-locked scratch: a D2H copy into pageable memory is a stream round trip of its
+  // own, so two of them plus the synchronize cost three waits where one does
+  uint32_t* const st = (uint32_t*)ctx->pinned;          // [status words | pair total | build status words]
+  uint32_t* const st_build = st + 16;
+  // The build's status (key-evaluation errors, duplicate keys?) is needed before the probe only to choose between the
+  // unique-key and the CSR layout. Unique keys are the rule (every FK -> PK join), so unless this build side is known to
+  // have had duplicates the probe is launched on that assumption and the build status is read together with the probe's:
+  // one host round trip less per join. A wrong guess is memory-safe (a slot's state word always names a valid build row),
+  // is detected below, remembered, and the join runs again the careful way.
+  const uint64_t dup_hint = fnv1a64(lkp.source) ^ (B * 0x9E3779B97F4A7C15ULL);
+  const bool speculate = env_int("QHIP_JOIN_FORCE_CSR", 0) == 0 && env_int("QHIP_JOIN_NO_SPECULATION", 0) == 0 && !ctx->join_dup_builds.count(dup_hint);
+  auto check_build_status = [&] {
+    check_status_words(st_build);
+    if (st_build[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
+    max_count = st_build[QS_MAXCOUNT];
+  };
+  QHIP_HIP_CHECK(hipMemcpyAsync(st_build, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, s));   // key evaluation + build
+  if (!speculate) {
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    check_build_status();
   }
   // Unique build keys (every FK -> PK join): each slot's state word names its one build row and nothing else is needed.
   // Otherwise group the build rows by slot with a stable radix sort (ascending build row inside a key: the order the
   // reference's reverse-built chains yield) into a CSR.
-  const bool unique_keys = max_count <= 1 && env_int("QHIP_JOIN_FORCE_CSR", 0) == 0;
+  const bool unique_keys = speculate || (max_count <= 1 && env_int("QHIP_JOIN_FORCE_CSR", 0) == 0);
   const uint32_t* start_ptr = nullptr;
   const uint32_t* rows_ptr = nullptr;
   if (!unique_keys) {
@@ -166,16 +186,22 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     void* args[] = {&ka, &pl};
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 8));
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
-    uint32_t st[QS_WORDS];
-    uint32_t m32 = 0;
+    st[QS_WORDS] = 0;
     if (want_pairs) {
       exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, total.as<uint32_t>(), s);
-      QHIP_HIP_CHECK(hipMemcpyAsync(&m32, total.ptr, 4, hipMemcpyDeviceToHost, s));
+      QHIP_HIP_CHECK(hipMemcpyAsync(st + QS_WORDS, total.ptr, 4, hipMemcpyDeviceToHost, s));
     }
-    QHIP_HIP_CHECK(hipMemcpyAsync(st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost, s));
+    QHIP_HIP_CHECK(hipMemcpyAsync(st, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    if (speculate) {
+      check_build_status();
+      if (max_count > 1) {   // duplicate build keys after all: remember, and run again with the CSR layout
+        ctx->join_dup_builds.insert(dup_hint);
+        return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
+      }
+    }
     check_status_words(st);
-    M = m32;
+    M = st[QS_WORDS];
     if (want_pairs) {
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
@@ -189,6 +215,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
                        mark_in_probe ? visited.as<uint32_t>() : nullptr, s);
     }
     visited_done = mark_in_probe;
+  } else if (speculate) {
+    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    check_build_status();   // (duplicates do not matter without probe rows)
   }
   hipEventRecord(ctx->ev[3], s);
 
@@ -307,19 +336,24 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   out->batch_offsets.clear();
   out->batch_offsets.push_back(0);
   if (!semi_anti && R->num_batches() > 0 && M > 0) {
-    const size_t nb1 = R->batch_offsets.size();
-    std::vector<uint64_t> rows(R->batch_offsets.begin(), R->batch_offsets.end());
-    DevBuf drows(nb1 * 8), dpos(nb1 * 4);
-    QHIP_HIP_CHECK(hipMemcpyAsync(drows.ptr, rows.data(), nb1 * 8, hipMemcpyHostToDevice, s));
-    if (pad_right) launch_lookup_u32(final_off, drows.as<uint64_t>(), (uint32_t)nb1, P, (uint32_t)M, dpos.as<uint32_t>(), s);
-    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, drows.as<uint64_t>(), (uint32_t)nb1, dpos.as<uint32_t>(), s);   // probe rows ascend
-    std::vector<uint32_t> pos(nb1);
-    QHIP_HIP_CHECK(hipMemcpyAsync(pos.data(), dpos.ptr, nb1 * 4, hipMemcpyDeviceToHost, s));
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
-    for (size_t b = 1; b < nb1; ++b)
-      if (pos[b] > (uint32_t)out->batch_offsets.back()) out->batch_offsets.push_back(pos[b]);
+    const size_t nb1 = R->offsets().size();
+    // first output row of every probe batch, computed on the device and LEFT there (qhip_table::offsets() fetches it when
+    // somebody asks: a download, a Filter / Limit / probe side above; a parent's build side or an aggregate never does)
+    const uint64_t* drows = R->device_offsets();
+    auto pend = std::make_shared<PendingOffsets>();
+    pend->pos = std::make_shared<DevBuf>(nb1 * 4);
+    pend->n = nb1;
+    pend->skip_empty = true;
+    pend->tail = has_tail;
+    pend->total_rows = (int64_t)total_rows;
+    if (pad_right) launch_lookup_u32(final_off, drows, (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
+    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, drows, (uint32_t)nb1, pend->pos->as<uint32_t>(), s);   // probe rows ascend
+    out->batch_offsets.clear();
+    out->pending_offsets = pend;
+    if (env_int("QHIP_EAGER_OFFSETS", 0) != 0) (void)out->offsets();
+  } else if (has_tail) {
+    out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
   }
-  if (has_tail) out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
   hipEventRecord(ctx->ev[1], s);
   ctx->stats_timing_pending = 2;   // total = ev0..ev1, probe = ev2..ev3, read by qhip_ctx_last_stats
   ctx->stats.rows_in = (int64_t)P;

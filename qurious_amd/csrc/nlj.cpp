@@ -169,9 +169,9 @@ qhip_table* cross_join(Ctx* ctx, const qhip_table* L, const qhip_table* R) {
   out->batch_offsets = {0};
   uint64_t pos = 0;
   for (int64_t lb = 0; lb < L->num_batches(); ++lb) {
-    const uint64_t l0 = (uint64_t)L->batch_offsets[(size_t)lb], nl = (uint64_t)L->batch_offsets[(size_t)lb + 1] - l0;
+    const uint64_t l0 = (uint64_t)L->offsets()[(size_t)lb], nl = (uint64_t)L->offsets()[(size_t)lb + 1] - l0;
     for (int64_t rb = 0; rb < R->num_batches(); ++rb) {
-      const uint64_t r0 = (uint64_t)R->batch_offsets[(size_t)rb], nr = (uint64_t)R->batch_offsets[(size_t)rb + 1] - r0;
+      const uint64_t r0 = (uint64_t)R->offsets()[(size_t)rb], nr = (uint64_t)R->offsets()[(size_t)rb + 1] - r0;
       // left-row major inside the (left batch, right batch) block: pair k -> (l0 + k / nr, r0 + k % nr)
       if (nl > 0 && nr > 0) launch_pair_indices(ri->as<uint32_t>() + pos, li->as<uint32_t>() + pos, nl * nr, (uint32_t)nr, (uint32_t)r0, (uint32_t)l0, 0, s);
       for (uint64_t l = 0; l < nl; ++l) { pos += nr; out->batch_offsets.push_back((int64_t)pos); }

@@ -53,7 +53,7 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
   std::unique_ptr<qhip_table> out(new qhip_table());
   out->ctx = ctx;
   out->num_rows = N;
-  out->batch_offsets = in->batch_offsets;
+  out->batch_offsets = in->offsets();
   out->cols.resize((size_t)n_out);
   std::vector<int32_t> croots;
   std::vector<int> cslot;

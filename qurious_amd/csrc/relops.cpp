@@ -219,3 +219,41 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
 }
 
 }  // namespace qhip
+
+// The boundaries are read on the table's stream into the page-locked scratch (one round trip), once.
+const std::vector<int64_t>& qhip_table::offsets() const {
+  if (!pending_offsets) return batch_offsets;
+  const qhip::PendingOffsets& p = *pending_offsets;
+  if (!ctx) qhip::fail(QHIP_INVALID_ARGUMENT, "table with pending batch boundaries has no context");
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  std::vector<uint32_t> pos_v;
+  uint32_t* pos = (uint32_t*)((uint8_t*)ctx->pinned + 64);
+  if (64 + p.n * 4 + 1024 > ctx->pinned_bytes) {
+    pos_v.resize(p.n);
+    pos = pos_v.data();
+  }
+  QHIP_HIP_CHECK(hipMemcpyAsync(pos, p.pos->ptr, p.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  batch_offsets.clear();
+  if (p.skip_empty) {
+    batch_offsets.push_back(0);
+    for (size_t b = 1; b < p.n; ++b)
+      if ((int64_t)pos[b] > batch_offsets.back()) batch_offsets.push_back((int64_t)pos[b]);
+    if (p.tail) batch_offsets.push_back(p.total_rows);
+  } else {
+    batch_offsets.assign(pos, pos + p.n);
+  }
+  pending_offsets.reset();
+  return batch_offsets;
+}
+
+const uint64_t* qhip_table::device_offsets() const {
+  if (!offsets_dev) {
+    const std::vector<int64_t>& off = offsets();
+    std::vector<uint64_t> rows(off.begin(), off.end());
+    auto d = std::make_shared<qhip::DevBuf>(rows.size() * 8);
+    qhip::copy_sync(ctx->stream, d->ptr, rows.data(), rows.size() * 8, hipMemcpyHostToDevice);
+    offsets_dev = d;
+  }
+  return offsets_dev->as<uint64_t>();
+}

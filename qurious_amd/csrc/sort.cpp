@@ -148,10 +148,10 @@ qhip_table* limit_table(Ctx* ctx, const qhip_table* in, int64_t skip, int64_t fe
   int64_t first_row = -1;
   std::vector<int64_t> offs = {0};
   for (int64_t b = 0; b < in->num_batches(); ++b) {
-    const uint64_t rows = (uint64_t)(in->batch_offsets[(size_t)b + 1] - in->batch_offsets[(size_t)b]);
+    const uint64_t rows = (uint64_t)(in->offsets()[(size_t)b + 1] - in->offsets()[(size_t)b]);
     if (rows <= to_skip) { to_skip -= rows; continue; }
     const uint64_t new_rows = rows - to_skip;
-    if (first_row < 0) first_row = in->batch_offsets[(size_t)b] + (int64_t)to_skip;
+    if (first_row < 0) first_row = in->offsets()[(size_t)b] + (int64_t)to_skip;
     to_skip = 0;
     const uint64_t remaining = max_fetch - fetched;
     if (new_rows <= remaining) {

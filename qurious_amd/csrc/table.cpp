@@ -278,7 +278,7 @@ static void* xmalloc(size_t n) {
 void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* out) {
   if (b < 0 || b >= t->num_batches()) fail(QHIP_INVALID_ARGUMENT, "batch index out of range");
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
-  const int64_t r0 = t->batch_offsets[b], r1 = t->batch_offsets[b + 1], n = r1 - r0;
+  const int64_t r0 = t->offsets()[(size_t)b], r1 = t->offsets()[(size_t)b + 1], n = r1 - r0;
   std::unique_ptr<HostArrayPrivate> top(new HostArrayPrivate());
   top->child_storage.resize(t->cols.size());
   for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
@@ -398,7 +398,10 @@ int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
   });
 }
 
-int64_t qhip_table_num_batches(const qhip_table* t) { return t ? t->num_batches() : -1; }
+int64_t qhip_table_num_batches(const qhip_table* t) {
+  if (!t) return -1;
+  try { return t->num_batches(); } catch (const qhip::Error&) { return -1; }   // (pending boundaries are read from the device here)
+}
 int64_t qhip_table_num_rows(const qhip_table* t) { return t ? t->num_rows : -1; }
 int64_t qhip_table_num_columns(const qhip_table* t) { return t ? (int64_t)t->cols.size() : -1; }
 int64_t qhip_table_column_bytes(const qhip_table* t, int64_t col) {
