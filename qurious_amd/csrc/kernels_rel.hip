@@ -79,6 +79,35 @@ __global__ __launch_bounds__(QH_BLOCK) void k_scan_chunk_apply(const u32* in, u3
   }
 }
 
+// The middle phase for up to 16384 chunk sums (n <= 32M elements): ONE workgroup scans them in place, 2048 at a time
+// with a running carry, and leaves the grand total behind the last sum and in *total — one launch instead of the
+// recursion's five (sums, copy, apply, copy, copy), which matters when the whole scan is ~10 us of device time.
+__global__ __launch_bounds__(QH_BLOCK) void k_scan_sums_inplace(u32* sums, u32 nchunks, u32* total) {
+  __shared__ u32 wtot[4];
+  __shared__ u32 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 base = 0; base < nchunks; base += SCAN_CHUNK) {
+    const u32 first = base + threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = first + k < nchunks ? sums[first + k] : 0u; s += v[k]; }
+    const u32 incl = wave_incl_scan_u32(s);
+    const int wave = threadIdx.x >> 6;
+    if (qh_lane() == 63) wtot[wave] = incl;
+    __syncthreads();
+    u32 off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    u32 run = off + incl - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (first + k < nchunks) sums[first + k] = run; run += v[k]; }
+    __syncthreads();
+    if (threadIdx.x == QH_BLOCK - 1) carry_s = run;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[nchunks] = carry_s; if (total) *total = carry_s; }
+}
+
 // out[i] = sum(in[0..i)); out may alias in. *total (device) receives the grand total when non-null.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, hipStream_t s) {
   if (n == 0) {
@@ -89,16 +118,14 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*
   DevBuf sums_buf((nchunks + 1) * sizeof(uint32_t));   // pooled; reuse is stream-ordered (single stream per context)
   uint32_t* sums = sums_buf.as<uint32_t>();
   hipLaunchKernelGGL(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u64)n, (u32*)sums);
-  if (nchunks == 1) {
-    // one chunk: its sum is the total and its offset is zero
-    hipMemcpyAsync(sums + 1, sums, 4, hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(k_scan_chunk_apply, dim3(1), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)nullptr);
+  if (nchunks <= 16384) {
+    hipLaunchKernelGGL(k_scan_sums_inplace, dim3(1), dim3(QH_BLOCK), 0, s, (u32*)sums, (u32)nchunks, (u32*)total_dev);
   } else {
-    // scan the chunk sums in place (recursion depth <= 3 for n < 2^32)
+    // scan the chunk sums in place (recursion depth <= 2 for n < 2^32)
     exclusive_scan_u32(sums, sums, nchunks, sums + nchunks, s);
-    hipLaunchKernelGGL(k_scan_chunk_apply, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)sums);
+    if (total_dev) hipMemcpyAsync(total_dev, sums + nchunks, 4, hipMemcpyDeviceToDevice, s);
   }
-  if (total_dev) hipMemcpyAsync(total_dev, sums + nchunks, 4, hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(k_scan_chunk_apply, dim3((unsigned)nchunks), dim3(QH_BLOCK), 0, s, (const u32*)in, (u32*)out, (u64)n, (const u32*)sums);
 }
 
 // ================================================================ selection vector from a keep-mask
