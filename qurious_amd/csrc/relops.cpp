@@ -227,8 +227,8 @@ const std::vector<int64_t>& qhip_table::offsets() const {
   if (!ctx) qhip::fail(QHIP_INVALID_ARGUMENT, "table with pending batch boundaries has no context");
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   std::vector<uint32_t> pos_v;
-  uint32_t* pos = (uint32_t*)((uint8_t*)ctx->pinned + 64);
-  if (64 + p.n * 4 + 1024 > ctx->pinned_bytes) {
+  uint32_t* pos = (uint32_t*)((uint8_t*)ctx->pinned + 128);   // (the first 128 bytes hold status words)
+  if (128 + p.n * 4 + 1024 > ctx->pinned_bytes) {
     pos_v.resize(p.n);
     pos = pos_v.data();
   }

@@ -282,6 +282,28 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
   std::unique_ptr<HostArrayPrivate> top(new HostArrayPrivate());
   top->child_storage.resize(t->cols.size());
   for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
+  // Small buffers (a LIMIT's ten rows, a handful of groups) are fetched through the context's page-locked scratch: the
+  // copies are queued back to back and land after ONE wait, where a copy into pageable memory is a stream round trip each.
+  struct Staged { void* dst; size_t at; size_t n; };
+  std::vector<Staged> staged;
+  size_t staged_used = 128;   // (the first 128 bytes hold status words)
+  const size_t staged_end = ctx->pinned_bytes > 1024 ? ctx->pinned_bytes - 1024 : 0;
+  auto land_staged = [&] {
+    for (auto& f : staged) memcpy(f.dst, (const uint8_t*)ctx->pinned + f.at, f.n);
+    staged.clear();
+    staged_used = 128;
+  };
+  auto d2h = [&](void* dst, const void* src, size_t nbytes, hipStream_t st) {
+    if (!nbytes) return;
+    const size_t room = (nbytes + 15) & ~(size_t)15;
+    if (staged_used + room <= staged_end) {
+      QHIP_HIP_CHECK(hipMemcpyAsync((uint8_t*)ctx->pinned + staged_used, src, nbytes, hipMemcpyDeviceToHost, st));
+      staged.push_back({dst, staged_used, nbytes});
+      staged_used += room;
+    } else {
+      QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, st));
+    }
+  };
   struct Pending { uint8_t* raw; uint8_t* dst; int64_t bit_off; int64_t nbits; };
   std::vector<Pending> bitfix;                       // bitmaps to realign after the copies land
   struct OffFix { int32_t* off; int64_t n; };
@@ -333,6 +355,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
       int32_t* off = (int32_t*)xmalloc((size_t)(n + 1) * 4);
       d2h(off, (const int32_t*)col.values->ptr + r0, (size_t)(n + 1) * 4, ctx->stream);
       QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // need the offsets to size the data slice
+      land_staged();
       const int32_t base = off[0];
       const int64_t nbytes = (int64_t)off[n] - base;
       uint8_t* data = (uint8_t*)xmalloc((size_t)nbytes);
@@ -347,6 +370,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
     top->children.push_back(ca);
   }
   QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  land_staged();
   for (auto& f : bitfix) { copy_bits(f.raw, f.bit_off, f.dst, 0, f.nbits); free(f.raw); }
   for (auto& f : offfix) { const int32_t base = f.off[0]; for (int64_t i = 0; i < f.n; ++i) f.off[i] -= base; }
   for (auto& nf : nullfix) nf.first->null_count = n - count_set_bits(nf.second, 0, n);
