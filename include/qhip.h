@@ -208,10 +208,14 @@ int qhip_table_from_arrow(qhip_ctx* ctx, const struct ArrowSchema* schema,
 int qhip_table_from_arrow_lazy(qhip_ctx* ctx, const struct ArrowSchema* schema, struct ArrowArray* const* batches,
                                int64_t n_batches, qhip_table** out);
 /* Download batch `batch_index` as a struct ArrowArray (+ schema if out_schema != NULL).
- * Buffers are library-owned host memory freed by the release callbacks. */
+ * Buffers are library-owned host memory freed by the release callbacks.
+ * batch_index == -1: every row of the table as ONE array — a caller facing thousands of small batches (the reference's
+ * CSV loader makes 1024-row batches, datasource/file/csv.rs:63-66) downloads once and slices on the host at the
+ * boundaries qhip_table_batch_offsets returns (n_out = qhip_table_num_batches + 1 entries: first 0, last = rows). */
 int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
                         struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 int64_t qhip_table_num_batches(const qhip_table* t);
+int qhip_table_batch_offsets(const qhip_table* t, int64_t* out, int64_t n_out);
 int64_t qhip_table_num_rows(const qhip_table* t);
 int64_t qhip_table_num_columns(const qhip_table* t);
 /* bytes resident in HBM for column `col` (all buffers) — used for the roofline's algorithmic bytes */

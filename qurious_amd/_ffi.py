@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+from typing import List
 
 import pyarrow as pa
 
@@ -130,6 +131,7 @@ def load_library() -> C.CDLL:
             "qhip_table_from_arrow_lazy": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
             "qhip_table_to_arrow": (C.c_int, [vp, vp, i64, vp, vp]),
             "qhip_table_num_batches": (i64, [vp]),
+            "qhip_table_batch_offsets": (C.c_int, [vp, P(i64), i64]),
             "qhip_table_num_rows": (i64, [vp]),
             "qhip_table_num_columns": (i64, [vp]),
             "qhip_table_column_bytes": (i64, [vp, i64]),
@@ -265,9 +267,23 @@ class DeviceTable:
     def column_bytes(self, col: int) -> int:
         return self.ctx.lib.qhip_table_column_bytes(self.handle, col)
 
+    def batch_offsets(self) -> List[int]:
+        n = self.num_batches + 1
+        out = (C.c_int64 * n)()
+        self.ctx.check(self.ctx.lib.qhip_table_batch_offsets(self.handle, out, n))
+        return list(out)
+
     def to_batches(self):
+        nb = self.num_batches
+        if nb > 8:
+            # many batches: ONE download of every row, sliced on the host (zero-copy) at the batch boundaries
+            a, s = ArrowArrayStruct(), ArrowSchemaStruct()
+            self.ctx.check(self.ctx.lib.qhip_table_to_arrow(self.ctx.handle, self.handle, -1, C.addressof(a), C.addressof(s)))
+            whole = pa.RecordBatch._import_from_c(C.addressof(a), C.addressof(s))
+            off = self.batch_offsets()
+            return [whole.slice(off[b], off[b + 1] - off[b]) for b in range(nb)]
         out = []
-        for b in range(self.num_batches):
+        for b in range(nb):
             a = ArrowArrayStruct()
             s = ArrowSchemaStruct()
             self.ctx.check(self.ctx.lib.qhip_table_to_arrow(self.ctx.handle, self.handle, b, C.addressof(a), C.addressof(s)))

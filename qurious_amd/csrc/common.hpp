@@ -172,6 +172,9 @@ struct Ctx {
   std::unordered_set<uint64_t> join_dup_builds;   // build sides (key policy x row count) seen with duplicate keys: no speculation
   void* pinned = nullptr;            // small page-locked scratch for status / result read-backs (truly asynchronous D2H)
   size_t pinned_bytes = 0;
+  // two page-locked 8 MB slots through which uploads of MANY SMALL batches are coalesced (table.cpp), made on first use
+  void* up_slot[2] = {nullptr, nullptr};
+  hipEvent_t up_ev[2] = {nullptr, nullptr};
   std::string cache_dir;
   std::unordered_map<std::string, std::shared_ptr<void>> plan_cache;   // lowered plans keyed by their POD description
 };

@@ -250,6 +250,10 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   ctx->plan_cache.clear();
   ctx->status.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->up_slot[k]) (void)hipHostFree(ctx->up_slot[k]);
+    if (ctx->up_ev[k]) (void)hipEventDestroy(ctx->up_ev[k]);
+  }
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); g_live_contexts[ctx->device & 31].fetch_sub(1); }
   delete ctx;

@@ -34,6 +34,8 @@ void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyva
                               uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s);
 void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s);
+// p[i] += shifts[b] for the batch b with starts[b] <= i < starts[b + 1] (starts: nb + 1 ascending row numbers)
+void launch_add_i32_batched(int32_t* p, uint64_t n, const uint64_t* starts, const int32_t* shifts, uint32_t nb, hipStream_t s);
 // dst (zeroed) bits [dst_pos, dst_pos + nbits) |= src bits [0, nbits); src == nullptr appends ones
 void launch_bits_append(uint32_t* dst, uint64_t dst_pos, const uint8_t* src, uint64_t nbits, hipStream_t s);
 void launch_pair_indices(uint32_t* minor, uint32_t* major, uint64_t n, uint32_t n_minor, uint32_t minor0, uint32_t major0, int unused, hipStream_t s);

@@ -457,6 +457,15 @@ __global__ __launch_bounds__(QH_BLOCK) void k_bits_append(u32* dst, u64 dst_pos,
   if (bits) dst[w] |= bits << (u32)(lo & 31);
 }
 
+// ... and for MANY batches in one launch: row i belongs to the batch b with starts[b] <= i < starts[b + 1]
+__global__ __launch_bounds__(QH_BLOCK) void k_add_i32_batched(int* p, u64 n, const u64* starts, const int* shifts, u32 nb) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    u32 lo = 0, hi = nb;                    // last b with starts[b] <= i
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid; else hi = mid; }
+    p[i] += shifts[lo];
+  }
+}
+
 // index-vector composition for deferred gathers: out[k] = inner[idx[k]], NULL stays NULL
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inner, const u32* idx, u32* out, u64 m) {
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
@@ -673,6 +682,9 @@ void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint
 }
 void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s) {
   if (n && delta) hipLaunchKernelGGL(k_add_i32, dim3(grid_for(n, QH_BLOCK * 8, 1024)), dim3(QH_BLOCK), 0, s, (int*)p, (u64)n, (int)delta);
+}
+void launch_add_i32_batched(int32_t* p, uint64_t n, const uint64_t* starts, const int32_t* shifts, uint32_t nb, hipStream_t s) {
+  if (n && nb) hipLaunchKernelGGL(k_add_i32_batched, dim3(grid_for(n, QH_BLOCK * 4, 2048)), dim3(QH_BLOCK), 0, s, (int*)p, (u64)n, (const u64*)starts, (const int*)shifts, nb);
 }
 void launch_bits_append(uint32_t* dst, uint64_t dst_pos, const uint8_t* src, uint64_t nbits, hipStream_t s) {
   if (!nbits) return;

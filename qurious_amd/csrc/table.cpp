@@ -59,6 +59,46 @@ static void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
   if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s));
 }
 
+// Many small batches — the reference's CSV loader produces 1024-row batches (datasource/file/csv.rs:63-66: SF10 lineitem =
+// 58.6 k batches) — would mean one copy call per 4-16 KB buffer at ~10 us each. Their bytes are gathered instead into two
+// page-locked 8 MB slots (host memcpy) and sent as large asynchronous copies to a CONTIGUOUS device range, the fill of one
+// slot overlapping the DMA of the other.
+struct Coalescer {
+  static constexpr size_t kSlot = 8u << 20;
+  Ctx* ctx;
+  uint8_t* dst;          // device: next byte to write
+  int cur = 0;
+  size_t fill = 0;
+  Coalescer(Ctx* c, void* device_dst) : ctx(c), dst((uint8_t*)device_dst) {
+    for (int k = 0; k < 2; ++k)
+      if (!ctx->up_slot[k]) {
+        QHIP_HIP_CHECK(hipHostMalloc(&ctx->up_slot[k], kSlot, hipHostMallocDefault));
+        QHIP_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
+        QHIP_HIP_CHECK(hipEventRecord(ctx->up_ev[k], ctx->stream));
+      }
+    QHIP_HIP_CHECK(hipEventSynchronize(ctx->up_ev[cur]));   // a previous user's copy out of this slot has finished
+  }
+  void send() {
+    if (!fill) return;
+    QHIP_HIP_CHECK(hipMemcpyAsync(dst, ctx->up_slot[cur], fill, hipMemcpyHostToDevice, ctx->stream));
+    QHIP_HIP_CHECK(hipEventRecord(ctx->up_ev[cur], ctx->stream));
+    dst += fill;
+    fill = 0;
+    cur ^= 1;
+    QHIP_HIP_CHECK(hipEventSynchronize(ctx->up_ev[cur]));   // the other slot's copy (two sends ago) has finished
+  }
+  void append(const void* src, size_t n) {
+    const uint8_t* p = (const uint8_t*)src;
+    while (n) {
+      const size_t k = std::min(n, kSlot - fill);
+      memcpy((uint8_t*)ctx->up_slot[cur] + fill, p, k);
+      fill += k; p += k; n -= k;
+      if (fill == kSlot) send();
+    }
+  }
+  void finish() { send(); }
+};
+
 // One column of the batches -> HBM, concatenated (values / offsets rebased / bitmaps realigned). Synchronous.
 static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const ArrowArray* const* batches, int64_t nb,
                                const std::vector<int64_t>& batch_offsets) {
@@ -90,15 +130,20 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
     h2d(col.validity->ptr, dst, col.validity->bytes, ctx->stream);
   }
   const int w = dtype_width(col.type);
+  // (the page-locked slots only pay off when a copy call would otherwise move a few KB)
+  const bool small_batches = nb > 8 && N / nb < 32768 && env_int("QHIP_UPLOAD_NO_COALESCE", 0) == 0;
   if (w > 0) {
     col.values = std::make_shared<DevBuf>((size_t)N * w);
+    std::unique_ptr<Coalescer> co(small_batches ? new Coalescer(ctx, col.values->ptr) : nullptr);
     for (int64_t b = 0; b < nb; ++b) {
       const ArrowArray* ca = batches[b]->children[c];
       if (ca->length == 0) continue;
       if (ca->n_buffers < 2 || !ca->buffers[1]) fail(QHIP_INVALID_ARGUMENT, "missing values buffer");
-      h2d_stream(ctx, (uint8_t*)col.values->ptr + (size_t)batch_offsets[(size_t)b] * w, (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w,
-                 (size_t)ca->length * w);
+      const uint8_t* src = (const uint8_t*)ca->buffers[1] + (size_t)ca->offset * w;
+      if (co) co->append(src, (size_t)ca->length * w);
+      else h2d_stream(ctx, (uint8_t*)col.values->ptr + (size_t)batch_offsets[(size_t)b] * w, src, (size_t)ca->length * w);
     }
+    if (co) co->finish();
   } else if (col.type.id == QHIP_BOOL) {
     staging.emplace_back((size_t)((N + 7) / 8 + 8), 0);
     uint8_t* dst = staging.back().data();
@@ -125,21 +170,55 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
     int32_t* off_dev = col.values->as<int32_t>();
     std::vector<int32_t> shifts((size_t)nb, 0);
     int64_t pos = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-      const ArrowArray* ca = batches[b]->children[c];
-      if (ca->length == 0) continue;
-      const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
-      const int32_t base = so[0];
-      shifts[(size_t)b] = (int32_t)pos - base;
-      h2d_stream(ctx, off_dev + batch_offsets[(size_t)b], so, (size_t)ca->length * 4);
-      const int64_t nbytes = (int64_t)so[ca->length] - base;
-      h2d_stream(ctx, (uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes);
-      pos += nbytes;
-    }
-    h2d_flush(ctx);   // every copy is on the stream: the rebasing kernels below are ordered behind them
-    for (int64_t b = 0; b < nb; ++b) {
-      const ArrowArray* ca = batches[b]->children[c];
-      launch_add_i32(off_dev + batch_offsets[(size_t)b], (uint64_t)ca->length, shifts[(size_t)b], ctx->stream);
+    if (small_batches) {
+      // offsets and bytes each stream into a contiguous range: two passes over the batches through the two slots
+      {
+        Coalescer co(ctx, off_dev);
+        for (int64_t b = 0; b < nb; ++b) {
+          const ArrowArray* ca = batches[b]->children[c];
+          if (ca->length == 0) continue;
+          const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+          shifts[(size_t)b] = (int32_t)pos - so[0];
+          pos += (int64_t)so[ca->length] - so[0];
+          co.append(so, (size_t)ca->length * 4);
+        }
+        co.finish();
+      }
+      {
+        Coalescer co(ctx, col.data->ptr);
+        for (int64_t b = 0; b < nb; ++b) {
+          const ArrowArray* ca = batches[b]->children[c];
+          if (ca->length == 0) continue;
+          const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+          co.append((const uint8_t*)ca->buffers[2] + so[0], (size_t)((int64_t)so[ca->length] - so[0]));
+        }
+        co.finish();
+      }
+      // one rebasing launch for all batches: row -> batch by binary search in the batch starts
+      staging.emplace_back((size_t)(nb + 1) * 8 + (size_t)nb * 4, 0);
+      uint64_t* starts = (uint64_t*)staging.back().data();
+      for (int64_t b = 0; b <= nb; ++b) starts[b] = (uint64_t)batch_offsets[(size_t)b];
+      memcpy(starts + nb + 1, shifts.data(), (size_t)nb * 4);
+      DevBuf meta(staging.back().size());
+      h2d(meta.ptr, staging.back().data(), staging.back().size(), ctx->stream);
+      launch_add_i32_batched(off_dev, (uint64_t)N, meta.as<uint64_t>(), (const int32_t*)(meta.as<uint64_t>() + nb + 1), (uint32_t)nb, ctx->stream);
+    } else {
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        if (ca->length == 0) continue;
+        const int32_t* so = (const int32_t*)ca->buffers[1] + ca->offset;
+        const int32_t base = so[0];
+        shifts[(size_t)b] = (int32_t)pos - base;
+        h2d_stream(ctx, off_dev + batch_offsets[(size_t)b], so, (size_t)ca->length * 4);
+        const int64_t nbytes = (int64_t)so[ca->length] - base;
+        h2d_stream(ctx, (uint8_t*)col.data->ptr + pos, (const uint8_t*)ca->buffers[2] + base, (size_t)nbytes);
+        pos += nbytes;
+      }
+      h2d_flush(ctx);   // every copy is on the stream: the rebasing kernels below are ordered behind them
+      for (int64_t b = 0; b < nb; ++b) {
+        const ArrowArray* ca = batches[b]->children[c];
+        launch_add_i32(off_dev + batch_offsets[(size_t)b], (uint64_t)ca->length, shifts[(size_t)b], ctx->stream);
+      }
     }
     staging.emplace_back(4, 0);
     const int32_t last = (int32_t)total;
@@ -276,9 +355,10 @@ static void* xmalloc(size_t n) {
 }
 
 void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* out) {
-  if (b < 0 || b >= t->num_batches()) fail(QHIP_INVALID_ARGUMENT, "batch index out of range");
+  if (b < -1 || b >= t->num_batches()) fail(QHIP_INVALID_ARGUMENT, "batch index out of range");
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
-  const int64_t r0 = t->offsets()[(size_t)b], r1 = t->offsets()[(size_t)b + 1], n = r1 - r0;
+  // b == -1: every row as ONE array (a caller with thousands of small batches downloads once and slices on the host)
+  const int64_t r0 = b < 0 ? 0 : t->offsets()[(size_t)b], r1 = b < 0 ? t->num_rows : t->offsets()[(size_t)b + 1], n = r1 - r0;
   std::unique_ptr<HostArrayPrivate> top(new HostArrayPrivate());
   top->child_storage.resize(t->cols.size());
   for (auto& c : top->child_storage) memset(&c, 0, sizeof(c));
@@ -420,6 +500,16 @@ int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
     if (out_array) table_batch_to_arrow(ctx, t, batch_index, out_array);
     if (out_schema) table_schema_to_arrow(t, out_schema);
   });
+}
+
+int qhip_table_batch_offsets(const qhip_table* t, int64_t* out, int64_t n_out) {
+  if (!t || !out) return QHIP_INVALID_ARGUMENT;
+  try {
+    const std::vector<int64_t>& off = t->offsets();
+    if (n_out != (int64_t)off.size()) return QHIP_INVALID_ARGUMENT;
+    for (size_t k = 0; k < off.size(); ++k) out[k] = off[k];
+    return QHIP_OK;
+  } catch (const qhip::Error& e) { return e.code; }
 }
 
 int64_t qhip_table_num_batches(const qhip_table* t) {

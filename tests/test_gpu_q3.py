@@ -216,3 +216,40 @@ def test_repartitioned_join_equals_plain_join(ctx, oracle):
     # world == 1: the distributed node degenerates to the local join
     d = exchange.DistributedHashJoinExec.try_new(L, R, JoinType.Inner, on, None)
     assert rows_of(d.execute()) == rows_of(plain.execute())
+
+
+def _rebatch(batches, rows):
+    out = []
+    for b in batches:
+        out.extend(b.slice(o, min(rows, b.num_rows - o)) for o in range(0, b.num_rows, rows))
+    return out
+
+
+def test_q3_over_1024_row_batches_like_the_reference_csv_loader(ctx, oracle):
+    """TPC-H tables loaded by COPY arrive as 1024-row batches (datasource/file/csv.rs:63-66): thousands of
+    small batches per table go up through the coalesced upload, the join emits one batch per non-empty probe batch
+    (hash_join.rs:363-372) and the many-batch download slices one transfer — same rows, same batch structure as the oracle"""
+    c, o, l = synth.q3_tables(0.25, orders_per_batch=50_000)
+    c, o, l = _rebatch(c, 1024), _rebatch(o, 1024), _rebatch(l, 1024)
+    assert len(l) > 1400 and all(b.num_rows <= 1024 for b in l)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    plan = queries.q3(*tabs)
+    assert sorted(rows_of(plan.execute())) == sorted(rows_of(oracle.execute(plan)))
+    j2 = plan.input
+    got, want = j2.execute(), oracle.execute(j2)
+    assert [b.num_rows for b in got] == [b.num_rows for b in want] and len(got) > 500
+    assert rows_of(got) == rows_of(want)
+    # a Filter keeps one (possibly empty) batch per input batch; Utf8 + NULLs through the coalesced upload
+    rng = np.random.default_rng(12)
+    n = 300_000
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("b", pa.bool_())])
+    big = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 1000, n), type=I64, mask=rng.random(n) < 0.1),
+                                      pa.array(["w%d" % v for v in rng.integers(0, 5000, n)], mask=rng.random(n) < 0.1),
+                                      pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1)], schema=schema)
+    small = _rebatch([big], 1000)
+    f = q.Filter(table_scan(schema, small), q.BinaryExpr(col("k", 0), q.Operator.Lt, q.Literal(q.ScalarValue.Int64(300))))
+    gf, wf = f.execute(), oracle.execute(f)
+    assert [b.num_rows for b in gf] == [b.num_rows for b in wf] and len(gf) == 300
+    assert rows_of(gf) == rows_of(wf)
+    assert rows_of(table_scan(schema, small).execute()) == rows_of([big])
