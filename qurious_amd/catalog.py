@@ -36,6 +36,17 @@ def catalog_sources():
     out.append(("q3 join-1 output keys", planning.keys_source(j1.schema(), [j2.on[0][0]])))
     out.append(("q3 lineitem probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))
     out.append(("q3 aggregate", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+    # small inputs (SF10: 0.3 M joined rows) run the one-row-per-thread variant of the same kernel (csrc/agg.cpp)
+    import os
+    saved = os.environ.get("QHIP_AGG_R")
+    os.environ["QHIP_AGG_R"] = "1"
+    try:
+        out.append(("q3 aggregate, 1 row/thread", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+    finally:
+        if saved is None:
+            os.environ.pop("QHIP_AGG_R", None)
+        else:
+            os.environ["QHIP_AGG_R"] = saved
     top = queries.q3_top10(*tabs)
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)

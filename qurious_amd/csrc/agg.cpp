@@ -174,7 +174,12 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   put(&pred_root, sizeof pred_root);
   put(group_roots, sizeof(int32_t) * (size_t)n_groups);
   put(aggs, sizeof(qhip_agg) * (size_t)n_aggs);
-  const int r_env = env_int("QHIP_AGG_R", 0), kc_env = env_int("QHIP_AGG_KC", -1);
+  // rows per thread: the register-budget rule of plan_aggregate (R = 2..4) suits inputs that fill the chip many times
+  // over; a SMALL input (the 0.3 M joined rows Q3 aggregates) is a latency chain per row — fewer rows per thread and more
+  // workgroups shorten it (Q3's aggregate kernel: 73 -> 49 us)
+  const int64_t small_rows = (int64_t)256 * ctx->num_cus * 8;
+  const int r_env = env_int("QHIP_AGG_R", 0) ? env_int("QHIP_AGG_R", 0) : in->num_rows <= small_rows ? 1 : in->num_rows <= 2 * small_rows ? 2 : 0;
+  const int kc_env = env_int("QHIP_AGG_KC", -1);
   put(&r_env, sizeof r_env); put(&kc_env, sizeof kc_env);
   std::shared_ptr<AggPlan> plan_ptr;
   auto cached = ctx->plan_cache.find(key);
@@ -235,7 +240,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
   const int64_t tile_rows = (int64_t)256 * plan.R;
   const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
-  const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", 4);
+  const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : 4);
   unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
 
   // First attempt: a SMALL table (4096 slots) replicated 32 times, workgroup b merging into replica b % 32. Clearing and
