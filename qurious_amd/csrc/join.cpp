@@ -196,6 +196,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (speculate) {
       check_build_status();
       if (max_count > 1) {   // duplicate build keys after all: remember, and run again with the CSR layout
+        if (ctx->join_dup_builds.size() > 4096) ctx->join_dup_builds.clear();   // a hint, not a record
         ctx->join_dup_builds.insert(dup_hint);
         return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
       }
