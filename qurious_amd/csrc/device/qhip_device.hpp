@@ -629,7 +629,8 @@ template <int W> __device__ __forceinline__ u64 qh_key_hash(const u64* k) {
 
 struct ProbeLaunch {
   const u64* table;      // distinct build keys
-  const u32* bloom;      // one bit per (hash >> 32) & bloom_mask: 0 => the key is not in the table (the filter stays in L2)
+  const u32* bloom;      // hash filter: qh_bloom_bits(h) all set in word ((h >> 32) & bloom_mask) >> 5, else the key is not
+                         // in the table (the filter stays in L2)
   const u32* count;      // build rows per slot (unused when start == nullptr)
   const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
@@ -642,6 +643,12 @@ struct ProbeLaunch {
   u32* status;
   u32 nslots, bloom_mask;
 };
+
+// The build's hash filter is a blocked Bloom filter with TWO bits per key inside ONE 32-bit word (word and first bit from
+// hash bits 32.., second bit from the top five hash bits): the probe still pays one L2 access per row, but with ~11 bits
+// per key the false positives — each of which is a random 128-byte HBM line of the 64 MB table fetched for nothing — drop
+// from ~9 % to ~3 % of the probing rows (Q3 J2: 32 M probing rows, 0.3 M true matches).
+__device__ __forceinline__ u32 qh_bloom_bits(u64 h) { return (1u << ((u32)(h >> 32) & 31u)) | (1u << (u32)(h >> 59)); }
 
 #define QH_PROBE_R 4   // probe rows per thread and tile
 // Probe pass 1 (hash_join.rs:218-275 for every probe batch at once): evaluate the fused scan filter and the key words
@@ -676,7 +683,8 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
     u64 st[R], kw[R][P::W];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      ok[r] = ok[r] && ((fw[r] >> ((u32)(h[r] >> 32) & 31u)) & 1u);
+      const u32 bits = qh_bloom_bits(h[r]);
+      ok[r] = ok[r] && (fw[r] & bits) == bits;
       const u64* slot = L.table + (size_t)(ok[r] ? ((u32)h[r] & (L.nslots - 1)) : 0u) * (1 + P::W);
       st[r] = slot[0];
 #pragma unroll

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // key words visible before the slot reads as ready
             qh_st64<MemHbm>(slot, (u64)i + 2);
             const u32 bit = (u32)(h >> 32) & bloom_mask;
-            atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
+            atomicOr(&bloom[bit >> 5], qh_bloom_bits(h));
             sid = s;
             break;
           }
