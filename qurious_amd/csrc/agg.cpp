@@ -232,7 +232,15 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   // LDS-staged table: as many slots as fit the per-workgroup LDS budget
   uint32_t l_nslots = 0;
   if (plan.W > 0) {
-    const int lds_budget = env_int("QHIP_AGG_LDS_BYTES", 32 * 1024);
+    // Many groups (the plan's previous run says so) on a mid-sized input: every workgroup's LDS table ends up full and is
+    // merged slot by slot into the HBM table at the end, the heavy keys by EVERY workgroup — same-slot atomic traffic that
+    // grows with the number of workgroups, and with ~1000 workgroups x 512 slots as many HBM updates as the input has
+    // rows. One workgroup per CU with a 64 KB table halves the merges and quarters the contention (Q3 with Zipf(1.1)
+    // keys, 1.35 M rows -> 175 k groups: kernel 0.456 -> 0.264 ms). On inputs far bigger than the merge (50 M rows ->
+    // 1 M groups, tools/highcard_timing.py) the rows that miss the LDS table dominate and more workgroups hide their
+    // latency better (4.7 vs 5.3 ms), so the default shape stays.
+    const bool merge_heavy = plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
+    const int lds_budget = env_int("QHIP_AGG_LDS_BYTES", merge_heavy ? 64 * 1024 : 32 * 1024);
     l_nslots = 16;
     while ((uint64_t)l_nslots * 2 * slot_bytes <= (uint64_t)lds_budget) l_nslots *= 2;
     if ((uint64_t)l_nslots * slot_bytes > 64 * 1024) l_nslots = 0;   // slot too wide for LDS staging
@@ -240,7 +248,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
   const int64_t tile_rows = (int64_t)256 * plan.R;
   const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
-  const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : 4);
+  const bool merge_heavy_grid = plan.W > 0 && plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
+  const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : merge_heavy_grid ? 1 : 4);
   unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
 
   // First attempt: a SMALL table (4096 slots) replicated 32 times, workgroup b merging into replica b % 32. Clearing and
