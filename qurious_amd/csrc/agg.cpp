@@ -260,6 +260,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const uint32_t cap_max = plan.W == 0 ? 1 : std::max<uint32_t>(1024, pow2_ceil((uint64_t)std::max<int64_t>(N, 1) * 2));
   uint32_t cap = plan.W == 0 ? 1 : std::min<uint32_t>(cap_max, (uint32_t)env_int("QHIP_AGG_INITIAL_SLOTS", 4096));
   uint32_t replicas = plan.W == 0 ? 1 : (uint32_t)std::max(1, env_int("QHIP_AGG_REPLICAS", 32));
+  if (plan.W > 0 && env_int("QHIP_AGG_PARTITION", 1) == 2) {   // tests: the partitioned path on every grouped aggregate
+    replicas = 1;
+    cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(cap, 4096));
+  }
   if (plan.W > 0 && plan.last_groups > cap / 4) {
     // the same plan produced many groups last time: go straight to one table with room for them
     cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(1u << 16, pow2_ceil((uint64_t)plan.last_groups * 2)));
@@ -434,7 +438,62 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     L.collect_stats = env_int("QHIP_AGG_STATS", 0) ? 1u : 0u;
     void* args[] = {&ka, &L};
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (N > 0)
+    // Many groups on a big input: partition the rows by key hash first, so that every bin's groups fit an LDS table and the
+    // HBM table is touched once per GROUP instead of once per row (device/qhip_device.hpp, "partitioned aggregation").
+    // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
+    const int pa_mode = env_int("QHIP_AGG_PARTITION", 1);
+    const bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena &&
+                             (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768));
+    std::vector<uint32_t> item_first;   // (kept alive until the call's next synchronisation)
+    if (partitioned) {
+      hipStream_t s = ctx->stream;
+      const uint32_t per_bin = std::max<uint32_t>(16, l_nslots * 3 / 8);   // groups a bin should hold: LDS table 3/8 full
+      uint32_t n_bins = 16;
+      while (n_bins < 4096 && (uint64_t)n_bins * per_bin < std::max<uint32_t>(plan.last_groups, 1)) n_bins *= 2;
+      uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)N + 255) / 256, (uint64_t)ctx->num_cus * (uint64_t)std::max(1, env_int("QHIP_AGG_PART_WGS_PER_CU", 4))));
+      const uint64_t rows_per_wg = ((((uint64_t)N + g1 - 1) / g1) + 255) / 256 * 256;
+      g1 = ((uint64_t)N + rows_per_wg - 1) / rows_per_wg;
+      const uint64_t n_hist = (uint64_t)n_bins * g1;
+      DevBuf hist((n_hist + 1) * 4), records((size_t)N * (slot_bytes - 8) + 8), items_dev;
+      std::shared_ptr<Module> m_hist = get_module(ctx, plan.source, "qk_agg_part_hist");
+      std::shared_ptr<Module> m_scat = get_module(ctx, plan.source, "qk_agg_part_scatter");
+      std::shared_ptr<Module> m_red = get_module(ctx, plan.source, "qk_agg_reduce");
+      HPartLaunch pl;
+      pl.hist = hist.as<uint32_t>();
+      pl.records = records.as<uint64_t>();
+      pl.status = status_dev;
+      pl.n_bins = n_bins;
+      pl.rows_per_wg = (uint32_t)rows_per_wg;
+      void* pargs[] = {&ka, &pl};
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(m_hist->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
+      exclusive_scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), n_hist, hist.as<uint32_t>() + n_hist, s);
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(m_scat->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
+      // first record of every bin (= of its first workgroup's run) + the record total: one strided read-back
+      uint32_t* first = (uint32_t*)((uint8_t*)ctx->pinned + 128);
+      QHIP_HIP_CHECK(hipMemcpy2DAsync(first, 4, hist.ptr, (size_t)g1 * 4, 4, n_bins, hipMemcpyDeviceToHost, s));
+      QHIP_HIP_CHECK(hipMemcpyAsync(first + n_bins, hist.as<uint32_t>() + n_hist, 4, hipMemcpyDeviceToHost, s));
+      QHIP_HIP_CHECK(hipStreamSynchronize(s));
+      // work items: a bin, or a slice of a big one (a heavy key's bin is aggregated by several workgroups, each merging
+      // its LDS table into the HBM table: the key is merged once per slice, not once per row)
+      const uint32_t max_item = (uint32_t)std::max(4096, env_int("QHIP_AGG_PARTITION_ITEM", 32768));
+      for (uint32_t b = 0; b < n_bins; ++b)
+        for (uint32_t r = first[b]; r < first[b + 1]; r += max_item) item_first.push_back(r);
+      const uint32_t n_items = (uint32_t)item_first.size();
+      item_first.push_back(first[n_bins]);
+      if (n_items) {
+        items_dev.alloc(item_first.size() * 4);
+        QHIP_HIP_CHECK(hipMemcpyAsync(items_dev.ptr, item_first.data(), item_first.size() * 4, hipMemcpyHostToDevice, s));
+        HReduceLaunch rl;
+        rl.records = records.as<uint64_t>();
+        rl.item_first = items_dev.as<uint32_t>();
+        rl.n_items = n_items;
+        void* rargs[] = {&rl, &L};
+        const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 4);
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, s, rargs, nullptr));
+        QHIP_HIP_CHECK(hipStreamSynchronize(s));   // hist / records / items go back to the pool here; item_first is pageable
+      }
+
+    } else if (N > 0)
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));

@@ -750,9 +750,10 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     }
   }
   s << "  }\n";
-  // slot_merge: LDS slot (plain reads, after the workgroup barrier) -> HBM slot
-  s << "  __device__ static __forceinline__ void slot_merge(u64* gs, const u64* ls) {\n";
-  s << "    const u64* cell = ls + " << 1 + P.W << ";\n    Part q;\n";
+  // part_from_slot / part_to_slot: a slot-shaped record (plain memory) <-> Part; slot_merge: LDS slot (plain reads, after
+  // the workgroup barrier) -> HBM slot
+  s << "  __device__ static __forceinline__ void part_from_slot(const u64* ls, Part& q) {\n";
+  s << "    const u64* cell = ls + " << 1 + P.W << ";\n";
   for (size_t c = 0; c < P.cells.size(); ++c) {
     const CellDesc& cd = P.cells[c];
     const std::string at = "cell[" + std::to_string(cd.off) + "]";
@@ -764,10 +765,32 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
       default: s << "    q.c" << c << " = " << at << ";\n"; break;
     }
   }
+  s << "  }\n";
+  s << "  __device__ static __forceinline__ void part_to_slot(u64* ls, const Part& q) {\n";
+  s << "    u64* cell = ls + " << 1 + P.W << ";\n";
+  for (size_t c = 0; c < P.cells.size(); ++c) {
+    const CellDesc& cd = P.cells[c];
+    const std::string at = "cell[" + std::to_string(cd.off) + "]";
+    const std::string at1 = "cell[" + std::to_string(cd.off + 1) + "]";
+    const std::string C = "q.c" + std::to_string(c);
+    switch (cd.kind) {
+      case CELL_SUM_I128: case CELL_MAXORD128: s << "    " << at << " = (u64)(u128)" << C << "; " << at1 << " = (u64)((u128)" << C << " >> 64);\n"; break;
+      case CELL_SUM_F64: s << "    " << at << " = (u64)__double_as_longlong(" << C << ");\n"; break;
+      default: s << "    " << at << " = " << C << ";\n"; break;
+    }
+  }
+  s << "  }\n";
+  s << "  __device__ static __forceinline__ void slot_merge(u64* gs, const u64* ls) {\n    Part q;\n    part_from_slot(ls, q);\n";
   s << "    slot_update<MemHbm>(gs, q);\n  }\n";
   s << "};\n";
   P.kernel_name = "qk_filter_agg";
   s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P>(a, L); }\n";
+  if (P.W > 0) {
+    // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_hist(KArgs a, PartLaunch L) { qh_agg_part_body<P, false>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_scatter(KArgs a, PartLaunch L) { qh_agg_part_body<P, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_reduce(ReduceLaunch R, AggLaunch L) { qh_agg_reduce_body<P>(R, L); }\n";
+  }
   P.source = s.str();
   P.bind = g.bind;
 }

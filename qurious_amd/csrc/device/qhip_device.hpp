@@ -385,6 +385,29 @@ __device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L,
   }
 }
 
+// Every ready slot of the workgroup's LDS table is merged into the HBM table (one find-or-insert + the cells' atomics per
+// slot); returns this thread's count of merged slots. Callers synchronise the workgroup before.
+template <class P>
+__device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& L) {
+  constexpr int W = P::W;
+  u32 used = 0;
+  for (u32 s = threadIdx.x; s < L.l_nslots; s += QH_BLOCK) {
+    u64* ls = ltable + (size_t)s * P::SLOT_WORDS;
+    if (ls[0] == QH_READY) {
+      ++used;
+      u64 key[W > 0 ? W : 1];
+      u64 h = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { key[w] = ls[1 + w]; h = qh_mix64(h ^ key[w]); }
+      bool inserted;
+      u64* gs = qh_find_or_insert<MemHbm, W>(L.gtable, L.g_nslots, P::SLOT_WORDS, key, h, QH_HBM_MAX_PROBE, &inserted);
+      if (!gs) atomicOr(&L.status[QS_OVERFLOW], 1u);
+      else P::slot_merge(gs, ls);
+    }
+  }
+  return used;
+}
+
 template <class P>
 __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
@@ -552,21 +575,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   }
   // ---- merge this workgroup's LDS table into the HBM table
   __syncthreads();
-  u32 used = 0;
-  for (u32 s = tid; s < L.l_nslots; s += QH_BLOCK) {
-    u64* ls = ltable + (size_t)s * P::SLOT_WORDS;
-    if (ls[0] == QH_READY) {
-      ++used;
-      u64 key[W > 0 ? W : 1];
-      u64 h = 0;
-#pragma unroll
-      for (int w = 0; w < W; ++w) { key[w] = ls[1 + w]; h = qh_mix64(h ^ key[w]); }
-      bool inserted;
-      u64* gs = qh_find_or_insert<MemHbm, W>(L.gtable, L.g_nslots, P::SLOT_WORDS, key, h, QH_HBM_MAX_PROBE, &inserted);
-      if (!gs) atomicOr(&L.status[QS_OVERFLOW], 1u);
-      else P::slot_merge(gs, ls);
-    }
-  }
+  u32 used = qh_merge_lds_table<P>(ltable, L);
   if (L.collect_stats && L.l_nslots) {
     // LDS-table occupancy (statistics runs only): one global atomic per workgroup
     __syncthreads();
@@ -578,6 +587,102 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     __syncthreads();
     if (tid == 0 && *total) atomicAdd(&L.status[QS_LDS_USED], *total);
   }
+}
+
+// ------------------------------------------------------------------ partitioned aggregation (many groups on a big input)
+// Groups that do not fit the workgroup's LDS table cost one random HBM line and two or three HBM atomics per ROW in the
+// kernel above (~30 G operations/s: 50 M rows -> 1 M groups in 4.7 ms). Here the rows are first split by key hash into
+// bins whose groups DO fit an LDS table — sequential traffic only — and every bin is then aggregated in LDS and merged
+// into the HBM table once per GROUP:
+//   pass 1  qh_agg_part_body<P, false>  per-workgroup histogram of the passing rows over the bins
+//           (exclusive scan of hist[bin][workgroup], bin-major -> every (bin, workgroup) run's first record)
+//   pass 2  qh_agg_part_body<P, true>   the same rows again (same static row range per workgroup): each becomes a
+//                                       record [key words | its partial cells] (a slot minus the state word) in its run
+//   pass 3  qh_agg_reduce_body<P>       work items = record ranges of one bin (big bins are cut): LDS table, then the
+//                                       merge into the HBM table; the usual compaction / finalisation follows
+struct PartLaunch {
+  u32* hist;        // [n_bins][gridDim.x] counts (pass 1 out) / exclusive scan = first record of the run (pass 2 in)
+  u64* records;     // pass 2 out: SLOT_WORDS - 1 words per record
+  u32* status;
+  u32 n_bins;       // power of two, <= 4096
+  u32 rows_per_wg;  // static row range of a workgroup (multiple of QH_BLOCK)
+};
+
+__device__ __forceinline__ u32 qh_part_bin(u64 h, u32 n_bins) { return (u32)(h >> 40) & (n_bins - 1); }   // the HBM table uses the LOW bits
+
+template <class P, bool SCATTER>
+__device__ __forceinline__ void qh_agg_part_body(const KArgs& a, const PartLaunch& L) {
+  constexpr int W = P::W;
+  u32* cnt = (u32*)qh_dyn_lds;              // [n_bins] counts (pass 1) / next free record of the bin's run (pass 2)
+  const u32 tid = threadIdx.x;
+  for (u32 b = tid; b < L.n_bins; b += QH_BLOCK) cnt[b] = SCATTER ? L.hist[(size_t)b * gridDim.x + blockIdx.x] : 0u;
+  __syncthreads();
+  const i64 first = (i64)blockIdx.x * L.rows_per_wg;
+  const i64 last = first + L.rows_per_wg < a.nrows ? first + L.rows_per_wg : a.nrows;
+  u32 err = 0;
+  for (i64 tb = first; tb < last; tb += QH_BLOCK) {
+    const bool inb = tb + tid < last;
+    typename P::Raw raw;
+    typename P::Row row;
+    P::load(a, tb, inb ? tid : (u32)(last - 1 - tb), raw);
+    u32 e = 0;
+    P::eval(a, raw, row, e);
+    err |= inb ? e : 0u;
+    if (row.pass && inb) {
+      u64 h = 0;
+#pragma unroll
+      for (int w = 0; w < W; ++w) h = qh_mix64(h ^ row.key[w]);
+      const u32 pos = atomicAdd(&cnt[qh_part_bin(h, L.n_bins)], 1u);
+      if (SCATTER) {
+        typename P::Part part;
+        P::part_init(part);
+        P::template part_add<true>(part, row, true);
+        // a record is a slot without its state word: [key words | cells] (the slot-shaped view starts one word earlier)
+        u64* rec = L.records + (size_t)pos * (P::SLOT_WORDS - 1) - 1;
+#pragma unroll
+        for (int w = 0; w < W; ++w) rec[1 + w] = row.key[w];
+        P::part_to_slot(rec, part);
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (u32 b = tid; b < L.n_bins; b += QH_BLOCK) L.hist[(size_t)b * gridDim.x + blockIdx.x] = cnt[b];
+    qh_report(L.status, err);   // (pass 2 sees the same rows: errors are reported once)
+  }
+}
+
+struct ReduceLaunch {
+  const u64* records;
+  const u32* item_first;   // work item k = records [item_first[k], item_first[k + 1]), all of one bin
+  u32 n_items;
+};
+
+template <class P>
+__device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const AggLaunch& L) {
+  constexpr int W = P::W;
+  u64* ltable = (u64*)qh_dyn_lds;
+  const u32 tid = threadIdx.x;
+  const u32 lwords = L.l_nslots * (u32)P::SLOT_WORDS;
+  u32 err = 0;
+  for (u32 item = blockIdx.x; item < R.n_items; item += gridDim.x) {
+    for (u32 k = tid; k < lwords; k += QH_BLOCK) ltable[k] = 0;
+    __syncthreads();
+    const u32 r0 = R.item_first[item], r1 = R.item_first[item + 1];
+    for (u32 i = r0 + tid; i < r1; i += QH_BLOCK) {
+      const u64* rec = R.records + (size_t)i * (P::SLOT_WORDS - 1) - 1;
+      u64 key[W > 0 ? W : 1];
+#pragma unroll
+      for (int w = 0; w < W; ++w) key[w] = rec[1 + w];
+      typename P::Part part;
+      P::part_from_slot(rec, part);
+      qh_update_group<P>(ltable, L, key, part, err);   // LDS table; a bin with more groups than it holds spills to HBM
+    }
+    __syncthreads();
+    (void)qh_merge_lds_table<P>(ltable, L);
+    __syncthreads();
+  }
+  qh_report(L.status, err);
 }
 
 // ------------------------------------------------------------------ predicate -> selection mask kernel

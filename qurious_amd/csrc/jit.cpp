@@ -74,7 +74,10 @@ std::string cache_path_for(const std::string& dir, const std::string& full_sourc
 }
 
 std::shared_ptr<Module> get_module(Ctx* ctx, const std::string& policy_source, const std::string& kernel_name) {
-  auto it = ctx->modules.find(policy_source);
+  // one loaded module per (source, entry point): a policy source may hold several kernels (the aggregate's partitioned
+  // path); the code object is compiled and cached once per source either way
+  const std::string mkey = policy_source + "\n//entry:" + kernel_name;
+  auto it = ctx->modules.find(mkey);
   if (it != ctx->modules.end()) return it->second;
   const auto t0 = std::chrono::steady_clock::now();
   const std::string src = full_source_for(policy_source);
@@ -105,7 +108,7 @@ std::shared_ptr<Module> get_module(Ctx* ctx, const std::string& policy_source, c
   // a long-lived context that keeps seeing new plans does not keep every code object loaded for ever: beyond 512 modules
   // the in-memory cache starts over (callers hold shared_ptrs to what they are running; the disk cache still has the rest)
   if (ctx->modules.size() >= 512) ctx->modules.clear();
-  ctx->modules[policy_source] = m;
+  ctx->modules[mkey] = m;
   ctx->stats.jit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return m;
 }

@@ -35,6 +35,23 @@ struct HAggLaunch {
 };
 static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
 
+// host mirrors of PartLaunch / ReduceLaunch (the aggregate's partitioned path)
+struct HPartLaunch {
+  uint32_t* hist;
+  uint64_t* records;
+  uint32_t* status;
+  uint32_t n_bins;
+  uint32_t rows_per_wg;
+};
+static_assert(sizeof(HPartLaunch) == 32, "PartLaunch layout");
+struct HReduceLaunch {
+  const uint64_t* records;
+  const uint32_t* item_first;
+  uint32_t n_items;
+  uint32_t pad_ = 0;
+};
+static_assert(sizeof(HReduceLaunch) == 24, "ReduceLaunch layout");
+
 struct HProjOut {
   void* v[kMaxCols];
   uint64_t* n[kMaxCols];
