@@ -398,6 +398,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   bool spec_enqueued = false;
   uint64_t* table_dev = nullptr;
   uint64_t* dense_dev = nullptr;    // [counter | dense slots]
+  bool ran_partitioned = false;
   for (;;) {
     const size_t table_bytes = (size_t)cap * replicas * slot_bytes;
     const uint32_t total_slots = cap * replicas;
@@ -446,6 +447,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
                              (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768));
     std::vector<uint32_t> item_first;   // (kept alive until the call's next synchronisation)
     if (partitioned) {
+      ran_partitioned = true;
       hipStream_t s = ctx->stream;
       const uint32_t per_bin = std::max<uint32_t>(16, l_nslots * 3 / 8);   // groups a bin should hold: LDS table 3/8 full
       uint32_t n_bins = 16;
@@ -587,7 +589,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
       ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
       ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : plan.kernel_name.c_str());
       return result;
     }
     if (replicas == 1 && G >= dev_threshold) {
@@ -663,7 +665,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
     ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", plan.kernel_name.c_str());
+    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : plan.kernel_name.c_str());
   };
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe

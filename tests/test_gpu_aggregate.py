@@ -212,3 +212,48 @@ def test_device_side_output_assembly_matches_host_side(ctx, oracle, monkeypatch)
     for k in g2:
         for a, b in zip(g2[k], w2[k]):
             assert (a is None and b is None) or abs(a - b) <= 1e-6 * max(1.0, abs(b))
+
+
+def test_partitioned_path_for_many_groups(ctx, oracle, monkeypatch):
+    """the partitioned aggregate (rows split by key-hash bin, per-bin LDS aggregation, one HBM merge per group — what runs for
+    many groups on a big input) forced on: every cell kind, NULL keys and values, two keys incl. Utf8, a fused filter,
+    heavy keys next to a long tail, more groups than one LDS table per bin holds"""
+    import decimal
+    monkeypatch.setenv("QHIP_AGG_PARTITION", "2")
+    rng = np.random.default_rng(41)
+    n = 300_000
+    heavy = rng.random(n) < 0.3
+    k = np.where(heavy, rng.integers(0, 5, n), rng.integers(0, 120_000, n))
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("v", I64), pa.field("d", pa.decimal128(15, 2)), pa.field("f", pa.float64())])
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(k, type=I64, mask=rng.random(n) < 0.02),
+        pa.array(["g%d" % v for v in rng.integers(0, 7, n)], type=pa.string(), mask=rng.random(n) < 0.02),
+        pa.array(rng.integers(-10**9, 10**9, n), type=I64, mask=rng.random(n) < 0.1),
+        pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**10, 10**10, n)], type=pa.decimal128(15, 2), mask=rng.random(n) < 0.1),
+        pa.array(rng.integers(-1000, 1000, n).astype(np.float64), type=pa.float64(), mask=rng.random(n) < 0.1)], schema=schema)
+    scan = table_scan(schema, [batch.slice(0, 100_000), batch.slice(100_000, 0), batch.slice(100_000)])
+    D = pa.decimal128(15, 2)
+    aggs = [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(col("v", 2)), q.CountAggregateExpr(lit_i64(1)),
+            q.MinAggregateExpr(col("v", 2), I64), q.MaxAggregateExpr(col("d", 3), D), q.SumAggregateExpr(col("d", 3), D),
+            q.AvgAggregateExpr(col("d", 3), D, pa.decimal128(19, 6)), q.SumAggregateExpr(col("f", 4), pa.float64()),
+            q.MinAggregateExpr(col("f", 4), pa.float64())]
+    got = _same(q.HashAggregate(None, scan, [col("k", 0)], aggs), oracle)
+    assert len(got) > 90_000
+    assert ctx.last_stats()["main_kernel_name"].startswith("qk_agg_part")
+    _same(q.HashAggregate(None, scan, [col("k", 0), col("s", 1)], aggs[:4]), oracle)
+    pred = q.BinaryExpr(col("v", 2), Operator.Gt, lit_i64(0))
+    _same(q.HashAggregate(None, q.Scan(schema, scan.datasource, None, pred), [col("k", 0)], aggs[:3]), oracle)
+    # the automatic choice: a plan that produced many groups from a big input partitions its next run by itself
+    monkeypatch.delenv("QHIP_AGG_PARTITION")
+    m = 5_000_000
+    kk = rng.integers(0, 400_000, m)
+    big = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+    bscan = table_scan(big, [pa.RecordBatch.from_arrays([pa.array(kk, type=I64), pa.array(rng.integers(0, 100, m), type=I64)], schema=big)])
+    plan = q.HashAggregate(None, bscan, [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64), q.CountAggregateExpr(lit_i64(1))])
+    first = sorted(rows_of(plan.execute()))
+    assert not ctx.last_stats()["main_kernel_name"].startswith("qk_agg_part")
+    second = sorted(rows_of(plan.execute()))
+    assert ctx.last_stats()["main_kernel_name"].startswith("qk_agg_part")
+    assert first == second and len(first) == len(np.unique(kk))
+    sums = np.bincount(kk, weights=None, minlength=400_000)
+    assert [r[2] for r in first] == [int(c) for c in sums[sums > 0]]
