@@ -452,6 +452,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       const uint32_t per_bin = std::max<uint32_t>(16, l_nslots * 3 / 8);   // groups a bin should hold: LDS table 3/8 full
       uint32_t n_bins = 16;
       while (n_bins < 4096 && (uint64_t)n_bins * per_bin < std::max<uint32_t>(plan.last_groups, 1)) n_bins *= 2;
+      if (env_int("QHIP_AGG_PART_BINS", 0) >= 16) n_bins = (uint32_t)pow2_ceil((uint64_t)std::min(4096, env_int("QHIP_AGG_PART_BINS", 0)));
       uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)N + 255) / 256, (uint64_t)ctx->num_cus * (uint64_t)std::max(1, env_int("QHIP_AGG_PART_WGS_PER_CU", 4))));
       const uint64_t rows_per_wg = ((((uint64_t)N + g1 - 1) / g1) + 255) / 256 * 256;
       g1 = ((uint64_t)N + rows_per_wg - 1) / rows_per_wg;
