@@ -443,7 +443,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // HBM table is touched once per GROUP instead of once per row (device/qhip_device.hpp, "partitioned aggregation").
     // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
     const int pa_mode = env_int("QHIP_AGG_PARTITION", 1);
-    const bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena &&
+    // (an instrumented run, QHIP_AGG_STATS, measures the fused kernel's LDS table and keeps to it)
+    const bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
                              (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768));
     std::vector<uint32_t> item_first;   // (kept alive until the call's next synchronisation)
     if (partitioned) {
