@@ -620,28 +620,46 @@ __device__ __forceinline__ void qh_agg_part_body(const KArgs& a, const PartLaunc
   const i64 first = (i64)blockIdx.x * L.rows_per_wg;
   const i64 last = first + L.rows_per_wg < a.nrows ? first + L.rows_per_wg : a.nrows;
   u32 err = 0;
-  for (i64 tb = first; tb < last; tb += QH_BLOCK) {
-    const bool inb = tb + tid < last;
-    typename P::Raw raw;
-    typename P::Row row;
-    P::load(a, tb, inb ? tid : (u32)(last - 1 - tb), raw);
-    u32 e = 0;
-    P::eval(a, raw, row, e);
-    err |= inb ? e : 0u;
-    if (row.pass && inb) {
-      u64 h = 0;
+  // PR rows per thread and iteration, in phases like the fused kernel: all loads of the tile first (their latencies
+  // overlap), then evaluation and the LDS rank, then the record stores
+  constexpr int PR = 4;
+  for (i64 tb = first; tb < last; tb += (i64)QH_BLOCK * PR) {
+    typename P::Raw raw[PR];
+    typename P::Row row[PR];
 #pragma unroll
-      for (int w = 0; w < W; ++w) h = qh_mix64(h ^ row.key[w]);
-      const u32 pos = atomicAdd(&cnt[qh_part_bin(h, L.n_bins)], 1u);
-      if (SCATTER) {
-        typename P::Part part;
-        P::part_init(part);
-        P::template part_add<true>(part, row, true);
-        // a record is a slot without its state word: [key words | cells] (the slot-shaped view starts one word earlier)
-        u64* rec = L.records + (size_t)pos * (P::SLOT_WORDS - 1) - 1;
+    for (int r = 0; r < PR; ++r) {
+      const u32 o = (u32)r * QH_BLOCK + tid;
+      P::load(a, tb, tb + (i64)o < last ? o : (u32)(last - 1 - tb), raw[r]);
+    }
+    u32 pos[PR];
 #pragma unroll
-        for (int w = 0; w < W; ++w) rec[1 + w] = row.key[w];
-        P::part_to_slot(rec, part);
+    for (int r = 0; r < PR; ++r) {
+      const bool inb = tb + (i64)((u32)r * QH_BLOCK + tid) < last;
+      u32 e = 0;
+      P::eval(a, raw[r], row[r], e);
+      err |= inb ? e : 0u;
+      row[r].pass = row[r].pass && inb;
+      pos[r] = 0;
+      if (row[r].pass) {
+        u64 h = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) h = qh_mix64(h ^ row[r].key[w]);
+        pos[r] = atomicAdd(&cnt[qh_part_bin(h, L.n_bins)], 1u);
+      }
+    }
+    if (SCATTER) {
+#pragma unroll
+      for (int r = 0; r < PR; ++r) {
+        if (row[r].pass) {
+          typename P::Part part;
+          P::part_init(part);
+          P::template part_add<true>(part, row[r], true);
+          // a record is a slot without its state word: [key words | cells] (the slot-shaped view starts one word earlier)
+          u64* rec = L.records + (size_t)pos[r] * (P::SLOT_WORDS - 1) - 1;
+#pragma unroll
+          for (int w = 0; w < W; ++w) rec[1 + w] = row[r].key[w];
+          P::part_to_slot(rec, part);
+        }
       }
     }
   }
@@ -669,14 +687,23 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
     for (u32 k = tid; k < lwords; k += QH_BLOCK) ltable[k] = 0;
     __syncthreads();
     const u32 r0 = R.item_first[item], r1 = R.item_first[item + 1];
-    for (u32 i = r0 + tid; i < r1; i += QH_BLOCK) {
-      const u64* rec = R.records + (size_t)i * (P::SLOT_WORDS - 1) - 1;
-      u64 key[W > 0 ? W : 1];
+    constexpr int RR = 4;   // records per thread and iteration: their loads are issued together
+    for (u32 i0 = r0; i0 < r1; i0 += QH_BLOCK * RR) {
+      u64 key[RR][W > 0 ? W : 1];
+      typename P::Part part[RR];
+      bool live[RR];
 #pragma unroll
-      for (int w = 0; w < W; ++w) key[w] = rec[1 + w];
-      typename P::Part part;
-      P::part_from_slot(rec, part);
-      qh_update_group<P>(ltable, L, key, part, err);   // LDS table; a bin with more groups than it holds spills to HBM
+      for (int r = 0; r < RR; ++r) {
+        const u32 i = i0 + (u32)r * QH_BLOCK + tid;
+        live[r] = i < r1;
+        const u64* rec = R.records + (size_t)(live[r] ? i : r1 - 1) * (P::SLOT_WORDS - 1) - 1;
+#pragma unroll
+        for (int w = 0; w < W; ++w) key[r][w] = rec[1 + w];
+        P::part_from_slot(rec, part[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < RR; ++r)
+        if (live[r]) qh_update_group<P>(ltable, L, key[r], part[r], err);   // LDS table; a bin with more groups than it holds spills to HBM
     }
     __syncthreads();
     (void)qh_merge_lds_table<P>(ltable, L);
