@@ -444,9 +444,19 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
     const int pa_mode = env_int("QHIP_AGG_PARTITION", 1);
     // (an instrumented run, QHIP_AGG_STATS, measures the fused kernel's LDS table and keeps to it)
-    const bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
+    bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
                              (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768));
     std::vector<uint32_t> item_first;   // (kept alive until the call's next synchronisation)
+    // the record buffer is as big as the input's key + argument columns: when HBM cannot hold it the fused kernel runs
+    DevBuf pa_records;
+    if (partitioned) {
+      try {
+        pa_records.alloc((size_t)N * (slot_bytes - 8) + 8);
+      } catch (const Error& e) {
+        if (e.code != QHIP_OUT_OF_MEMORY) throw;
+        partitioned = false;
+      }
+    }
     if (partitioned) {
       ran_partitioned = true;
       hipStream_t s = ctx->stream;
@@ -458,7 +468,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       const uint64_t rows_per_wg = ((((uint64_t)N + g1 - 1) / g1) + 255) / 256 * 256;
       g1 = ((uint64_t)N + rows_per_wg - 1) / rows_per_wg;
       const uint64_t n_hist = (uint64_t)n_bins * g1;
-      DevBuf hist((n_hist + 1) * 4), records((size_t)N * (slot_bytes - 8) + 8), items_dev;
+      DevBuf hist((n_hist + 1) * 4), items_dev;
+      DevBuf& records = pa_records;
       std::shared_ptr<Module> m_hist = get_module(ctx, plan.source, "qk_agg_part_hist");
       std::shared_ptr<Module> m_scat = get_module(ctx, plan.source, "qk_agg_part_scatter");
       std::shared_ptr<Module> m_red = get_module(ctx, plan.source, "qk_agg_reduce");
