@@ -157,6 +157,14 @@ def test_exchange_join_world2_gloo(tmp_path):
     assert int(open(tmp_path / "ok").read()) > 1000
 
 
+def test_exchange_join_world3_gloo(tmp_path):
+    """an odd number of ranks: uneven slices, three-way grouped send / receive rounds"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert int(open(tmp_path / "ok").read()) > 1000
+
+
 def test_partition_rule_is_deterministic_and_balanced():
     from oracle import qoracle
     keys = pa.array(np.arange(100000), type=I64)
