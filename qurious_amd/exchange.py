@@ -77,6 +77,12 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None, meta: Optional[
     rank = dist.get_rank(group)
     assert len(send) == world
     dev = send[0].device
+    # gloo moves host memory only: device tensors are staged through the host there (how several processes sharing ONE
+    # GPU rehearse the exchange, tools/exchange_rehearsal.py --world 2); RCCL sends device memory as it is
+    out_dev = dev
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        send = [t.cpu() for t in send]
+        dev = torch.device("cpu")
     t_start = time.perf_counter()
     n_meta = len(meta[0]) if meta else 0
     head_out = torch.tensor([[send[r].numel()] + (list(meta[r]) if meta else []) for r in range(world)], dtype=torch.int64).to(dev)
@@ -107,6 +113,11 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None, meta: Optional[
             w.wait()
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
+    if out_dev != dev:
+        staged = _Received(t.to(out_dev) for t in recv)
+        staged.meta = recv.meta
+        recv = staged
+        torch.cuda.synchronize(out_dev)
     _STATS["bytes_sent"] += sum(int(t.numel()) for r, t in enumerate(send) if r != rank)
     _STATS["bytes_received"] += sum(int(t.numel()) for r, t in enumerate(recv) if r != rank)
     _STATS["seconds"] += time.perf_counter() - t_start

@@ -187,6 +187,11 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    # two PROCESSES sharing the GPU, each with its slice of the tables, exchanging over gloo (device buffers staged through
+    # the host): real cross-rank partition / transport / unpack / join / merge; the union equals the single-process plan
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2"],
+                       env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and r.stdout.count("equal to the single-process plan") == 2, r.stdout[-2000:] + r.stderr[-4000:]
     env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     for extra in (["--rows", "3000000", "--no-extra", "--no-cpu-baseline"], ["--workload", "q3", "--sf", "0.2", "--no-cpu-baseline"],
                   ["--workload", "q3", "--sf", "0.2", "--strategy", "repartition", "--no-cpu-baseline"]):

@@ -25,10 +25,65 @@ def rows_of(batches):
     return sorted(out, key=repr)
 
 
+def two_rank_worker(rank, world, port, sf, out_dir):
+    """`world` PROCESSES sharing the one GPU, each with its own libqhip context and its slice of the tables, exchanging over
+    gloo (device tensors staged through the host): partition -> wire images -> transport between different ranks ->
+    unpack + concat -> join / merge. The union of the ranks' results must equal the single-process plan over all rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ctx = q.get_context()
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c, o, l = synth.q3_tables(sf, rank, world)
+        mine = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+                q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+        results = {}
+        for name, plan in (("repartition", queries.q3(*mine, join_cls=exchange.DistributedHashJoinExec)),
+                           ("broadcast", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
+            exchange.prune_exchange_columns(plan)
+            exchange.exchange_stats()
+            local = rows_of(plan.execute_device().to_batches())
+            st = exchange.exchange_stats()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (local, st["bytes_sent"]))
+            results[name] = gathered
+        if rank == 0:
+            cc, oo, ll = synth.q3_tables(sf)
+            whole = queries.q3(q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, cc), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, oo),
+                               q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, ll))
+            want = rows_of(whole.execute())
+            for name, gathered in results.items():
+                got = sorted((r for part, _ in gathered for r in part), key=repr)
+                keys = [r[0] for r in got]
+                assert got == want and len(keys) == len(set(keys)) and len(want) > 100, f"{name}: union of the ranks differs from the single-process plan"
+                assert all(sent > 0 for _, sent in gathered)            # every rank really sent rows to the others
+                print(f"[rehearsal] {world} processes, {name}: {len(got)} groups in all ({[len(p) for p, _ in gathered]} per rank) equal to the "
+                      f"single-process plan; bytes sent per rank {[s for _, s in gathered]}")
+            open(os.path.join(out_dir, "ok_two_rank"), "w").write(str(len(want)))
+        ctx.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sf", type=float, default=0.2)
+    ap.add_argument("--world", type=int, default=1, help="> 1: that many processes share the GPU and exchange over gloo")
     args = ap.parse_args()
+    if args.world > 1:
+        import socket
+        import tempfile
+        import torch.multiprocessing as mp
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(two_rank_worker, args=(args.world, port, args.sf, d), nprocs=args.world, join=True)
+            assert os.path.exists(os.path.join(d, "ok_two_rank"))
+        print("REHEARSAL OK")
+        return
     os.environ["QHIP_EXCHANGE_FORCE"] = "1"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
