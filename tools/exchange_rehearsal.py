@@ -5,7 +5,10 @@ code a multi-GPU launch runs is executed — and checked against the plain singl
 one-GPU box the tests get. (What it cannot show is the transport between two different GPUs; the world_size-2 gloo tests
 in tests/test_distributed_cpu.py cover the protocol of the rounds.)
 
-    python tools/exchange_rehearsal.py [--sf 0.2]
+With --world N (> 1) it instead starts N processes that share the GPU, each holding its slice of the tables, and lets
+them exchange over gloo (device buffers staged through the host): everything but RCCL's own transport runs across ranks.
+
+    python tools/exchange_rehearsal.py [--sf 0.2] [--world 2]
 """
 import argparse
 import os
