@@ -7,7 +7,6 @@ from typing import Optional, Sequence, Tuple
 
 import pyarrow as pa
 
-from . import _ffi
 from .datatypes import JoinType
 from .expr import AggregateExpr, PhysicalExpr
 from .plan import (CrossJoin, Filter, HashAggregate, HashJoinExec, JoinFilter, Limit, MemoryTable, NestedLoopJoinExec, NoGroupingAggregate, PhysicalPlan,
