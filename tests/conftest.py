@@ -37,3 +37,42 @@ def oracle():
 def ctx():
     """The process-wide HIP context; GPU tests fail loudly (no skip, no fallback) when it cannot be created."""
     return qurious_amd.get_context()
+
+
+class _OracleEngine:
+    """The CPU oracle as an engine: execute(plan) / evaluate(expr, batch)."""
+    name = "oracle"
+
+    def __init__(self, qoracle):
+        self._o = qoracle
+
+    def execute(self, plan):
+        return self._o.execute(plan)
+
+    def evaluate(self, expr, batch):
+        return self._o.evaluate(expr, batch)
+
+
+class _HipEngine:
+    """The product path as an engine: plans execute through libqhip's C ABI; an expression is evaluated the way the
+    reference's Projection does it (projection.rs:27-46), over a one-batch MemoryTable."""
+    name = "hip"
+
+    def execute(self, plan):
+        return plan.execute()
+
+    def evaluate(self, expr, batch):
+        import pyarrow as pa
+        scan = qurious_amd.Scan(batch.schema, qurious_amd.MemoryTable.try_new(batch.schema, [batch]), None, None)
+        out = qurious_amd.Projection(None, scan, [expr]).execute()
+        return pa.concat_arrays([b.column(0) for b in out]) if len(out) != 1 else out[0].column(0)
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request):
+    if request.param == "oracle":
+        from oracle import qoracle
+        qoracle.lib()
+        return _OracleEngine(qoracle)
+    qurious_amd.get_context()   # fails loudly without a gfx950 device: no fallback
+    return _HipEngine()

@@ -124,7 +124,17 @@ def test_planner_choices_mirror_the_reference():
     assert type(agg) is q.HashAggregate and agg.children() == [scan]
     assert isinstance(pl.physical_plan_filter(scan, q.IsNull(col("a", 0))), q.Filter)
     j = pl.physical_plan_join(scan, scan, q.JoinType.Left, [(col("a", 0), col("a", 0))], None)
-    assert isinstance(j, q.HashJoinExec) and [f.nullable for f in j.schema()] == [True, True, True, True] or True
+    assert isinstance(j, q.HashJoinExec)
+    # join/mod.rs:55-61 on a schema with one NOT NULL and one nullable field per side: Left keeps the left side's
+    # nullability and makes every right field nullable; Inner keeps both; Full makes everything nullable
+    mixed = pa.schema([pa.field("a", pa.int64(), False), pa.field("b", pa.int64(), True)])
+    mscan = pl.physical_plan_table_scan(mixed, q.MemoryTable.try_new(mixed, []), None)
+    on = [(col("a", 0), col("a", 0))]
+    assert [f.nullable for f in pl.physical_plan_join(mscan, mscan, q.JoinType.Left, on, None).schema()] == [False, True, True, True]
+    assert [f.nullable for f in pl.physical_plan_join(mscan, mscan, q.JoinType.Right, on, None).schema()] == [True, True, False, True]
+    assert [f.nullable for f in pl.physical_plan_join(mscan, mscan, q.JoinType.Inner, on, None).schema()] == [False, True, False, True]
+    assert [f.nullable for f in pl.physical_plan_join(mscan, mscan, q.JoinType.Full, on, None).schema()] == [True, True, True, True]
+    assert [f.nullable for f in pl.physical_plan_join(mscan, mscan, q.JoinType.LeftAnti, on, None).schema()] == [False, True]
     assert [f.name for f in j.schema()] == ["a", "b", "a", "b"] and j.children() == [scan, scan]
     assert isinstance(pl.physical_plan_join(scan, scan, q.JoinType.Inner, [], None), q.NestedLoopJoinExec)   # planner/mod.rs:316-320
     # join schema nullability by join type (join/mod.rs:55-61)

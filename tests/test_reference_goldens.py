@@ -1,5 +1,8 @@
-"""Pin the CPU oracle (oracle/qoracle.c) against every golden vector the reference's own tests hold for the
-hot path (tests/golden/reference_vectors.json). CPU only."""
+"""Every golden vector the reference's own tests hold for the hot path (SURVEY Appendix B,
+tests/golden/reference_vectors.json), replayed through an `engine` (tests/conftest.py): the CPU oracle
+(oracle/qoracle.c — this pins it; runs under -m "not gpu") and the HIP path through the C ABI (`[hip]`, marked gpu).
+The SipHash / JoinHashMap vectors concern structures only the oracle has (the HIP path keys its tables by the real key
+words) and stay oracle-only."""
 import decimal
 
 import numpy as np
@@ -100,38 +103,38 @@ def _join_case(case):
     return q.HashJoinExec.try_new(left, right, JoinType[case["join_type"]], on, None)
 
 
-def test_hash_join_exec_goldens(oracle, golden):
+def test_hash_join_exec_goldens(engine, golden):
     for case in golden["hash_join_exec"]["cases"]:
-        got = rows_of(oracle.execute(_join_case(case)))
+        got = rows_of(engine.execute(_join_case(case)))
         assert got == [tuple(r) for r in case["expected"]], case["name"]
 
 
 # ---------------------------------------------------------------- expression vectors (binary.rs:100-251)
-def test_binary_expr_int32_vectors(oracle, golden):
+def test_binary_expr_int32_vectors(engine, golden):
     for case in golden["binary_expr_int32"]["cases"]:
         batch = pa.RecordBatch.from_arrays([pa.array(case["l"], type=pa.int32()), pa.array(case["r"], type=pa.int32())], names=["a", "b"])
         e = q.BinaryExpr(col("a", 0), Operator[case["op"]], col("b", 1))
-        assert oracle.evaluate(e, batch).to_pylist() == case["expected"], case["op"]
+        assert engine.evaluate(e, batch).to_pylist() == case["expected"], case["op"]
 
 
-def test_binary_expr_boolean_vectors(oracle, golden):
+def test_binary_expr_boolean_vectors(engine, golden):
     g = golden["binary_expr_boolean"]
     batch = pa.RecordBatch.from_arrays([pa.array(g["l"]), pa.array(g["r"])], names=["a", "b"])
     for op in ("And", "Or"):
-        assert oracle.evaluate(q.BinaryExpr(col("a", 0), Operator[op], col("b", 1)), batch).to_pylist() == g[op]
+        assert engine.evaluate(q.BinaryExpr(col("a", 0), Operator[op], col("b", 1)), batch).to_pylist() == g[op]
 
 
-def test_kleene_logic(oracle):
+def test_kleene_logic(engine):
     a = pa.array([True, True, True, False, False, False, None, None, None])
     b = pa.array([True, False, None, True, False, None, True, False, None])
     batch = pa.RecordBatch.from_arrays([a, b], names=["a", "b"])
-    assert oracle.evaluate(q.BinaryExpr(col("a", 0), Operator.And, col("b", 1)), batch).to_pylist() == \
+    assert engine.evaluate(q.BinaryExpr(col("a", 0), Operator.And, col("b", 1)), batch).to_pylist() == \
         [True, False, None, False, False, False, None, False, None]
-    assert oracle.evaluate(q.BinaryExpr(col("a", 0), Operator.Or, col("b", 1)), batch).to_pylist() == \
+    assert engine.evaluate(q.BinaryExpr(col("a", 0), Operator.Or, col("b", 1)), batch).to_pylist() == \
         [True, True, True, True, False, None, True, None, None]
 
 
-def test_binary_expr_decimal_vector(oracle, golden):
+def test_binary_expr_decimal_vector(engine, golden):
     g = golden["binary_expr_decimal"]
     t = pa.decimal128(*g["input_type"])
     dec = lambda u: decimal.Decimal(u).scaleb(-g["input_type"][1])
@@ -139,12 +142,12 @@ def test_binary_expr_decimal_vector(oracle, golden):
                                        names=["l_extendedprice", "l_discount"])
     one = q.CastExpr(q.Literal(S.Int16(1)), t)
     e = q.BinaryExpr(col("l_extendedprice", 0), Operator.Mul, q.BinaryExpr(one, Operator.Sub, col("l_discount", 1)))
-    out = oracle.evaluate(e, batch)
+    out = engine.evaluate(e, batch)
     assert out.type == pa.decimal128(*g["expected_type"])
     assert out[0].as_py() == decimal.Decimal(g["expected_unscaled"]).scaleb(-g["expected_type"][1])
 
 
-def test_q1_type_rules(oracle):
+def test_q1_type_rules(engine):
     """1 - l_discount -> (23,2); price * that -> (38,4); * (1 + l_tax) -> (38,6) (q1.slt:24 scale digits)."""
     t = pa.decimal128(15, 2)
     D = decimal.Decimal
@@ -154,9 +157,9 @@ def test_q1_type_rules(oracle):
     e1 = q.BinaryExpr(one, Operator.Sub, col("d", 1))
     e2 = q.BinaryExpr(col("p", 0), Operator.Mul, e1)
     e3 = q.BinaryExpr(e2, Operator.Mul, q.BinaryExpr(one, Operator.Add, col("x", 2)))
-    assert oracle.evaluate(e1, batch).type == pa.decimal128(23, 2)
-    assert oracle.evaluate(e2, batch).type == pa.decimal128(38, 4)
-    r = oracle.evaluate(e3, batch)
+    assert engine.evaluate(e1, batch).type == pa.decimal128(23, 2)
+    assert engine.evaluate(e2, batch).type == pa.decimal128(38, 4)
+    r = engine.evaluate(e3, batch)
     assert r.type == pa.decimal128(38, 6)
     assert r[0].as_py() == D("102.600000")
 
@@ -186,77 +189,77 @@ def _sum(e):
     return q.SumAggregateExpr(e, I64)
 
 
-def test_slt_where(oracle, golden):
+def test_slt_where(engine, golden):
     g = golden["slt"]["where_t1"]
     t = lambda: _t(["v1", "v2"], g["rows"])
     v1, v2 = col("v1", 0), col("v2", 1)
-    assert rows_of(oracle.execute(_filter(t(), q.BinaryExpr(v1, Operator.Gt, v2)))) == [tuple(r) for r in g["v1_gt_v2"]]
-    assert rows_of(oracle.execute(_filter(t(), q.BinaryExpr(v2, Operator.Gt, lit_i64(2))))) == [tuple(r) for r in g["v2_gt_2"]]
+    assert rows_of(engine.execute(_filter(t(), q.BinaryExpr(v1, Operator.Gt, v2)))) == [tuple(r) for r in g["v1_gt_v2"]]
+    assert rows_of(engine.execute(_filter(t(), q.BinaryExpr(v2, Operator.Gt, lit_i64(2))))) == [tuple(r) for r in g["v2_gt_2"]]
     pred = q.BinaryExpr(q.BinaryExpr(v1, Operator.Eq, lit_i64(1)), Operator.Or, q.BinaryExpr(v2, Operator.Eq, lit_i64(2)))
-    assert rows_of(oracle.execute(_filter(t(), pred))) == [tuple(r) for r in g["v1_eq_1_or_v2_eq_2"]]
+    assert rows_of(engine.execute(_filter(t(), pred))) == [tuple(r) for r in g["v1_eq_1_or_v2_eq_2"]]
     plan = _agg(_filter(t(), q.BinaryExpr(v1, Operator.NotEq, lit_i64(1))), [], [_sum(v2)])
-    assert rows_of(oracle.execute(plan)) == [(g["sum_v2_where_v1_ne_1"],)]
+    assert rows_of(engine.execute(plan)) == [(g["sum_v2_where_v1_ne_1"],)]
     g2 = golden["slt"]["where_t2"]
     for op, key in ((Operator.Lt, "sum_v2_v1_lt_1"), (Operator.LtEq, "sum_v2_v1_le_1"), (Operator.GtEq, "sum_v2_v1_ge_1")):
         plan = _agg(_filter(_t(["v1", "v2"], g2["rows"]), q.BinaryExpr(v1, op, lit_i64(1))), [], [_sum(v2)])
-        assert rows_of(oracle.execute(plan)) == [(g2[key],)]
+        assert rows_of(engine.execute(plan)) == [(g2[key],)]
     g3 = golden["slt"]["where_t3"]
-    out = rows_of(oracle.execute(_filter(_t(["v1", "v2"], g3["rows"]), q.IsNull(v1))))
+    out = rows_of(engine.execute(_filter(_t(["v1", "v2"], g3["rows"]), q.IsNull(v1))))
     assert [r[1] for r in out] == g3["v2_where_v1_is_null"]
-    out = rows_of(oracle.execute(_filter(_t(["v1", "v2"], g3["rows"]), q.IsNotNull(v1))))
+    out = rows_of(engine.execute(_filter(_t(["v1", "v2"], g3["rows"]), q.IsNotNull(v1))))
     assert [r[1] for r in out] == g3["v2_where_v1_is_not_null"]
 
 
-def test_slt_filter_null(oracle, golden):
+def test_slt_filter_null(engine, golden):
     g = golden["slt"]["filter_null"]
     plan = _filter(_t(["v1", "v2"], g["rows"]), q.BinaryExpr(col("v1", 0), Operator.Gt, lit_i64(1)))
-    assert rows_of(oracle.execute(plan)) == [tuple(r) for r in g["v1_gt_1"]]
+    assert rows_of(engine.execute(plan)) == [tuple(r) for r in g["v1_gt_1"]]
 
 
-def test_slt_aggregation(oracle, golden):
+def test_slt_aggregation(engine, golden):
     g = golden["slt"]["aggregation"]
     types = [I64, I64, pa.float64()]
     t = lambda rows=g["rows"]: _t(["v1", "v2", "v3"], rows, types)
     v1, v2, v3 = col("v1", 0), col("v2", 1), col("v3", 2)
-    out = rows_of(oracle.execute(q.NoGroupingAggregate(None, t(), [_sum(v1), q.SumAggregateExpr(v3, pa.float64())])))
+    out = rows_of(engine.execute(q.NoGroupingAggregate(None, t(), [_sum(v1), q.SumAggregateExpr(v3, pa.float64())])))
     assert out[0][0] == g["sum_v1"] and abs(out[0][1] - g["sum_v3"]) < 1e-9
-    out = rows_of(oracle.execute(q.NoGroupingAggregate(None, t(), [q.MinAggregateExpr(v1, I64), q.MaxAggregateExpr(v1, I64), q.CountAggregateExpr(lit_i64(1))])))
+    out = rows_of(engine.execute(q.NoGroupingAggregate(None, t(), [q.MinAggregateExpr(v1, I64), q.MaxAggregateExpr(v1, I64), q.CountAggregateExpr(lit_i64(1))])))
     assert out == [(g["min_v1"], g["max_v1"], g["count"])]
     plan = q.NoGroupingAggregate(None, _filter(t(), q.BinaryExpr(v2, Operator.Gt, lit_i64(3))), [q.MaxAggregateExpr(v1, I64)])
-    assert rows_of(oracle.execute(plan)) == [(g["max_v1_where_v2_gt_3"],)]
-    out = sorted_rows(oracle.execute(q.HashAggregate(None, t(), [v2], [_sum(v1)])))
+    assert rows_of(engine.execute(plan)) == [(g["max_v1_where_v2_gt_3"],)]
+    out = sorted_rows(engine.execute(q.HashAggregate(None, t(), [v2], [_sum(v1)])))
     assert out == sorted((r[1], r[0]) for r in g["sum_v1_group_by_v2"])
     # empty table: zero batches
     empty = q.Scan(pa.schema([pa.field("v1", I64), pa.field("v2", I64)]), q.MemoryTable.try_new(pa.schema([pa.field("v1", I64), pa.field("v2", I64)]), []))
-    assert rows_of(oracle.execute(q.NoGroupingAggregate(None, empty, [q.CountAggregateExpr(lit_i64(1)), _sum(col("v1", 0))]))) == [(g["empty_count"], g["empty_sum"])]
-    assert oracle.execute(q.HashAggregate(None, empty, [col("v1", 0)], [q.CountAggregateExpr(lit_i64(1))])) == []
+    assert rows_of(engine.execute(q.NoGroupingAggregate(None, empty, [q.CountAggregateExpr(lit_i64(1)), _sum(col("v1", 0))]))) == [(g["empty_count"], g["empty_sum"])]
+    assert engine.execute(q.HashAggregate(None, empty, [col("v1", 0)], [q.CountAggregateExpr(lit_i64(1))])) == []
 
 
-def test_slt_group_by_and_having(oracle, golden):
+def test_slt_group_by_and_having(engine, golden):
     g = golden["slt"]["group_by"]
     t = _t(["v1", "v2"], g["rows"])
     key = q.BinaryExpr(col("v2", 1), Operator.Add, lit_i64(1))
-    out = sorted_rows(oracle.execute(q.HashAggregate(None, t, [key], [_sum(col("v1", 0))])))
+    out = sorted_rows(engine.execute(q.HashAggregate(None, t, [key], [_sum(col("v1", 0))])))
     assert out == sorted(tuple(r) for r in g["v2_plus_1__sum_v1"])
-    out = sorted_rows(oracle.execute(q.HashAggregate(None, t, [key], [_sum(col("v1", 0)), q.CountAggregateExpr(lit_i64(1))])))
+    out = sorted_rows(engine.execute(q.HashAggregate(None, t, [key], [_sum(col("v1", 0)), q.CountAggregateExpr(lit_i64(1))])))
     assert out == sorted((r[1], r[0], r[2]) for r in g["sum_v1__v2_plus_1__count"])
     h = golden["slt"]["having"]
     t = _t(["x", "y"], h["rows"])
     agg = q.HashAggregate(None, t, [col("y", 1)], [_sum(col("x", 0))])
-    out = rows_of(oracle.execute(_filter(agg, q.BinaryExpr(col("k0", 0), Operator.Eq, lit_i64(2)))))
+    out = rows_of(engine.execute(_filter(agg, q.BinaryExpr(col("k0", 0), Operator.Eq, lit_i64(2)))))
     assert out == [tuple(r) for r in h["y_sumx_having_y_eq_2"]]
     agg = q.HashAggregate(None, t, [col("y", 1)], [q.CountAggregateExpr(col("x", 0))])
-    out = rows_of(oracle.execute(_filter(agg, q.BinaryExpr(col("a0", 1), Operator.Gt, lit_i64(1)))))
+    out = rows_of(engine.execute(_filter(agg, q.BinaryExpr(col("a0", 1), Operator.Gt, lit_i64(1)))))
     assert [(r[1], r[0]) for r in out] == [tuple(r) for r in h["countx_y_having_gt_1"]]
     agg = q.HashAggregate(None, t, [col("x", 0)], [q.MaxAggregateExpr(col("y", 1), I64)])
-    out = rows_of(oracle.execute(_filter(agg, q.BinaryExpr(col("a0", 1), Operator.Eq, lit_i64(22)))))
+    out = rows_of(engine.execute(_filter(agg, q.BinaryExpr(col("a0", 1), Operator.Eq, lit_i64(22)))))
     assert [r[0] for r in out] == h["x_having_max_y_22"]
 
 
-def test_slt_count_and_bigint(oracle, golden):
+def test_slt_count_and_bigint(engine, golden):
     c = golden["slt"]["count"]
     t = lambda v=c["v"]: _t(["v"], [(x,) for x in v])
-    cnt = lambda inp: rows_of(oracle.execute(q.NoGroupingAggregate(None, inp, [q.CountAggregateExpr(lit_i64(1))])))[0][0]
+    cnt = lambda inp: rows_of(engine.execute(q.NoGroupingAggregate(None, inp, [q.CountAggregateExpr(lit_i64(1))])))[0][0]
     assert cnt(t()) == c["count_all"]
     gt5 = lambda inp: _filter(inp, q.BinaryExpr(col("v", 0), Operator.Gt, lit_i64(5)))
     assert cnt(gt5(t())) == c["count_v_gt_5"]
@@ -267,35 +270,35 @@ def test_slt_count_and_bigint(oracle, golden):
     v2 = col("v2", 0)
     f = lambda op, lit: _filter(t, q.BinaryExpr(v2, op, lit_i64(lit)))
     assert cnt(f(Operator.Gt, 2)) == b["count_v2_gt_2"]
-    assert rows_of(oracle.execute(q.NoGroupingAggregate(None, f(Operator.Gt, 2), [q.MinAggregateExpr(v2, I64)]))) == [(b["min_where_gt_2"],)]
-    assert rows_of(oracle.execute(q.NoGroupingAggregate(None, t, [q.MaxAggregateExpr(v2, I64)]))) == [(b["max"],)]
-    assert rows_of(oracle.execute(q.NoGroupingAggregate(None, f(Operator.Lt, 10), [_sum(v2)]))) == [(b["sum_where_lt_10"],)]
+    assert rows_of(engine.execute(q.NoGroupingAggregate(None, f(Operator.Gt, 2), [q.MinAggregateExpr(v2, I64)]))) == [(b["min_where_gt_2"],)]
+    assert rows_of(engine.execute(q.NoGroupingAggregate(None, t, [q.MaxAggregateExpr(v2, I64)]))) == [(b["max"],)]
+    assert rows_of(engine.execute(q.NoGroupingAggregate(None, f(Operator.Lt, 10), [_sum(v2)]))) == [(b["sum_where_lt_10"],)]
 
 
-def test_slt_join(oracle, golden):
+def test_slt_join(engine, golden):
     j = golden["slt"]["join_xy"]
     x = _t(["a", "b"], j["x"])
     y = _t(["c", "d"], j["y"])
     plan = q.HashJoinExec.try_new(x, y, JoinType.Inner, [(col("a", 0), col("c", 0))], None)
-    assert rows_of(oracle.execute(plan)) == [tuple(r) for r in j["inner_a_eq_c"]]
+    assert rows_of(engine.execute(plan)) == [tuple(r) for r in j["inner_a_eq_c"]]
     j = golden["slt"]["join_ab"]
     for jt, key in ((JoinType.Left, "left"), (JoinType.Right, "right"), (JoinType.Full, "full")):
         a = _t(["v1", "v2"], j["a"])
         b = _t(["v3", "v4"], j["b"])
         plan = q.HashJoinExec.try_new(a, b, jt, [(col("v1", 0), col("v3", 0))], None)
-        assert rows_of(oracle.execute(plan)) == [tuple(r) for r in j[key]], key
+        assert rows_of(engine.execute(plan)) == [tuple(r) for r in j[key]], key
     j = golden["slt"]["join_two_keys"]
     a = _t(["v1", "v2"], j["a"])
     b = _t(["v3", "v4", "v5"], j["b"])
     on = [(col("v1", 0), col("v3", 0)), (col("v2", 1), col("v4", 1))]
-    assert rows_of(oracle.execute(q.HashJoinExec.try_new(a, b, JoinType.Inner, on, None))) == [tuple(r) for r in j["inner_v1_v3_and_v2_v4"]]
+    assert rows_of(engine.execute(q.HashJoinExec.try_new(a, b, JoinType.Inner, on, None))) == [tuple(r) for r in j["inner_v1_v3_and_v2_v4"]]
     fschema = pa.schema([pa.field("v1", I64), pa.field("v5", I64)])
     jf = q.JoinFilter(q.BinaryExpr(col("v1", 0), Operator.Lt, col("v5", 1)), [(0, q.JoinSide.Left), (2, q.JoinSide.Right)], fschema)
-    assert rows_of(oracle.execute(q.HashJoinExec.try_new(a, b, JoinType.Inner, on, jf))) == [tuple(r) for r in j["plus_residual_v1_lt_v5"]]
+    assert rows_of(engine.execute(q.HashJoinExec.try_new(a, b, JoinType.Inner, on, jf))) == [tuple(r) for r in j["plus_residual_v1_lt_v5"]]
 
 
 # ---------------------------------------------------------------- Q1 SF0.01 algebraic checks (q1.slt:24-27)
-def test_q1_avg_is_truncating_division(oracle, golden):
+def test_q1_avg_is_truncating_division(engine, golden):
     """avg_qty == floor(sum_qty * 10^4 / count) * 10^-6 for all four groups pins DecimalAvgAccumulator (avg.rs:91-116)."""
     D = decimal.Decimal
     t = pa.decimal128(15, 2)
@@ -308,6 +311,6 @@ def test_q1_avg_is_truncating_division(oracle, golden):
                                             pa.array([sum_qty] + [D("0.00")] * (count - 1), type=t)], names=["k", "q"])
         scan = table_scan(batch.schema, [batch])
         plan = q.HashAggregate(None, scan, [col("k", 0)], [q.AvgAggregateExpr(col("q", 1), t, q.avg_return_type(t))])
-        out = oracle.execute(plan)[0]
+        out = engine.execute(plan)[0]
         assert out.column(1).type == pa.decimal128(19, 6)
         assert out.column(1)[0].as_py() == avg_qty, row[:2]
