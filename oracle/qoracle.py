@@ -8,7 +8,7 @@ join/{hash_join,mod}.rs, utils/{array,batch}.rs. pyarrow (Arrow C++) is used onl
 take / concat / array construction, never for decimal arithmetic (it differs from arrow-rs there).
 
 Pinning: the filter / aggregate / hash-join / sort / limit / nested-loop / cross-join restatements are pinned by the
-reference's own unit-test and .slt vectors (tests/golden/reference_vectors.json, tests/test_oracle_golden.py,
+reference's own unit-test and .slt vectors (tests/golden/reference_vectors.json, tests/test_reference_goldens.py,
 tests/test_sort_limit.py, tests/test_nlj_cross.py). CASE (arrow `zip`), LIKE (arrow `like`) and Projection have NO vectors
 in the reference (only TPC-H outputs whose inputs are unavailable offline): for those three the parity is UNPINNED by the
 reference's tests; the restatement is cross-checked against Arrow C++ instead (tests/test_projection_exprs.py).

@@ -2,7 +2,7 @@
 this repo, on the generic operators where their semantics coincide (SURVEY §8c "independent cross-check available here"):
 filter with NULL predicates, multi-key sort with NULLs first, integer GROUP BY aggregates, equi-joins of every type as row
 multisets. Decimal precision rules and AVG are NOT checked here — Arrow C++ differs from arrow-rs there and the
-reference's own vectors pin them (tests/test_oracle_golden.py)."""
+reference's own vectors pin them (tests/test_reference_goldens.py)."""
 import numpy as np
 import pyarrow as pa
 import pyarrow.compute as pc
