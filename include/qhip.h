@@ -334,6 +334,11 @@ int qhip_plan_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nu
 int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
                            const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
                            int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
+/* The build-side kernel of qhip_hash_join_execute's LDS-staged build (scan filter + key words -> region entries of the
+ * join table, hash_join.rs:148-175); predicate_root = -1 for no fused scan filter. */
+int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                             const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
+                             int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
 /* The image kernel of qhip_sort_execute for the key expressions, and the kernel of qhip_projection_execute for the
  * computed (non-Column) expressions among `roots`. */
 int qhip_plan_sort_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,

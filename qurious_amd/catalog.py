@@ -32,6 +32,8 @@ def catalog_sources():
     j2 = agg.input
     j1 = j2.left
     out.append(("q3 customer keys+filter", planning.keys_source(CUSTOMER_SCHEMA, [j1.on[0][0]])))
+    out.append(("q3 customer build entries", planning.scatter_source(CUSTOMER_SCHEMA, [j1.on[0][0]], j1.left.filter)))
+    out.append(("q3 join-1 output build entries", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
     out.append(("q3 orders probe", planning.probe_source(ORDERS_SCHEMA, [j1.on[0][1]], j1.right.filter)))
     out.append(("q3 join-1 output keys", planning.keys_source(j1.schema(), [j2.on[0][0]])))
     out.append(("q3 lineitem probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))

@@ -106,6 +106,10 @@ int ExprGen::lit_slot(const ENode& n) {
   if (bind.lit_lo.size() >= 24) fail(QHIP_UNSUPPORTED, "more than 24 literals in one kernel");
   uint64_t lo = n.lo; int64_t hi = n.hi;
   if (n.type.id == QHIP_FLOAT64 || n.type.id == QHIP_FLOAT32) { double f = n.f; memcpy(&lo, &f, 8); hi = 0; }
+  if (n.type.id == QHIP_UTF8) {   // the first 8 bytes as a kernel scalar: `col = 'BUILDING'` is one masked word compare (qh_streq_lit)
+    lo = 0; hi = 0;
+    memcpy(&lo, n.s.data(), std::min<size_t>(8, n.s.size()));
+  }
   bind.lit_lo.push_back(lo);
   bind.lit_hi.push_back(hi);
   if (n.type.id == QHIP_UTF8) bind.strlits += n.s;
@@ -208,7 +212,8 @@ void ExprGen::emit(int k, std::string& out) {
       const int s = lit_slot(n);
       const std::string S = std::to_string(s);
       if (n.type.id == QHIP_UTF8)
-        o << "    const u8* p" << K << " = a.strlit + a.stroff[" << S << "]; const int l" << K << " = a.stroff[" << s + 1 << "] - a.stroff[" << S << "];\n";
+        o << "    const u8* p" << K << " = a.strlit + a.stroff[" << S << "]; const int l" << K << " = a.stroff[" << s + 1 << "] - a.stroff[" << S << "];"
+          << " const u64 w" << K << " = a.lit_lo[" << S << "];\n";
       else if (n.type.id == QHIP_DECIMAL128)
         o << "    const i128 " << v << " = qh_mk128(a.lit_lo[" << S << "], a.lit_hi[" << S << "]);\n";
       else if (n.type.id == QHIP_FLOAT64)
@@ -230,8 +235,14 @@ void ExprGen::emit(int k, std::string& out) {
       if (is_cmp(n.op)) {
         std::string e;
         if (l.type.id == QHIP_UTF8) {
-          if (n.op == QHIP_OP_EQ) e = "qh_streq(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ")";
-          else if (n.op == QHIP_OP_NOTEQ) e = "!qh_streq(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ")";
+          // (in)equality with a literal: its first 8 bytes travel as a kernel scalar (lit_slot), so values of up to 8 bytes
+          // compare as one masked word instead of a byte loop with an early exit
+          const bool rlit = r.kind == QHIP_EXPR_LITERAL && !r.lit_null, llit = l.kind == QHIP_EXPR_LITERAL && !l.lit_null;
+          std::string eqx = "qh_streq(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ")";
+          if (rlit && !llit) eqx = "qh_streq_lit(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ", w" + std::to_string(n.right) + ")";
+          else if (llit && !rlit) eqx = "qh_streq_lit(" + ptr(n.right) + ", " + len(n.right) + ", " + ptr(n.left) + ", " + len(n.left) + ", w" + std::to_string(n.left) + ")";
+          if (n.op == QHIP_OP_EQ) e = eqx;
+          else if (n.op == QHIP_OP_NOTEQ) e = "!" + eqx;
           else e = "(qh_strcmp(" + ptr(n.left) + ", " + len(n.left) + ", " + ptr(n.right) + ", " + len(n.right) + ") " + c_cmp(n.op) + " 0)";
         } else if (dtype_is_float(l.type)) {
           // arrow-rs compares floats in IEEE total order
@@ -813,11 +824,20 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
 }
 
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root,
-               bool probe_kernel) {
+               int kernel) {
   out = KeysPlan();
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
+  const bool raw = kernel == KEYS_KERNEL_PROBE;
+  if (raw) {
+    // the probe kernel is software-pipelined over its tiles: a row's column loads are issued one stage (load(), branch-free,
+    // tile-relative addressing) before its filter / key words are computed from them (keys())
+    g.set_indexing(" + tb", "o", "(tb + (i64)o)");
+    g.set_raw_mode(true);
+    for (auto& kd : out.keys)
+      if (kd.type.id == QHIP_UTF8 && es.at(kd.root).kind == QHIP_EXPR_COLUMN) g.mark_utf8_key(kd.root, kd.words);
+  }
   std::string code, all;
   if (predicate_root >= 0) {
     // scan filter fused into the key evaluation: a row the predicate rejects gets an invalid key, i.e. it is never
@@ -830,15 +850,23 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   if (predicate_root >= 0) all = "(" + g.ok(predicate_root) + " && " + g.val(predicate_root) + ") && " + all;
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
-  s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
+  if (raw) {
+    s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
+    s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
+    s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const Raw& w, u64* k, u32& err) {\n" << code;
+  } else {
+    s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
+  }
   s << "    return " << all << ";\n  }\n};\n";
-  if (probe_kernel)
+  if (kernel == KEYS_KERNEL_PROBE)
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P>(a, L); }\n";
+  else if (kernel == KEYS_KERNEL_SCATTER)
+    s << "extern \"C\" __global__ __launch_bounds__(QH_SCATTER_BLOCK) void qk_join_scatter(KArgs a, ScatterLaunch L) { qh_join_scatter_body<P>(a, L); }\n";
   else
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
          "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
   out.source = s.str();
-  out.kernel_name = probe_kernel ? "qk_join_probe" : "qk_eval_keys";
+  out.kernel_name = kernel == KEYS_KERNEL_PROBE ? "qk_join_probe" : kernel == KEYS_KERNEL_SCATTER ? "qk_join_scatter" : "qk_eval_keys";
   out.bind = g.bind;
 }
 

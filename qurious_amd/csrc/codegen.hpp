@@ -109,9 +109,11 @@ struct KeysPlan {
   std::vector<KeyDesc> keys;
   KernelBindings bind; std::string source; std::string kernel_name;
 };
-// probe_kernel: emit qk_join_probe (fused filter + key + lookup + ordered pair emit, qh_join_probe_body) instead of qk_eval_keys
+// which kernel wraps the generated key policy: qk_eval_keys (key words -> arrays), qk_join_probe (fused filter + key + lookup,
+// qh_join_probe_body) or qk_join_scatter (build rows -> region entries of the LDS-staged join build, qh_join_scatter_body)
+enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2 };
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
-               bool probe_kernel = false);
+               int kernel = KEYS_KERNEL_EVAL);
 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };

@@ -58,7 +58,6 @@ __device__ __forceinline__ i128 qh_nt_load_i128(const i128* p) {
   return (i128)(((u128)(((u64)v.w << 32) | v.z) << 64) | (u128)(((u64)v.y << 32) | v.x));
 }
 __device__ __forceinline__ double qh_f64(u64 bits) { return __longlong_as_double((i64)bits); }
-
 // f64 <-> u64 whose unsigned order is the IEEE total order (arrow's min/max kernels compare floats that way)
 __device__ __forceinline__ u64 qh_f64_ord(double d) { u64 b = (u64)__double_as_longlong(d); return (b >> 63) ? ~b : (b | 0x8000000000000000ULL); }
 __device__ __forceinline__ double qh_ord_f64(u64 k) { u64 b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k; return __longlong_as_double((i64)b); }
@@ -127,6 +126,14 @@ __device__ __forceinline__ bool qh_streq(const u8* a, int la, const u8* b, int l
   if (la != lb) return false;
   for (int k = 0; k < la; ++k) if (a[k] != b[k]) return false;
   return true;
+}
+// value == literal, the literal's first 8 bytes given as a word (wave-uniform): literals of up to 8 bytes are ONE unaligned
+// 8-byte load masked to the literal's length (every Utf8 data buffer carries >= 8 bytes of slack) instead of a byte loop
+__device__ __forceinline__ bool qh_streq_lit(const u8* a, int la, const u8* lit, int llit, u64 lit_word) {
+  if (llit > 8) return qh_streq(a, la, lit, llit);
+  const u64 raw = *(const qh_u64_unaligned*)a;
+  const u64 mask = llit >= 8 ? ~0ULL : ((1ULL << (8 * llit)) - 1ULL);
+  return la == llit && ((raw ^ lit_word) & mask) == 0;
 }
 // Wrapping 128-bit product with wave-uniform fast paths: Decimal128 operands of real tables are small (TPC-H money
 // fits 32..40 bits), and a generic 128 x 128 multiply costs ~45 VALU instructions. If every active lane's operands
@@ -738,31 +745,42 @@ __device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32
 // ------------------------------------------------------------------ hash join: fused scan-filter + key + probe + ordered emit
 // read-only lookup in the distinct-key table of the build side (slot = [state][key words W]) after the build kernels
 // have completed (plain cached loads)
+// Slot addressing of the join table. Legacy layout: ONE open-addressing table of `mask + 1` slots (base = 0). Region layout
+// (LDS-staged build, k_join_region_build): the table is cut into regions of 2^slot_bits slots, a key lives in region
+// qh_region(h) and its probe sequence wraps inside that region, so a region is assembled in LDS by one workgroup and stored
+// as whole lines. slot index = base + (s & mask).
+__device__ __forceinline__ u32 qh_region(u64 h, u32 n_regions) { return (u32)(((h >> 32) * (u64)n_regions) >> 32); }
 template <int W>
-__device__ __forceinline__ u32 qh_join_find(const u64* table, u32 nslots, const u64* k, u64 h) {
-  u32 s = (u32)h & (nslots - 1);
-  for (u32 probes = 0; probes < nslots; ++probes) {
-    const u64* slot = table + (size_t)s * (1 + W);
+__device__ __forceinline__ u32 qh_join_find(const u64* table, u32 base, u32 mask, const u64* k, u32 s) {
+  for (u32 probes = 0; probes <= mask; ++probes) {
+    const u32 at = base + (s & mask);
+    const u64* slot = table + (size_t)at * (1 + W);
     if (slot[0] < QH_READY) return 0xFFFFFFFFu;
     bool eq = true;
 #pragma unroll
     for (int w = 0; w < W; ++w) eq &= slot[1 + w] == k[w];
-    if (eq) return s;
-    s = (s + 1) & (nslots - 1);
+    if (eq) return at;
+    ++s;
   }
   return 0xFFFFFFFFu;
 }
+// Hash of a join key: ONE 64-bit multiply and a fold per key word. The probe kernel hashes every probing row, and a 64-bit
+// multiply is four quarter-rate 32-bit ones — the two multiplies of qh_mix64 were about a third of that kernel's VALU time.
+// The high half of the product depends on every key bit (it picks the region / the legacy filter word); folding it into
+// the low half does the same for the slot and filter-bit fields taken from there (a bare product's low bits would only
+// depend on the key's low bits: TPC-H order keys use 8 of every 32 values).
+__device__ __forceinline__ u64 qh_fold_mul(u64 x) { x *= 0x9E3779B97F4A7C15ULL; return x ^ (x >> 32); }
 template <int W> __device__ __forceinline__ u64 qh_key_hash(const u64* k) {
-  u64 h = 0;
+  u64 h = qh_fold_mul(k[0]);
 #pragma unroll
-  for (int w = 0; w < W; ++w) h = qh_mix64(h ^ k[w]);
+  for (int w = 1; w < W; ++w) h = qh_fold_mul(h ^ k[w]) + (u64)w;
   return h;
 }
 
 struct ProbeLaunch {
   const u64* table;      // distinct build keys
-  const u32* bloom;      // hash filter: qh_bloom_bits(h) all set in word ((h >> 32) & bloom_mask) >> 5, else the key is not
-                         // in the table (the filter stays in L2)
+  const u64* bloom;      // hash filter of 64-bit words: qh_filter_mask() of the key all set in its word, else the key is not in
+                         // the table (the filter stays in L2)
   const u32* count;      // build rows per slot (unused when start == nullptr)
   const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
@@ -773,92 +791,275 @@ struct ProbeLaunch {
   u32* tile_total;       // out, per tile: number of (build, probe) pairs
   u32* visited;          // build-row bitmap to mark here (LeftSemi / LeftAnti without a residual filter) or nullptr
   u32* status;
-  u32 nslots, bloom_mask;
+  u32 nslots, bloom_mask;  // legacy layout: slots of the one table (power of two), 64-bit words of the filter - 1
+  u32 n_regions;           // region layout (0 = legacy): regions of 2^slot_bits slots, each with a filter slice of
+  u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; dbg: timing experiments only (QHIP_PROBE_DBG, results are wrong)
 };
 
-// The build's hash filter is a blocked Bloom filter with TWO bits per key inside ONE 32-bit word (word and first bit from
-// hash bits 32.., second bit from the top five hash bits): the probe still pays one L2 access per row, but with ~11 bits
-// per key the false positives — each of which is a random 128-byte HBM line of the 64 MB table fetched for nothing — drop
-// from ~9 % to ~3 % of the probing rows (Q3 J2: 32 M probing rows, 0.3 M true matches).
-__device__ __forceinline__ u32 qh_bloom_bits(u64 h) { return (1u << ((u32)(h >> 32) & 31u)) | (1u << (u32)(h >> 59)); }
+// The build's hash filter is a blocked Bloom filter: FOUR bits per key inside ONE 64-bit word (two in each half), sized at
+// 8 filter bits per table slot = 16 or more per key. A probe row pays one 8-byte L2 access; what the filter lets through
+// by mistake (~0.3 % of the probing rows) costs a random 128-byte line of the table and — since such a key usually finds
+// its home slot taken by another key — a dependent walk along the probe sequence, which stalls the software pipeline of
+// qh_join_probe_body. (The first filter had two bits per key in a 32-bit word at ~10 bits per key: 3-5 % false positives,
+// i.e. a walk in nearly every 256-row tile.)
+__device__ __forceinline__ u64 qh_filter_mask(u32 x) {
+  const u32 lo = (1u << (x & 31u)) | (1u << ((x >> 5) & 31u)), hi = (1u << ((x >> 10) & 31u)) | (1u << ((x >> 15) & 31u));
+  return ((u64)hi << 32) | lo;
+}
+// legacy layout (one table): word from the high hash half, bits from the low one
+__device__ __forceinline__ u32 qh_filter_word(u64 h, u32 word_mask) { return (u32)(h >> 32) & word_mask; }
+// region layout: the region comes from the HIGH 32 hash bits (qh_region), everything inside a region from disjoint fields
+// above each other from bit 0: slot = h[0, sb), filter word of the region's slice = h[sb, sb + wb), the mask = the next 20
+__device__ __forceinline__ u32 qh_rfilter_word(u64 h, u32 sb, u32 wb) { return ((u32)h >> sb) & ((1u << wb) - 1u); }
+__device__ __forceinline__ u64 qh_rfilter_mask(u64 h, u32 sb, u32 wb) { return qh_filter_mask((u32)(h >> (sb + wb))); }
 
 #define QH_PROBE_R 4   // probe rows per thread and tile
 // Probe pass 1 (hash_join.rs:218-275 for every probe batch at once): evaluate the fused scan filter and the key words
 // straight from the probe table's columns, look the key up, keep (slot, probe row) of the matching rows only — compacted
 // per 256-row tile with ballot/popcount ranks — and the pair count per tile. Pass 2 (k_join_emit) turns the entries into
 // ordered (build row, probe row) pairs once the tile totals have been scanned.
-// Phases, each a branch-free pass over the thread's R rows so that their loads are in flight together (a lookup is a
-// chain of dependent random reads; R independent chains per thread and many waves per CU hide its latency):
-// key words -> filter bit -> home slot of the table -> (rarely) the rest of the probe sequence -> row count.
+//
+// A lookup is a chain of dependent reads — columns -> filter word -> home slot -> (rarely) the rest of the probe sequence —
+// and a wavefront that walks the chain tile by tile spends its life waiting (measured: 56 % of the wave cycles in
+// s_waitcnt, HBM and L2 both far from saturated). So the chain is SOFTWARE-PIPELINED over the wavefront's tiles: every
+// trip of the loop finishes tile t (stage 4: compare the slot, write the entries), tests the filter words of tile t + 1 and
+// issues its slot loads (stage 3), hashes the keys of tile t + 2 and issues its filter loads (stage 2), and issues the
+// column loads of tile t + 3 (stage 1). Loads return in order, so each stage waits only for what was issued a whole trip
+// earlier, and three tiles' worth of loads are in flight per wavefront all the time. Every stage is a branch-free pass
+// over the thread's R rows. Policy P: struct Raw, load(a, tile base, lane offset, raw) issues a row's column loads,
+// keys(a, raw, k, err) computes filter + key words from them.
+// The tiles in flight keep their state in three register sets that rotate through the stages (the loop is unrolled three
+// trips deep): a tile's key words stay where stage 2 put them until stage 4 has used them, and a tile's column loads land in
+// the set whose tile has just finished — no register copies between the stages. (Written as one loop with loop-carried
+// stage variables the compiler places the copies of the freshly loaded registers at the loop head, behind an
+// s_waitcnt vmcnt(0): the pipeline drains every trip.)
+template <class P>
+struct QhProbeTile {
+  typename P::Raw raw[QH_PROBE_R];                       // stage 1 -> 2
+  u64 k[QH_PROBE_R][P::W];                               // stage 2 -> 4
+  u64 fw[QH_PROBE_R], fm[QH_PROBE_R];                    // stage 2 -> 3: filter word, the key's mask
+  u32 at[QH_PROBE_R];                                    // stage 2 -> 4: the key's home slot (base + slot inside the region)
+  u64 st[QH_PROBE_R], kw[QH_PROBE_R][P::W];              // stage 3 -> 4
+  bool ok[QH_PROBE_R];
+  i64 tile;                                              // wave-uniform
+  bool live;                                             // wave-uniform: a real tile of this wavefront (not a drain trip's)
+};
+struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, stride, mine; };
+
+// stage 1: issue the column loads of the wavefront's j-th tile (j beyond its last tile: tile 0 once more, not live)
+template <class P>
+__device__ __forceinline__ void qh_probe_stage1(const KArgs& a, QhProbeTile<P>& x, const QhProbeCtx& c, i64 j) {
+  constexpr int R = QH_PROBE_R, TILE = 64 * R;
+  x.live = j < c.mine;
+  x.tile = x.live ? c.first + j * c.stride : 0;   // (a drain trip reads tile 0: the same L2-resident lines for every wavefront)
+  const i64 tb = x.tile * TILE;
+  // row r * 64 + lane: the lanes of one load / lookup instruction hold 64 CONSECUTIVE rows. Fact tables are usually stored
+  // in foreign-key order (lineitem by order key), so the filter and table lookups of an instruction fall into few cache
+  // lines. (Measured alternative: a lane owning 4 consecutive rows reads each column with 16-byte loads, but spreads an
+  // instruction's lookups over 4x as many keys — Q3's lineitem probe 217 -> 312 us; the kernel is VALU-bound, not
+  // load-width-bound.)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32 o = (u32)r * 64 + (u32)c.lane;
+    P::load(a, tb, tb + (i64)o < a.nrows ? o : (u32)(a.nrows - 1 - tb), x.raw[r]);
+  }
+}
+// stage 2: filter + key words from the columns, hash, issue the filter-word loads
+template <class P>
+__device__ __forceinline__ void qh_probe_stage2(const KArgs& a, const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c, u32& err) {
+  constexpr int R = QH_PROBE_R, TILE = 64 * R, W = P::W;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool inb = x.tile * TILE + r * 64 + c.lane < a.nrows;
+    u32 e = 0;
+    x.ok[r] = P::keys(a, x.raw[r], x.k[r], e) && inb;
+    err |= (inb && x.live) ? e : 0u;
+    const u64 h = qh_key_hash<W>(x.k[r]);
+    const u32 reg = c.regions ? qh_region(h, L.n_regions) : 0u;
+    x.at[r] = (c.regions ? reg << L.slot_bits : 0u) + ((u32)h & c.smask);
+    x.fm[r] = c.regions ? qh_rfilter_mask(h, L.slot_bits, L.bword_bits) : qh_filter_mask((u32)h);
+    const u32 word = c.regions ? (reg << L.bword_bits) + qh_rfilter_word(h, L.slot_bits, L.bword_bits) : qh_filter_word(h, L.bloom_mask);
+    x.fw[r] = L.bloom[(x.ok[r] && !(L.dbg & 4u)) ? word : 0u];
+  }
+}
+// stage 3: filter test, issue the home-slot loads of the rows that pass
+template <class P>
+__device__ __forceinline__ void qh_probe_stage3(const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c) {
+  constexpr int R = QH_PROBE_R, W = P::W;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    x.ok[r] = x.ok[r] && (x.fw[r] & x.fm[r]) == x.fm[r] && !(L.dbg & 2u);
+    const u64* slot = L.table + (size_t)(x.ok[r] ? x.at[r] : 0u) * (1 + W);
+    x.st[r] = slot[0];
+#pragma unroll
+    for (int w = 0; w < W; ++w) x.kw[r][w] = slot[1 + w];
+  }
+}
+// stage 4: compare the home slot, walk on after a collision (rare: the filter), write the tile's entries and counts
+template <class P>
+__device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c) {
+  constexpr int R = QH_PROBE_R, TILE = 64 * R, W = P::W;
+  const int lane = c.lane;
+  u32 sid[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    sid[r] = 0xFFFFFFFFu;
+    if (x.ok[r] && x.st[r] >= QH_READY) {
+      bool eq = true;
+#pragma unroll
+      for (int w = 0; w < W; ++w) eq &= x.kw[r][w] == x.k[r][w];
+      const u32 home = x.at[r] & c.smask, base = x.at[r] & ~c.smask;
+      sid[r] = eq ? x.at[r] : (L.dbg & 1u) ? 0xFFFFFFFFu : qh_join_find<W>(L.table, base, c.smask, x.k[r], home + 1);   // collision: walk on from the next slot
+      // unique build keys: the slot's state word carries its one build row, which is all pass 2 needs
+      if (!L.start && sid[r] != 0xFFFFFFFFu) sid[r] = (u32)((eq ? x.st[r] : L.table[(size_t)sid[r] * (1 + W)]) - 2);
+    }
+  }
+  if (!x.live) return;   // wave-uniform: a drain trip writes nothing
+  u32 total = 0, nent = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool found = sid[r] != 0xFFFFFFFFu;
+    u32 cnt = 1u;
+    if (L.start) cnt = L.count[found ? sid[r] : 0u];   // (wave-uniform branch: duplicated build keys only)
+    total += found ? cnt : 0u;
+    const u64 m = qh_ballot(found);
+    if (found) {
+      const size_t pos = (size_t)x.tile * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+      L.ent_slot[pos] = sid[r];
+      L.ent_row[pos] = (u32)(x.tile * TILE + r * 64 + lane);
+    }
+    nent += (u32)__builtin_popcountll(m);
+  }
+  if (L.visited) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (sid[r] != 0xFFFFFFFFu) {
+        const u32 s0 = L.start ? L.start[sid[r]] : 0u, cnt = L.start ? L.count[sid[r]] : 1u;
+        for (u32 q = 0; q < cnt; ++q) { const u32 b = L.start ? L.rows[s0 + q] : sid[r]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
+      }
+  }
+  total = (u32)qh_wave_sum_u64(total);
+  if (lane == 0) { L.tile_total[x.tile] = total; L.tile_nent[x.tile] = nent; }
+}
+
 template <class P>
 __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLaunch& L) {
   constexpr int R = QH_PROBE_R, TILE = 64 * R, NW = QH_BLOCK / 64;
-  const int lane = qh_lane();
   const i64 ntiles = (a.nrows + TILE - 1) / TILE;
+  QhProbeCtx c;
+  // where a key lives: legacy = one table (base 0, mask nslots - 1); region layout = its region's slot range
+  c.regions = L.n_regions != 0;
+  c.smask = c.regions ? (1u << L.slot_bits) - 1u : L.nslots - 1u;
+  c.lane = qh_lane();
+  // the wavefront's tiles: first, first + stride, ... (wave-uniform numbers, kept in SGPRs: the pipeline's control flow is scalar)
+  c.stride = (i64)gridDim.x * NW;
+  c.first = (i64)blockIdx.x * NW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (c.first >= ntiles) return;
+  c.mine = (ntiles - c.first + c.stride - 1) / c.stride;
   u32 err = 0;
-  for (i64 tile = (i64)blockIdx.x * NW + (threadIdx.x >> 6); tile < ntiles; tile += (i64)gridDim.x * NW) {
-    u32 sid[R];
-    u64 k[R][P::W], h[R];
-    bool ok[R];
+  QhProbeTile<P> A, B, C;
+  // fill the pipeline. EVERY stage call below and in the loop is unconditional and works on a real tile (the trips behind
+  // the wavefront's last tile run on tile 0 without writing): the number of memory operations between a load and its use is
+  // then the same on every path, which is what lets the compiler wait with s_waitcnt vmcnt(N > 0) for exactly the loads
+  // issued a trip earlier. (With `if (tile valid)` around the stages it must assume the shortest path and drains.)
+  qh_probe_stage1<P>(a, A, c, 0);
+  qh_probe_stage2<P>(a, L, A, c, err);
+  qh_probe_stage1<P>(a, B, c, 1);
+  qh_probe_stage3<P>(L, A, c);
+  qh_probe_stage2<P>(a, L, B, c, err);
+  qh_probe_stage1<P>(a, C, c, 2);
+  // one trip: finish X4's tile, filter-test X3's, hash X2's, then give X4 (free now) the wavefront's next tile
+#define QH_PROBE_TRIP(X4, X3, X2, J)          \
+  qh_probe_stage4<P>(L, X4, c);               \
+  qh_probe_stage3<P>(L, X3, c);               \
+  qh_probe_stage2<P>(a, L, X2, c, err);       \
+  qh_probe_stage1<P>(a, X4, c, (J));
+  for (i64 j = 3; j < c.mine + 3; j += 3) {   // wave-uniform; stage 4 has run for tiles 0 .. j - 1 after the trip group
+    QH_PROBE_TRIP(A, B, C, j)
+    QH_PROBE_TRIP(B, C, A, j + 1)
+    QH_PROBE_TRIP(C, A, B, j + 2)
+  }
+#undef QH_PROBE_TRIP
+  qh_report(L.status, err);
+}
+
+// ------------------------------------------------------------------ hash join build, step 1: keys -> entries grouped by region
+// LDS-staged build of the join table (build_hash_table, hash_join.rs:148-175). The table is cut into regions of
+// 2^slot_bits slots (a key's region comes from the high half of its hash). This kernel evaluates the fused scan filter
+// and the key words of the build rows straight from the build table's columns. A workgroup owns a contiguous row range
+// and leaves its valid rows as ENTRIES [row + 2 | key words] — the shape of a slot — in `entries` at the range's own
+// position, grouped by region (a counting sort inside the workgroup: count per region in LDS, exclusive scan, re-read the
+// rows L2-warm and place them), plus the first entry of every region in `first[workgroup][region]` (n_regions + 1 values).
+// k_join_region_build then collects a region's entries from all workgroups, assembles the region's open-addressing
+// image in LDS and stores it as whole lines. No global atomic anywhere, no memset of the table. (A first version reserved
+// room in the regions with one global atomic per (workgroup, region): 512 workgroups x 16 counters per 64-byte line
+// serialise at the memory side — 40 us for any build size.)
+struct ScatterLaunch {
+  u64* entries;      // nrows entries of (1 + W) words; workgroup g writes [g * rows_per_wg, ...) from the front
+  u32* first;        // [workgroups][n_regions + 1]
+  u32* status;
+  u32 n_regions;
+  u32 rows_per_wg;   // static row range of a workgroup
+};
+
+#define QH_SCATTER_BLOCK 1024   // 16 wavefronts per workgroup: a workgroup's row range is two or three rows per thread, so each
+                                // of its phases is ONE round of loads (the phases are latency chains, not bandwidth)
+template <class P>
+__device__ __forceinline__ void qh_join_scatter_body(const KArgs& a, const ScatterLaunch& L) {
+  constexpr int R = 4, W = P::W, TB = QH_SCATTER_BLOCK;
+  u32* cnt = (u32*)qh_dyn_lds;         // [n_regions + 1] rows of this workgroup per region, then the next free place of the region's run
+  __shared__ u32 wsum[TB / 64];
+  const u32 tid = threadIdx.x, nr = L.n_regions;
+  for (u32 r = tid; r <= nr; r += TB) cnt[r] = 0;
+  __syncthreads();
+  const i64 first = (i64)blockIdx.x * L.rows_per_wg;
+  const i64 last = first + L.rows_per_wg < a.nrows ? first + L.rows_per_wg : a.nrows;
+  u32 err = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (i64 tb = first; tb < last; tb += (i64)TB * R) {
+      u64 k[R][W];
+      bool ok[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const i64 i = tile * TILE + r * 64 + lane;
-      const bool inb = i < a.nrows;
-      u32 e = 0;
-      ok[r] = P::keys(a, inb ? i : a.nrows - 1, k[r], e) && inb;
-      err |= inb ? e : 0u;
-      h[r] = qh_key_hash<P::W>(k[r]);
-    }
-    u32 fw[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) fw[r] = L.bloom[ok[r] ? (((u32)(h[r] >> 32) & L.bloom_mask) >> 5) : 0u];
-    u64 st[R], kw[R][P::W];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u32 bits = qh_bloom_bits(h[r]);
-      ok[r] = ok[r] && (fw[r] & bits) == bits;
-      const u64* slot = L.table + (size_t)(ok[r] ? ((u32)h[r] & (L.nslots - 1)) : 0u) * (1 + P::W);
-      st[r] = slot[0];
-#pragma unroll
-      for (int w = 0; w < P::W; ++w) kw[r][w] = slot[1 + w];
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      sid[r] = 0xFFFFFFFFu;
-      if (ok[r] && st[r] >= QH_READY) {
-        bool eq = true;
-#pragma unroll
-        for (int w = 0; w < P::W; ++w) eq &= kw[r][w] == k[r][w];
-        const u32 home = (u32)h[r] & (L.nslots - 1);
-        sid[r] = eq ? home : qh_join_find<P::W>(L.table, L.nslots, k[r], (u64)home + 1);   // collision: walk on from the next slot
-        // unique build keys: the slot's state word carries its one build row, which is all pass 2 needs
-        if (!L.start && sid[r] != 0xFFFFFFFFu) sid[r] = (u32)((eq ? st[r] : L.table[(size_t)sid[r] * (1 + P::W)]) - 2);
+      for (int r = 0; r < R; ++r) {
+        const i64 i = tb + (i64)r * TB + tid;
+        const bool inb = i < last;
+        u32 e = 0;
+        ok[r] = P::keys(a, inb ? i : last - 1, k[r], e) && inb;
+        if (pass == 0) err |= inb ? e : 0u;
       }
-    }
-    u32 total = 0, nent = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool found = sid[r] != 0xFFFFFFFFu;
-      const u32 c = L.start ? L.count[found ? sid[r] : 0u] : 1u;
-      total += found ? c : 0u;
-      const u64 m = qh_ballot(found);
-      if (found) {
-        const size_t pos = (size_t)tile * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
-        L.ent_slot[pos] = sid[r];
-        L.ent_row[pos] = (u32)(tile * TILE + r * 64 + lane);
-      }
-      nent += (u32)__builtin_popcountll(m);
-    }
-    if (L.visited) {
+      for (int r = 0; r < R; ++r) {
+        if (ok[r]) {
+          const u32 reg = qh_region(qh_key_hash<W>(k[r]), nr);
+          const u32 pos = atomicAdd(&cnt[reg], 1u);
+          if (pass == 1) {
+            u64* e = L.entries + ((size_t)first + pos) * (1 + W);
+            e[0] = (u64)(tb + (i64)r * TB + tid) + 2;
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (sid[r] != 0xFFFFFFFFu) {
-          const u32 s0 = L.start ? L.start[sid[r]] : 0u, c = L.start ? L.count[sid[r]] : 1u;
-          for (u32 q = 0; q < c; ++q) { const u32 b = L.start ? L.rows[s0 + q] : sid[r]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
+            for (int w = 0; w < W; ++w) e[1 + w] = k[r][w];
+          }
         }
+      }
     }
-    total = (u32)qh_wave_sum_u64(total);
-    if (lane == 0) { L.tile_total[tile] = total; L.tile_nent[tile] = nent; }
+    __syncthreads();
+    if (pass == 0) {
+      // exclusive scan of the per-region counts (thread t owns ch consecutive regions), published to first[workgroup][]
+      const u32 ch = (nr + TB) / TB;   // ceil((nr + 1) / TB)
+      const u32 r0 = tid * ch;
+      u32 sum = 0;
+      for (u32 j = 0; j < ch; ++j) sum += r0 + j <= nr ? cnt[r0 + j] : 0u;
+      u32 incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)incl, d, 64); if ((int)(tid & 63) >= d) incl += t; }
+      if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      u32 run = incl - sum;
+      for (u32 w = 0; w < (tid >> 6); ++w) run += wsum[w];
+      u32* out = L.first + (size_t)blockIdx.x * (nr + 1);
+      for (u32 j = 0; j < ch; ++j)
+        if (r0 + j <= nr) { const u32 c = cnt[r0 + j]; cnt[r0 + j] = run; out[r0 + j] = run; run += c; }
+      __syncthreads();
+    }
   }
   qh_report(L.status, err);
 }

@@ -34,8 +34,7 @@ uint32_t pow2_ceil32(uint64_t x) {
 }
 int log2u(uint32_t x) { int b = 0; while ((1u << b) < x) ++b; return b; }
 
-uint64_t fnv1a64(const std::string& str) {
-  uint64_t h = 1469598103934665603ULL;
+uint64_t fnv1a64(const std::string& str, uint64_t h = 1469598103934665603ULL) {
   for (unsigned char c : str) { h ^= c; h *= 1099511628211ULL; }
   return h;
 }
@@ -88,8 +87,26 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
   QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
-  eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
-  plan_keys(res, rcols, on_r, n_on, rkp, rpred, true);   // the probe side's keys are evaluated inside the probe kernel
+  // The build's status (key-evaluation errors, duplicate keys?) is needed before the probe only to choose between the
+  // unique-key and the CSR layout. Unique keys are the rule (every FK -> PK join), so unless this build side is known to
+  // have had duplicates the probe is launched on that assumption and the build status is read together with the probe's:
+  // one host round trip less per join. A wrong guess is memory-safe (a slot's state word always names a valid build row),
+  // is detected below, remembered, and the join runs again the careful way.
+  // (the hint identifies the build side by its key / filter expressions and row count)
+  uint64_t dup_hint = B * 0x9E3779B97F4A7C15ULL + (uint64_t)(lpred + 1);
+  for (int k = 0; k < nlex; ++k) {
+    qhip_expr e = lex[k];
+    const char* str = e.lit_str;
+    e.lit_str = nullptr;
+    dup_hint = fnv1a64(std::string((const char*)&e, sizeof e), dup_hint);
+    if (str && e.lit_len > 0 && e.kind == QHIP_EXPR_LITERAL) dup_hint = fnv1a64(std::string(str, (size_t)e.lit_len), dup_hint);
+  }
+  for (int k = 0; k < n_on; ++k) dup_hint = dup_hint * 1099511628211ULL + (uint64_t)on_l[k];
+  const bool speculate = env_int("QHIP_JOIN_FORCE_CSR", 0) == 0 && env_int("QHIP_JOIN_NO_SPECULATION", 0) == 0 && !ctx->join_dup_builds.count(dup_hint);
+  const int region_mode = env_int("QHIP_JOIN_REGION", 1);   // LDS-staged region build: 0 never, 1 when it pays, 2 always (tests)
+  const bool want_regions = speculate && B > 0 && (region_mode == 2 || (region_mode == 1 && B >= 2048));
+  plan_keys(les, lcols, on_l, n_on, lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL);
+  plan_keys(res, rcols, on_r, n_on, rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
   for (int k = 0; k < n_on; ++k)
     if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
       fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
@@ -97,31 +114,69 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const int W = lkp.W;
   if (rkp.W != W) fail(QHIP_HIP_ERROR, "join key layouts of the two sides differ (internal error)");
 
-  // ---- build: distinct-key table (+ a one-bit-per-hash filter that stays in L2) and the build rows of every key
-  const uint32_t nslots = std::max<uint32_t>(16, pow2_ceil32(B * 2));
-  const uint32_t bloom_bits = std::max<uint32_t>(1024, nslots < (1u << 29) ? nslots * 4 : nslots);
-  // one zero-filled arena: [table | count | bloom]
-  const size_t table_bytes = (size_t)nslots * (1 + W) * 8, count_bytes = ((size_t)nslots + 2) * 4, bloom_bytes = (size_t)bloom_bits / 8;
+  // ---- build. Two layouts of the distinct-key table (slot = [state | key words], state - 2 = the build row):
+  //  * region layout, LDS-staged (the default while unique build keys are assumed): the table is cut into regions of 2^sb
+  //    slots at load <= 1/2; qk_join_scatter (JIT: fused scan filter + key words) drops every build row as an entry into its
+  //    region, k_join_region_build assembles each region and its slice of the hash filter in LDS and stores them as whole
+  //    lines. No memset, no per-row HBM atomic. Duplicate keys / an overfull region are detected there -> legacy layout.
+  //  * legacy layout: ONE open-addressing table filled with agent-scope atomics (k_join_build_insert), per-slot counts and,
+  //    for duplicated keys, the CSR of the build rows of every key.
+  uint32_t n_regions = 0, slot_bits = 0, bword_bits = 0;
+  if (want_regions) {
+    // region = the biggest power of two of slots within 32 KB of LDS (W = 1: 2048 slots); 64 KB when that keeps the
+    // number of regions (two LDS counters each in qk_join_scatter) within 8192
+    slot_bits = 4;
+    while (((size_t)16 * (1 + W) << slot_bits) <= 32 * 1024) ++slot_bits;
+    auto regions_for = [&](uint32_t sb) { return (uint32_t)((B + (1ull << (sb - 1)) - 1) >> (sb - 1)); };   // load <= 1/2
+    if (env_int("QHIP_JOIN_REGION_SLOT_BITS", 0) >= 4) slot_bits = (uint32_t)env_int("QHIP_JOIN_REGION_SLOT_BITS", 0);
+    else if (regions_for(slot_bits) > 8192 && ((size_t)16 * (1 + W) << slot_bits) <= 60 * 1024) ++slot_bits;
+    n_regions = regions_for(slot_bits);
+    bword_bits = slot_bits - 3;   // 64-bit filter words per region: 8 filter bits per slot = >= 16 per key
+    if (n_regions > 8192 || (((size_t)8 * (1 + W)) << slot_bits) + ((size_t)8 << bword_bits) > 64 * 1024) n_regions = 0;
+  }
+  const bool region_build = n_regions > 0;
+  const uint32_t nslots = region_build ? n_regions << slot_bits : std::max<uint32_t>(16, pow2_ceil32(B * 2));
+  // hash filter: 64-bit words, 8 bits per slot (region layout: 2^bword_bits words per region)
+  const uint32_t filter_words = region_build ? n_regions << bword_bits : std::max<uint32_t>(16, nslots / 8);
+  // one arena: [table | count | filter] (legacy: zero-filled; region layout: every byte of table and filter is stored by
+  // k_join_region_build, the counts are not used)
+  const size_t table_bytes = (size_t)nslots * (1 + W) * 8, count_bytes = region_build ? 0 : (((size_t)nslots + 2) * 4 + 7) / 8 * 8, bloom_bytes = (size_t)filter_words * 8;
   DevBuf arena(table_bytes + count_bytes + bloom_bytes);
-  QHIP_HIP_CHECK(hipMemsetAsync(arena.ptr, 0, arena.bytes, s));
   uint64_t* table = arena.as<uint64_t>();
   uint32_t* count = (uint32_t*)(arena.as<uint8_t>() + table_bytes);
-  uint32_t* bloom = (uint32_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
-  DevBuf start, row_slot((B + 1) * 4), sorted_rows;
-  launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
-                           bloom_bits - 1, ctx->status.as<uint32_t>(), s);
+  uint64_t* bloom = (uint64_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
+  DevBuf start, row_slot, sorted_rows;
+  if (region_build) {
+    std::shared_ptr<Module> mod = get_module(ctx, lkp.source, lkp.kernel_name);
+    HKArgs ka;
+    DevBuf strlit;
+    fill_kargs(ctx, L, lkp.bind, ka, strlit);
+    // a step-1 workgroup (1024 threads) owns a row range of two or three rows per thread when the rows allow (2
+    // workgroups per CU); its entries stay inside the range, so nothing is shared between workgroups
+    uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>((B + 2047) / 2048, (uint64_t)ctx->num_cus * 2));
+    const uint64_t rows_per_wg = (((B + wgs - 1) / wgs) + 63) / 64 * 64;
+    wgs = (B + rows_per_wg - 1) / rows_per_wg;
+    DevBuf entries(B * (1 + (size_t)W) * 8), first(wgs * ((size_t)n_regions + 1) * 4);
+    HScatterLaunch sl;
+    sl.entries = entries.as<uint64_t>(); sl.first = first.as<uint32_t>(); sl.status = ctx->status.as<uint32_t>();
+    sl.n_regions = n_regions; sl.rows_per_wg = (uint32_t)rows_per_wg;
+    void* args[] = {&ka, &sl};
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, (unsigned)wgs, 1, 1, 1024, 1, 1, (n_regions + 1) * 4, s, args, nullptr));
+    launch_join_region_build(W, entries.as<uint64_t>(), first.as<uint32_t>(), (uint32_t)wgs, (uint32_t)rows_per_wg, table, bloom, n_regions,
+                             slot_bits, bword_bits, ctx->status.as<uint32_t>(), s);
+    // (entries / first go back to the pool here; whoever gets them next runs on the same stream, i.e. afterwards)
+  } else {
+    QHIP_HIP_CHECK(hipMemsetAsync(arena.ptr, 0, arena.bytes, s));
+    row_slot.alloc((B + 1) * 4);
+    eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
+    launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
+                             filter_words - 1, ctx->status.as<uint32_t>(), s);
+  }
   uint32_t max_count = 0;
   // read-backs land in the context's page-locked scratch: a D2H copy into pageable memory is a stream round trip of its
   // own, so two of them plus the synchronize cost three waits where one does
   uint32_t* const st = (uint32_t*)ctx->pinned;          // [status words | pair total | build status words]
   uint32_t* const st_build = st + 16;
-  // The build's status (key-evaluation errors, duplicate keys?) is needed before the probe only to choose between the
-  // unique-key and the CSR layout. Unique keys are the rule (every FK -> PK join), so unless this build side is known to
-  // have had duplicates the probe is launched on that assumption and the build status is read together with the probe's:
-  // one host round trip less per join. A wrong guess is memory-safe (a slot's state word always names a valid build row),
-  // is detected below, remembered, and the join runs again the careful way.
-  const uint64_t dup_hint = fnv1a64(lkp.source) ^ (B * 0x9E3779B97F4A7C15ULL);
-  const bool speculate = env_int("QHIP_JOIN_FORCE_CSR", 0) == 0 && env_int("QHIP_JOIN_NO_SPECULATION", 0) == 0 && !ctx->join_dup_builds.count(dup_hint);
   auto check_build_status = [&] {
     check_status_words(st_build);
     if (st_build[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
@@ -181,10 +236,17 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.tile_total = tile_tot.as<uint32_t>();
     pl.visited = (mark_in_probe && !want_pairs) ? visited.as<uint32_t>() : nullptr;
     pl.status = ctx->status.as<uint32_t>();
-    pl.nslots = nslots; pl.bloom_mask = bloom_bits - 1;
+    pl.nslots = nslots; pl.bloom_mask = filter_words - 1;
+    pl.n_regions = n_regions; pl.slot_bits = slot_bits; pl.bword_bits = bword_bits;
+    pl.dbg = (uint32_t)env_int("QHIP_PROBE_DBG", 0);
     QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
     void* args[] = {&ka, &pl};
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 8));
+    // ~12 tiles per wavefront once every CU has work: each wavefront pays three trips to fill and drain its pipeline,
+    // and the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of exactly
+    // the assumed residency that is one short runs its remainder as a second round) — the hardware deals them out as
+    // earlier ones finish, so the tail is a fraction of one workgroup's share
+    const uint64_t tpw = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::max<uint64_t>(std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 4), (ntiles + 4 * tpw - 1) / (4 * tpw)));
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     st[QS_WORDS] = 0;
     if (want_pairs) {

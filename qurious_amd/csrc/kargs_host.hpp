@@ -60,7 +60,7 @@ static_assert(sizeof(HProjOut) == 2 * 8 * 24, "ProjOut layout");
 
 struct HProbeLaunch {
   const uint64_t* table;
-  const uint32_t* bloom;
+  const uint64_t* bloom;
   const uint32_t* count;
   const uint32_t* start;
   const uint32_t* rows;
@@ -71,8 +71,18 @@ struct HProbeLaunch {
   uint32_t* visited;
   uint32_t* status;
   uint32_t nslots, bloom_mask;
+  uint32_t n_regions = 0, slot_bits = 0, bword_bits = 0, dbg = 0;   // region layout of the LDS-staged build (0 = legacy)
 };
-static_assert(sizeof(HProbeLaunch) == 11 * 8 + 8, "ProbeLaunch layout");
+static_assert(sizeof(HProbeLaunch) == 11 * 8 + 8 + 16, "ProbeLaunch layout");
+
+struct HScatterLaunch {
+  uint64_t* entries;
+  uint32_t* first;
+  uint32_t* status;
+  uint32_t n_regions;
+  uint32_t rows_per_wg;
+};
+static_assert(sizeof(HScatterLaunch) == 32, "ScatterLaunch layout");
 constexpr int kProbeTileRows = 64 * 4;   // one wavefront's share: 64 * QH_PROBE_R consecutive probe rows
 
 }  // namespace qhip

@@ -31,7 +31,11 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
 
 // hash join (kernels_rel.hip)
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
-                              uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
+                              uint32_t* row_slot, uint32_t* extra, uint64_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s);
+// LDS-staged build, step 2: one workgroup per region collects the region's entries of every step-1 workgroup and stores the
+// region's open-addressing image + filter slice
+void launch_join_region_build(int W, const uint64_t* entries, const uint32_t* first, uint32_t n_wgs, uint32_t rows_per_wg, uint64_t* table,
+                              uint64_t* bloom, uint32_t n_regions, uint32_t slot_bits, uint32_t bword_bits, uint32_t* status, hipStream_t s);
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s);
 void launch_add_i32(int32_t* p, uint64_t n, int32_t delta, hipStream_t s);
 // p[i] += shifts[b] for the batch b with starts[b] <= i < starts[b + 1] (starts: nb + 1 ascending row numbers)

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
 // Further rows of a key only count themselves in extra[slot] and raise the duplicates flag (status[QS_MAXCOUNT] = 2).
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys, const u64* keyvalid, u64 n, u64* table, u32 nslots,
-                                                               u32* row_slot, u32* extra, u32* bloom, u32 bloom_mask, u32* status) {
+                                                               u32* row_slot, u32* extra, u64* bloom, u32 bloom_mask, u32* status) {
   u32 flags = 0;
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
     u32 sid = nslots;   // NULL key: sorts behind every real slot, never probed
@@ -278,8 +278,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys,
             for (int w = 0; w < W; ++w) qh_st64<MemHbm>(slot + 1 + w, k[w]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // key words visible before the slot reads as ready
             qh_st64<MemHbm>(slot, (u64)i + 2);
-            const u32 bit = (u32)(h >> 32) & bloom_mask;
-            atomicOr(&bloom[bit >> 5], qh_bloom_bits(h));
+            (void)__hip_atomic_fetch_or(&bloom[qh_filter_word(h, bloom_mask)], qh_filter_mask((u32)h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sid = s;
             break;
           }
@@ -298,6 +297,106 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys,
     if (ovf) atomicOr(&status[QS_OVERFLOW], 1u);
   }
 }
+// LDS-staged build, step 2 (step 1: qh_join_scatter_body in device/qhip_device.hpp): ONE workgroup per region. Thread w
+// collects the region's entries [row + 2 | key words] that step-1 workgroup w (w + 512, ...) left in its own range of
+// `entries` (their positions: first[w][region], first[w][region + 1]) and inserts them into an open-addressing image of
+// the region in LDS (DS compare-and-swap on the state word, probe sequence wrapping inside the region); the region's
+// slice of the hash filter is assembled beside it, and both are stored as whole lines — the table is never memset and
+// never sees an HBM atomic. A second row with an equal key (the unique-key speculation failed) or a region with more
+// entries than 7/8 of its slots raises status[QS_MAXCOUNT] = 2: the host then builds the legacy layout.
+#define QH_REGION_BLOCK 512
+// one entry into the LDS image `lt` of a region of S slots (+ its filter bits into `lb`); true when an equal key is
+// already there
+template <int W>
+__device__ __forceinline__ bool region_insert(u64* lt, u64* lb, u32 S, u32 slot_bits, u32 bword_bits, const u64* ent) {
+  const u64 h = qh_key_hash<W>(ent + 1);
+  u32 s = (u32)h & (S - 1);
+  u32 probes = 0;
+  while (probes < S) {
+    u64* slot = lt + (size_t)s * (1 + W);
+    const u64 st = qh_ld64<MemLds>(slot);
+    if (st >= QH_READY) {
+      bool eq = true;
+#pragma unroll
+      for (int w = 0; w < W; ++w) eq &= qh_ld64<MemLds>(slot + 1 + w) == ent[1 + w];
+      if (eq) return true;
+      s = (s + 1) & (S - 1); ++probes;
+    } else if (st == QH_EMPTY) {
+      if (qh_cas64<MemLds>(slot, QH_EMPTY, QH_BUSY)) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) qh_st64<MemLds>(slot + 1 + w, ent[1 + w]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // key words before the slot reads as ready
+        qh_st64<MemLds>(slot, ent[0]);
+        (void)__hip_atomic_fetch_or(&lb[qh_rfilter_word(h, slot_bits, bword_bits)], qh_rfilter_mask(h, slot_bits, bword_bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return false;
+      }
+      // lost the claim: look at the same slot again
+    }
+    // QH_BUSY: the claimer is between claim and publish; look again (a lane never spins inside an iteration)
+  }
+  return false;
+}
+
+template <int W>
+__global__ __launch_bounds__(QH_REGION_BLOCK) void k_join_region_build(const u64* entries, const u32* first, u32 n_wgs, u32 n_regions,
+                                                                        u32 rows_per_wg, u64* table, u64* bloom, u32 slot_bits,
+                                                                        u32 bword_bits, u32* status) {
+  constexpr int RB = QH_REGION_BLOCK;
+  const u32 S = 1u << slot_bits, BW = 1u << bword_bits, reg = blockIdx.x, tid = threadIdx.x;
+  u64* lt = (u64*)qh_dyn_lds;                 // [S][1 + W]
+  u64* lb = lt + (size_t)S * (1 + W);         // [BW]
+  __shared__ u32 total;
+  // this thread's share: the region's entries of step-1 workgroups tid, tid + RB, ... (the loads of the first one are
+  // issued before the LDS image is cleared)
+  u32 lo = 0, hi = 0;
+  if (tid < n_wgs) { const u32* f = first + (size_t)tid * (n_regions + 1) + reg; lo = f[0]; hi = f[1]; }
+  if (tid == 0) total = 0;
+  for (u32 k = tid; k < S * (1 + W); k += RB) lt[k] = 0;
+  for (u32 k = tid; k < BW; k += RB) lb[k] = 0;
+  __syncthreads();
+  u32 mine = hi - lo;
+  for (u32 w = tid + RB; w < n_wgs; w += RB) { const u32* f = first + (size_t)w * (n_regions + 1) + reg; mine += f[1] - f[0]; }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  const bool overfull = total > S - (S >> 3);   // workgroup-uniform
+  bool careful = overfull;
+  if (!overfull) {
+    for (u32 w = tid; w < n_wgs; w += RB) {
+      if (w != tid) { const u32* f = first + (size_t)w * (n_regions + 1) + reg; lo = f[0]; hi = f[1]; }
+      const u64* src = entries + ((size_t)w * rows_per_wg + lo) * (1 + W);
+      const u32 n = hi - lo;
+      // four entries at a time: their loads are issued together (a thread has two entries on average, rarely more than four)
+      for (u32 e0 = 0; e0 < n; e0 += 4) {
+        u64 ent[4][1 + W];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 e = e0 + j < n ? e0 + j : n - 1;
+#pragma unroll
+          for (int x = 0; x < 1 + W; ++x) ent[j][x] = src[(size_t)e * (1 + W) + x];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (e0 + j < n) careful |= region_insert<W>(lt, lb, S, slot_bits, bword_bits, ent[j]);
+      }
+    }
+  }
+  __syncthreads();
+  // an overfull region is stored EMPTY: every state word the (speculatively launched) probe reads is a valid one
+  u64* gr = table + ((size_t)reg << slot_bits) * (1 + W);
+  typedef u64 v2u64 __attribute__((ext_vector_type(2)));
+  const u32 pairs = S * (1 + W) / 2;           // S is even
+  for (u32 k = tid; k < pairs; k += RB) {
+    v2u64 v;
+    v.x = overfull ? 0ULL : lt[2 * k];
+    v.y = overfull ? 0ULL : lt[2 * k + 1];
+    ((v2u64*)gr)[k] = v;
+  }
+  u64* gb = bloom + ((size_t)reg << bword_bits);
+  for (u32 k = tid; k < BW; k += RB) gb[k] = overfull ? 0ULL : lb[k];
+  const u64 any = qh_ballot(careful);
+  if (any && qh_lane() == 0 && __hip_atomic_load(&status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) atomicMax(&status[QS_MAXCOUNT], 2u);
+}
+
 // duplicated build keys: rows per slot = (slot occupied ? 1 : 0) + extra[slot]
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table, u32 nslots, u32* count) {
@@ -672,10 +771,17 @@ void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, ui
   }
 
 void launch_join_build_insert(int W, const uint64_t* keys, const uint64_t* keyvalid, uint64_t n, uint64_t* table, uint32_t nslots,
-                              uint32_t* row_slot, uint32_t* extra, uint32_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s) {
+                              uint32_t* row_slot, uint32_t* extra, uint64_t* bloom, uint32_t bloom_mask, uint32_t* status, hipStream_t s) {
   if (!n) return;
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_build_insert<KW>, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (const u64*)keyvalid, (u64)n,
-                                   (u64*)table, nslots, (u32*)row_slot, (u32*)extra, (u32*)bloom, bloom_mask, (u32*)status));
+                                   (u64*)table, nslots, (u32*)row_slot, (u32*)extra, (u64*)bloom, bloom_mask, (u32*)status));
+}
+void launch_join_region_build(int W, const uint64_t* entries, const uint32_t* first, uint32_t n_wgs, uint32_t rows_per_wg, uint64_t* table,
+                              uint64_t* bloom, uint32_t n_regions, uint32_t slot_bits, uint32_t bword_bits, uint32_t* status, hipStream_t s) {
+  if (!n_regions) return;
+  const size_t lds = ((size_t)8 * (1 + (size_t)W) << slot_bits) + ((size_t)8 << bword_bits);
+  DISPATCH_W(W, hipLaunchKernelGGL(k_join_region_build<KW>, dim3(n_regions), dim3(QH_REGION_BLOCK), lds, s, (const u64*)entries, (const u32*)first,
+                                   n_wgs, n_regions, rows_per_wg, (u64*)table, (u64*)bloom, slot_bits, bword_bits, (u32*)status));
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {
   DISPATCH_W(W, hipLaunchKernelGGL(k_join_full_counts<KW>, dim3(grid_for(nslots)), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, (u32*)count));

@@ -67,7 +67,19 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
     auto in = make_input(col_types, col_has_nulls, n_cols);
     ExprSet es; es.build(exprs, n_exprs, in);
     KeysPlan p;
-    plan_keys(es, in, key_roots, n_keys, p, predicate_root, true);
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_PROBE);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                             int32_t n_exprs, const int32_t* key_roots, int32_t n_keys, int32_t predicate_root, char* buf, size_t buflen,
+                             size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    ExprSet es; es.build(exprs, n_exprs, in);
+    KeysPlan p;
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_SCATTER);
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }

@@ -92,6 +92,20 @@ def probe_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: Opt
     return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot))
 
 
+def scatter_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: Optional[PhysicalExpr] = None,
+                   has_nulls: Optional[Sequence[bool]] = None) -> str:
+    """Source of the build-side kernel of HashJoinExec's LDS-staged build (key words -> region entries)."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_scatter_source
+    fn.restype = C.c_int
+    types, hn, n = _cols(schema, has_nulls)
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    proot = ea.lower(predicate) if predicate is not None else -1
+    arr, ne = ea.c_array()
+    return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot))
+
+
 def sort_keys_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], has_nulls: Optional[Sequence[bool]] = None) -> str:
     """Source of the order-preserving key image kernel Sort launches (Utf8 keys have no generated part)."""
     lib = _ffi.load_library()

@@ -76,3 +76,12 @@ def engine(request):
         return _OracleEngine(qoracle)
     qurious_amd.get_context()   # fails loudly without a gfx950 device: no fallback
     return _HipEngine()
+
+
+@pytest.fixture(params=["auto", "regions"])
+def join_layout(request, monkeypatch):
+    """Every join test runs twice: with the build layout libqhip picks by itself (small build sides: one table filled with
+    atomics) and with the LDS-staged region build forced on every join (QHIP_JOIN_REGION=2, csrc/join.cpp)."""
+    if request.param == "regions":
+        monkeypatch.setenv("QHIP_JOIN_REGION", "2")
+    return request.param

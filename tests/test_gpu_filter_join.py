@@ -94,6 +94,7 @@ def test_filter_all_layouts_multi_batch(ctx, oracle):
     assert plan.execute()[0].schema.names == ["d", "i32"]
 
 
+
 # ---------------------------------------------------------------- HashJoinExec
 def _join_case(case):
     left = build_table_scan_i32(case["left"])
@@ -103,14 +104,14 @@ def _join_case(case):
     return q.HashJoinExec.try_new(left, right, JoinType[case["join_type"]], on, None)
 
 
-def test_hash_join_exec_reference_goldens(ctx, golden):
+def test_hash_join_exec_reference_goldens(ctx, golden, join_layout):
     """hash_join.rs:396-698, 889-914 — output rows in the exact order the reference asserts"""
     for case in golden["hash_join_exec"]["cases"]:
         got = rows_of(_join_case(case).execute())
         assert got == [tuple(r) for r in case["expected"]], case["name"]
 
 
-def test_slt_join_goldens(ctx, golden):
+def test_slt_join_goldens(ctx, golden, join_layout):
     j = golden["slt"]["join_xy"]
     plan = q.HashJoinExec.try_new(_t(["a", "b"], j["x"]), _t(["c", "d"], j["y"]), JoinType.Inner, [(col("a", 0), col("c", 0))], None)
     assert rows_of(plan.execute()) == [tuple(r) for r in j["inner_a_eq_c"]]
@@ -140,7 +141,7 @@ def _random_sides(rng, nl, nr, nkeys, null_p=0.08):
 
 
 @pytest.mark.parametrize("jt", list(JoinType))
-def test_hash_join_all_types_random_vs_oracle(ctx, oracle, jt):
+def test_hash_join_all_types_random_vs_oracle(ctx, oracle, jt, join_layout):
     """duplicate keys on both sides, NULL keys (never match), two-column keys (Int64 + Utf8), probe side in ragged batches"""
     rng = np.random.default_rng(100 + int(jt))
     (ls, lb), (rs, rb) = _random_sides(rng, 700, 1500, 60)
@@ -159,7 +160,7 @@ def test_hash_join_all_types_random_vs_oracle(ctx, oracle, jt):
 
 @pytest.mark.parametrize("force_csr", [False, True])
 @pytest.mark.parametrize("unique_build", [True, False])
-def test_hash_join_probe_many_tiles(ctx, oracle, monkeypatch, force_csr, unique_build):
+def test_hash_join_probe_many_tiles(ctx, oracle, monkeypatch, force_csr, unique_build, join_layout):
     """2.5 M probe rows (~10^4 probe tiles) with a fused scan filter, over unique build keys (slot -> row, also forced
     through the CSR path) and duplicated ones (CSR from the stable sort): the reference's pair order in every case."""
     if force_csr:
@@ -185,7 +186,7 @@ def test_hash_join_probe_many_tiles(ctx, oracle, monkeypatch, force_csr, unique_
         _batches_equal(plan.execute(), oracle.execute(plan))
 
 
-def test_hash_join_many_pairs_per_probe_row(ctx, oracle):
+def test_hash_join_many_pairs_per_probe_row(ctx, oracle, join_layout):
     """heavily duplicated keys on both sides: ~100 build rows per probe row"""
     rng = np.random.default_rng(78)
     (ls, lb), (rs, rb) = _random_sides(rng, 4000, 3000, 40, null_p=0.02)
@@ -197,7 +198,7 @@ def test_hash_join_many_pairs_per_probe_row(ctx, oracle):
         _batches_equal(got, oracle.execute(plan))
 
 
-def test_hash_join_edge_cases(ctx, oracle):
+def test_hash_join_edge_cases(ctx, oracle, join_layout):
     (ls, lb), (rs, rb) = _random_sides(np.random.default_rng(5), 50, 80, 10)
     empty_l = table_scan(ls, [lb.slice(0, 0)])
     empty_r = table_scan(rs, [rb.slice(0, 0)])
@@ -214,7 +215,7 @@ def test_hash_join_edge_cases(ctx, oracle):
         q.HashJoinExec.try_new(full_l, full_r, JoinType.Inner, [(col("l_k1", 0), col("r_pay", 2))], None).execute()
 
 
-def test_join_then_aggregate_stays_on_device(ctx, oracle):
+def test_join_then_aggregate_stays_on_device(ctx, oracle, join_layout):
     """Q3-shaped mini pipeline: Scan(filter) |><| Scan(filter) -> HashAggregate(SUM(decimal expr)) — bit-exact"""
     rng = np.random.default_rng(9)
     D = decimal.Decimal
@@ -242,7 +243,7 @@ def test_join_then_aggregate_stays_on_device(ctx, oracle):
     assert got == want and len(got) > 100
 
 
-def test_utf8_keys_longer_than_one_word(ctx, oracle):
+def test_utf8_keys_longer_than_one_word(ctx, oracle, join_layout):
     """Utf8 group / join keys are packed into 1..4 key words sized from the column's longest value (<= 31 bytes)"""
     rng = np.random.default_rng(77)
     segs = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY", "", "4-NOT SPECIFIED", "x" * 31, "y" * 16, "ab"]

@@ -23,7 +23,7 @@ def _q3_tables(sf):
             q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
 
 
-def test_q3_sf001_matches_oracle(ctx, oracle):
+def test_q3_sf001_matches_oracle(ctx, oracle, join_layout):
     plan = queries.q3(*_q3_tables(0.01))
     got = sorted(rows_of(plan.execute()))
     want = sorted(rows_of(oracle.execute(plan)))
