@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the qurious-hip backend (contract: see the task prompt / DESIGN.md §Measurement).
+"""bench.py — benchmark of the qurious-hip backend on BASELINE.json's metric: rows/s on TPC-H Q1 scan+agg and Q3 hash-join
+at SF10, HBM-resident synthetic Arrow tables (contract: the task prompt / DESIGN.md §6).
 
     python bench.py --gpus N --steps K --warmup W            (N = 1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-BASELINE.json configs[1] — SELECT l_returnflag, SUM(l_quantity) FROM lineitem WHERE l_shipdate < '1998-09-01'
-GROUP BY l_returnflag over 100M synthetic rows (2^20-row Arrow batches) — executed by the fused filter +
-hash-aggregate HIP kernel through the C ABI. With N > 1 every rank owns its own 100M-row shard (weak scaling,
-rows are independent; partial aggregates are merged once on the host for verification — no data-path collective).
+A STEP is one pass of the hot path over the metric's two configurations: TPC-H Q1's aggregate list over SF10's
+59 986 052 lineitem rows (BASELINE configs[2]) followed by TPC-H Q3 at SF10 (configs[3]: customer |><| orders |><|
+lineitem -> GROUP BY). `value` = lineitem rows scanned by the two queries / wall time of K such steps, i.e. the job's
+whole-pipeline throughput including plan lowering, launches and the host round trips that size intermediate results.
+SF10 is fixed, so N > 1 is STRONG scaling: every rank holds a contiguous 1/N slice of every table; Q1 aggregates its
+slice and the partial groups are merged (one small all-gather), Q3's joins go through the exchange operators of
+qurious_amd/exchange.py over RCCL (--strategy broadcast: all-gather the small build sides; repartition: all-to-all both
+sides by key hash; both are measured at N > 1, `value` uses --strategy).
 
-Prints ONE JSON line on rank 0: value = rows/s of the whole job, plus
-  roofline     — algorithmic bytes (25 B/row) / mean device time of the dominant kernel (HIP events on
-                 the library's stream) vs the 8 TB/s HBM peak; `traffic` = PMC-measured HBM bytes per launch when a
-                 profile summary for this round exists under profiles/ (else null)
-                 `stream_read_GBps` = a plain streaming-read kernel timed in the same run (the achievable ceiling)
-  cpu_baseline — the CPU oracle's faithful-cost restatement of the reference executor (oracle/qoracle.c, 1 thread)
-                 timed on a bounded sample of the same workload on this box's host cores (single-GPU runs only).
-  extra        — (N = 1, default workload) the other single-GPU configurations: Q1's aggregate list and Q3 at SF10.
+Rank 0 prints ONE JSON line. Besides the contract's fields it carries
+  roofline      the step's dominant kernel (Q1's fused filter + aggregate): bytes the kernel actually reads per launch /
+                its mean device time (HIP events on the library's stream) against the 8 TB/s HBM peak; `traffic` = HBM
+                bytes per launch from this round's PMC profile (profiles/r02_pmc_summary.json) when that profile was taken
+                on the same kernel, row count and bytes per row — otherwise null with the reason
+  cpu_baseline  the CPU oracle (oracle/qoracle.c, a faithful-cost restatement of the reference executor, 1 thread because
+                the reference is single-threaded) on a bounded sample of the same two queries: 1 warm-up + median of 5
+  records       one record per configuration — q1_sf10 (configs[2]), q3_sf10 (configs[3]); at N = 1 also q1_mini
+                (configs[1], 100 M rows) and filter_lineitem (the standalone Filter operator) — each with its own value,
+                per-kernel roofline (bytes actually read) and cpu_baseline
+  exchange      (N > 1) bytes each rank sent, seconds inside the exchanges, GB/s against 7 x 153 GB/s of xGMI
 
-Other workloads: --workload q1_full | q3 [--sf S] [--skew 1.1] ; q3 with N > 1 shards the tables over the ranks and joins
-them with --strategy broadcast (all-gather the small build sides, default) or repartition (all-to-all both sides by key).
+Other modes: --workload q1_mini | q1_full | q3 | filter run ONE configuration as the step (profiling, parameter sweeps);
+--workload q3 --sf 100 --skew 1.1 --slice R/N generates only rank R's 1/N slice of SF100 (BASELINE configs[4] on one GPU).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -33,17 +41,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import qurious_amd as q  # noqa: E402  (before torch: binds the system ROCm runtime first)
+from qurious_amd import plan as qplan  # noqa: E402
 from qurious_amd import queries, synth  # noqa: E402
 
-ALGO_BYTES_PER_ROW = {"q1_mini": 25, "q1_full": 78}   # Date32 4 + Utf8 (4+1) [x2 for Q1] + Decimal128 16 [x4]
+METRIC = "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X"
+SURVEY_BYTES_PER_ROW = {"q1_mini": 25, "q1_full": 78}   # Date32 4 + Utf8 (4+1) [x2 for Q1] + Decimal128 16 [x4]
+Q3_SURVEY_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_PEAK_GBS = 7 * 153.0                               # 7 links x ~153 GB/s per GPU
+SF10_LINEITEM_ROWS = 59_986_052
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+
+USE_DIST = False   # set by main(): a torch.distributed process group (RCCL) is up
 
 
-def gen_table(first_row: int, n_rows: int, batch_rows: int) -> q.MemoryTable:
-    starts = list(range(0, n_rows, batch_rows))
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        batches = list(ex.map(lambda s: synth.lineitem_batch(first_row + s, min(batch_rows, n_rows - s)), starts))
-    return q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, batches)
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def result_key(batches):
@@ -53,183 +67,386 @@ def result_key(batches):
     return sorted(rows)
 
 
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+def lineitem_table(first_row: int, n_rows: int, batch_rows: int) -> q.MemoryTable:
+    starts = list(range(0, n_rows, batch_rows))
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        batches = list(ex.map(lambda s: synth.lineitem_batch(first_row + s, min(batch_rows, n_rows - s)), starts))
+    return q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, batches)
 
 
-USE_DIST = False   # set by main(): a torch.distributed process group (RCCL) is up
-
-Q3_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}   # SURVEY §8(d) algorithmic bytes per row
-
-
-def bench_q3(args, ctx, rank, world, barrier, dist, torch):
-    """configs[3]: TPC-H Q3 (customer |><| orders |><| lineitem -> GROUP BY) at --sf, tables sliced over the ranks, both
-    joins repartitioned by key with the RCCL exchange (qurious_amd/exchange.py) when world > 1."""
-    from qurious_amd import exchange
-    t0 = time.time()
-    c, o, l = synth.q3_tables_skewed(args.sf, args.skew, rank, world) if args.skew > 0 else synth.q3_tables(args.sf, rank, world)
-    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+def q3_memory_tables(sf, skew, rank, world):
+    c, o, l = synth.q3_tables_skewed(sf, skew, rank, world) if skew > 0 else synth.q3_tables(sf, rank, world)
+    return (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
             q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
-    rows = [sum(b.num_rows for b in t.data) for t in tabs]
-    log(f"generated SF{args.sf} slice {rows} rows in {time.time() - t0:.1f}s")
-    for t in tabs:
-        t.device_table()
-    if USE_DIST and args.strategy == "broadcast":
-        # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
-        plan = queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)
-    else:
-        plan = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec if USE_DIST else None)
-    if USE_DIST:
-        exchange.prune_exchange_columns(plan)   # the exchanges move only the columns the plan above them reads
-    for _ in range(args.warmup):
-        out = plan.execute_device()
-        log(f"warmup step: {out.num_rows} groups")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = plan.execute_device()
-    ctx.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if USE_DIST:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor(rows + [out.num_rows], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot)
-        rows_all = tot.tolist()
-    else:
-        rows_all = rows + [out.num_rows]
-    table_stats = None
-    if args.skew > 0 or os.environ.get("QHIP_AGG_STATS"):
-        # BASELINE configs[4]: LDS hash-table occupancy of the final aggregate (one extra, untimed, instrumented execution)
-        os.environ["QHIP_AGG_STATS"] = "1"
-        plan.execute_device()
-        st = ctx.last_stats()
-        os.environ.pop("QHIP_AGG_STATS", None)
-        table_stats = {"lds_table_slots_per_workgroup": st["lds_table_slots"], "lds_occupancy": st["lds_occupancy"],
-                       "lds_spilled": bool(st["lds_spilled"]), "hbm_table_slots": st["table_capacity"], "hbm_table_load": st["hbm_table_load"],
-                       "groups": st["groups"], "workgroups": st["workgroups"]}
-    xgmi = exchange.exchange_stats() if USE_DIST else None
-    if rank != 0:
-        dist.destroy_process_group()
-        return
-    algo_bytes = rows_all[0] * Q3_BYTES["customer"] + rows_all[1] * Q3_BYTES["orders"] + rows_all[2] * Q3_BYTES["lineitem"]
-    ms = elapsed / args.steps * 1e3
-    achieved = algo_bytes / (ms * 1e-3) / 1e9 / world
-    cpu_baseline = None
-    if not args.no_cpu_baseline and world == 1:
-        from oracle import qoracle
-        sf_small = min(args.sf, 0.05)
-        cs, os_, ls = synth.q3_tables(sf_small)
-        small = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, cs), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, os_),
-                 q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, ls))
-        splan = queries.q3(*small)
+
+
+# ---------------------------------------------------------------- timing helpers
+class Clock:
+    """K timed steps between two barrier + synchronize pairs; MAX over ranks."""
+
+    def __init__(self, ctx, torch, dist):
+        self.ctx, self.torch, self.dist = ctx, torch, dist
+
+    def barrier(self):
+        if USE_DIST:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.ctx.synchronize()
+
+    def run(self, step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        self.barrier()
         t0 = time.perf_counter()
-        want = qoracle.execute(splan)
-        cdt = time.perf_counter() - t0
-        assert result_key(want) == result_key(splan.execute()), "HIP Q3 result differs from the CPU oracle"
-        nl = sum(b.num_rows for b in ls)
-        cpu_baseline = {"value": nl / cdt, "unit": "rows/s", "cores": 1, "kind": "port", "seconds": cdt,
-                        "sample": f"Q3 at SF{sf_small} ({nl} lineitem rows) through oracle/qoracle.py + qoracle.c, 1 of {os.cpu_count()} host cores"}
-    line = {
-        "metric": "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X",
-        "value": rows_all[2] * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i128", "data": "synthetic",
-        "config": {"workload": f"configs[3] q3: TPC-H Q3 SF{args.sf} customer|><|orders|><|lineitem + GROUP BY, HBM-resident, "
-                               f"lineitem rows/s", "rows": {"customer": rows_all[0], "orders": rows_all[1], "lineitem": rows_all[2]},
-                   "groups": rows_all[3], "parallelism": (f"broadcast build sides, local probes, merged partial groups x{world}" if USE_DIST and args.strategy == "broadcast"
-                                   else f"hash-partitioned joins x{world}")},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "q3 pipeline (all kernels of one query, per GPU)", "kernel_ms": ms,
-                     "algorithmic_bytes": algo_bytes},
-        "cpu_baseline": cpu_baseline, "device": ctx.device_name(),
-    }
-    if args.skew > 0:
-        line["config"]["workload"] += f", join keys re-drawn from Zipf(s={args.skew}) (configs[4] shape)"
-    if table_stats:
-        line["aggregate_table"] = table_stats
-    if xgmi:
-        line["exchange"] = xgmi   # bytes this rank sent over xGMI and the time spent in the exchanges, per query
-    print(json.dumps(line))
-    if USE_DIST:
-        dist.destroy_process_group()
+        for _ in range(steps):
+            step()
+        self.ctx.synchronize()   # results are ordered on libqhip's own stream
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if USE_DIST:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
 
 
-def cpu_all_cores(workload, batches, threads):
-    """The CPU oracle over `threads` disjoint batch ranges at once (ctypes releases the GIL; the C code keeps no shared
-    state): rows/s of the wall time. Labelled context in the bench line — the reference executor is single-threaded."""
-    from oracle import qoracle
-    parts = [batches[i::threads] for i in range(threads)]
-    plans = [getattr(queries, workload)(q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, p)) for p in parts if p]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=len(plans)) as ex:
-        res = list(ex.map(qoracle.scan_filter_aggregate_timed, plans))
-    dt = time.perf_counter() - t0
-    rows = sum(r[2] for r in res)
-    return {"value": rows / dt, "unit": "rows/s", "threads": len(plans), "seconds": dt, "note": "oracle on row ranges in parallel; not the reference"}
-
-
-def extra_single_gpu(args, ctx, table):
-    """configs[2] (TPC-H Q1 aggregate list over the resident lineitem rows) and configs[3] (Q3 at SF10) on this GPU."""
-    out = {}
-    try:
-        plan = queries.q1_full(table)
-        for _ in range(3):
-            plan.execute_device()
-        ctx.synchronize()
-        ks = []
-        t0 = time.perf_counter()
-        for _ in range(10):
-            plan.execute_device()
-            ks.append(ctx.last_stats()["main_kernel_ms"])
-        ctx.synchronize()
-        dt = (time.perf_counter() - t0) / 10
-        km = sum(ks) / len(ks)
-        out["q1_full"] = {"workload": f"configs[2] TPC-H Q1 (2 keys, 8 aggregates) over {args.rows} resident lineitem rows",
-                          "rows_per_s": args.rows / dt, "ms_per_step": dt * 1e3, "kernel_ms": km,
-                          "kernel_bytes_per_row": min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78),
-                          "roofline_GBps": args.rows * min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78) / (km * 1e-3) / 1e9,
-                          "roofline_frac": args.rows * min(ALGO_BYTES_PER_ROW["q1_full"], ctx.last_stats().get("bytes_per_row_read") or 78) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        log(f"extra q1_full: kernel {km:.3f} ms")
-        c, o, l = synth.q3_tables(10.0)
-        tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
-                q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
-        rows = [sum(b.num_rows for b in t.data) for t in tabs]
-        p3 = queries.q3(*tabs)
-        for _ in range(3):
-            p3.execute_device()
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            res = p3.execute_device()
-        ctx.synchronize()
-        dt = (time.perf_counter() - t0) / 10
-        algo = rows[0] * Q3_BYTES["customer"] + rows[1] * Q3_BYTES["orders"] + rows[2] * Q3_BYTES["lineitem"]
-        out["q3_sf10"] = {"workload": "configs[3] TPC-H Q3 SF10 (two hash joins + GROUP BY) on one GPU", "rows": rows, "groups": res.num_rows,
-                          "lineitem_rows_per_s": rows[2] / dt, "ms_per_query": dt * 1e3, "algorithmic_GBps": algo / dt / 1e9}
-        log(f"extra q3 sf10: {dt * 1e3:.2f} ms/query")
-    except Exception as e:   # the headline line must not depend on the extras
-        out["error"] = f"{type(e).__name__}: {e}"
+def operator_stats(step, passes=5):
+    """`passes` instrumented (untimed) executions of `step`: per operator call, in execution order, the mean of its
+    qhip_exec_stats timings (HIP events on the library's stream) and its last other fields."""
+    runs = []
+    for _ in range(passes):
+        qplan.STATS_SINK = []
+        try:
+            step()
+        finally:
+            sink, qplan.STATS_SINK = qplan.STATS_SINK, None
+        runs.append(sink)
+    out = []
+    for k, (label, st) in enumerate(runs[-1]):
+        same = [r[k][1] for r in runs if len(r) == len(runs[-1])]
+        rec = dict(st)
+        for f in ("main_kernel_ms", "total_device_ms", "build_ms"):
+            rec[f] = sum(s[f] for s in same) / len(same)
+        rec["operator"] = label
+        out.append(rec)
     return out
 
 
+def pmc_traffic(workload, kernel, rows, bytes_per_row):
+    """HBM bytes per launch of `kernel` from this round's PMC profile — only when the profile was taken on the same
+    kernel at the same row count and bytes per row (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None, f"no {os.path.relpath(PMC_SUMMARY, ROOT)}"
+    try:
+        with open(PMC_SUMMARY) as f:
+            prof = json.load(f).get(workload, {})
+    except Exception as e:
+        return None, f"unreadable profile summary: {e}"
+    seen = []
+    for k in prof.get("kernels", []):
+        if k.get("kernel") != kernel:
+            continue
+        if int(k.get("rows", -1)) == int(rows) and abs(float(k.get("kernel_bytes_per_row", -1)) - float(bytes_per_row)) < 1e-6:
+            return k.get("hbm_bytes_per_launch"), f"{os.path.relpath(PMC_SUMMARY, ROOT)} ({prof.get('collected', 'r02')})"
+        seen.append(f"rows={k.get('rows')} bytes/row={k.get('kernel_bytes_per_row')}")
+    if seen:
+        return None, f"profile has {kernel} at {'; '.join(seen)} — this run: rows={rows} bytes/row={bytes_per_row}"
+    return None, f"{kernel} not in the profile summary of {workload}"
+
+
+def roofline(kernel, kernel_ms, bytes_per_launch, traffic=None, traffic_source=None, **extra):
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": kernel_ms,
+         "bytes_read_per_launch": bytes_per_launch}
+    r.update(extra)
+    return r
+
+
+def median_runs(fn, runs=5):
+    """1 warm-up + `runs` timed calls of fn() -> seconds; returns (median seconds, all timed seconds, last result)."""
+    res = fn()
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        res = fn()
+        times.append(time.perf_counter() - t0)
+    return statistics.median(times), times, res
+
+
+# ---------------------------------------------------------------- CPU baselines (rank 0, N = 1 only)
+def cpu_scan_aggregate(workload, table, batch_rows, sample_rows):
+    """The oracle's qo_scan_filter_aggregate (per-batch literal broadcast + cast + compare, compaction of all 7 columns,
+    concat, SipHash per row, hash -> group map, per-group take + reduce) over the first `sample_rows` rows."""
+    from oracle import qoracle
+    sample = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, table.data[: max(1, sample_rows // batch_rows)])
+    cplan = getattr(queries, workload)(sample)
+    rows = sum(b.num_rows for b in sample.data)
+    log(f"cpu baseline {workload}: oracle over {rows} rows, 1 warm-up + 5 runs ...")
+    med, times, res = median_runs(lambda: qoracle.scan_filter_aggregate_timed(cplan))
+    assert result_key([res[0]]) == result_key(cplan.execute()), f"HIP {workload} differs from the CPU oracle on the baseline sample"
+    log(f"cpu baseline {workload}: {rows / med / 1e6:.2f} M rows/s (median {med:.2f} s)")
+    return {"value": rows / med, "unit": "rows/s", "cores": 1, "kind": "port", "runs": len(times), "seconds_median": med,
+            "seconds_all": [round(t, 3) for t in times],
+            "sample": f"{rows} rows ({len(sample.data)} batches of {batch_rows}) of the same workload through oracle/qoracle.c "
+                      f"qo_scan_filter_aggregate, 1 of {os.cpu_count()} host cores (the reference executor is single-threaded), "
+                      "1 warm-up + median of 5; HIP result on the sample equals the oracle's bit for bit"}
+
+
+def cpu_q3(sf):
+    from oracle import qoracle
+    tabs = q3_memory_tables(sf, 0.0, 0, 1)
+    splan = queries.q3(*tabs)
+    nl = sum(b.num_rows for b in tabs[2].data)
+    log(f"cpu baseline q3: oracle at SF{sf} ({nl} lineitem rows), 1 warm-up + 5 runs ...")
+    med, times, want = median_runs(lambda: qoracle.execute(splan))
+    assert result_key(want) == result_key(splan.execute()), "HIP Q3 result differs from the CPU oracle on the baseline sample"
+    log(f"cpu baseline q3: {nl / med / 1e6:.2f} M lineitem rows/s (median {med:.2f} s)")
+    return {"value": nl / med, "unit": "rows/s", "cores": 1, "kind": "port", "runs": len(times), "seconds_median": med,
+            "seconds_all": [round(t, 3) for t in times],
+            "sample": f"Q3 at SF{sf} ({nl} lineitem rows) through oracle/qoracle.py + qoracle.c (JoinHashMap chains, SipHash, per-group "
+                      f"take + reduce), 1 of {os.cpu_count()} host cores, 1 warm-up + median of 5; HIP result on the sample equals the oracle's"}
+
+
+# ---------------------------------------------------------------- configurations
+class Q1:
+    """configs[1] (q1_mini, 100 M rows) / configs[2] (q1_full = TPC-H Q1's aggregate list, SF10 rows): the fused filter +
+    hash-aggregate kernel over this rank's slice of the table."""
+
+    def __init__(self, args, ctx, workload, rows_total, rank, world):
+        self.workload, self.rows_total, self.world, self.ctx = workload, rows_total, world, ctx
+        lo = rows_total * rank // world
+        self.rows = rows_total * (rank + 1) // world - lo
+        t0 = time.time()
+        self.table = lineitem_table(lo, self.rows, args.batch_rows)
+        self.t_gen = time.time() - t0
+        t0 = time.time()
+        dev = self.table.device_table()
+        self.t_upload = time.time() - t0
+        self.resident = sum(dev.column_bytes(c) for c in range(dev.num_columns))
+        # N > 1: every rank aggregates its slice into partial groups (AVG planned as SUM and COUNT) that are merged after one
+        # small all-gather; N = 1: the query as the reference's planner builds it
+        self.plan = queries.q1_partial(self.table) if USE_DIST and workload == "q1_full" else getattr(queries, workload)(self.table)
+        self.batch_rows = args.batch_rows
+        log(f"{workload}: {self.rows} rows generated in {self.t_gen:.1f}s, uploaded in {self.t_upload:.1f}s")
+
+    def step(self):
+        out = self.plan.execute_device()
+        if USE_DIST:
+            self.merged = merge_partial_groups(self.plan, out)
+        return out
+
+    def record(self, args, clock, with_cpu):
+        elapsed = clock.run(self.step, args.steps, args.warmup)
+        ops = operator_stats(self.step)
+        st = ops[-1]
+        bpr = min(SURVEY_BYTES_PER_ROW[self.workload], st.get("bytes_per_row_read") or SURVEY_BYTES_PER_ROW[self.workload])
+        kbytes = self.rows * bpr
+        traffic, src = pmc_traffic(self.workload, st["main_kernel_name"], self.rows, bpr)
+        cfg = "configs[1]" if self.workload == "q1_mini" else "configs[2]"
+        what = ("filter + GROUP BY l_returnflag, SUM(l_quantity)" if self.workload == "q1_mini" else
+                "TPC-H Q1: 2 keys, 4 SUM + 3 AVG + COUNT (q1.slt:5-12)")
+        rec = {"workload": f"{cfg} {self.workload}: {what} over {self.rows_total} synthetic lineitem rows "
+                           f"({args.batch_rows}-row Arrow batches, HBM-resident, {self.world} rank(s))",
+               "value": self.rows_total * args.steps / elapsed, "unit": "rows/s", "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
+               "rows": self.rows_total, "groups": st["groups"], "resident_bytes_per_gpu": self.resident,
+               "roofline": roofline(st["main_kernel_name"], st["main_kernel_ms"], kbytes, traffic, src,
+                                    algorithmic_bytes_per_row=SURVEY_BYTES_PER_ROW[self.workload], kernel_bytes_per_row=bpr,
+                                    rows_per_launch=self.rows),
+               "cpu_baseline": None}
+        if with_cpu:
+            rec["cpu_baseline"] = cpu_scan_aggregate(self.workload, self.table, self.batch_rows, args.cpu_sample_rows)
+        return rec, elapsed
+
+
+def merge_partial_groups(plan, out):
+    """N > 1, Q1: all-gather the ranks' partial groups (<= 16 groups x 8 int64 words) and merge them on the host: SUM of
+    sums, SUM of counts (the Decimal128 sums as two int64 halves). Returns {key: [sums..., count]}."""
+    import torch
+    import torch.distributed as dist
+    rows = result_key(out.to_batches())
+    nk = len(plan.group_exprs)
+    words = 2 * (len(rows[0]) - nk) if rows else 0
+    buf = torch.zeros((16, 2 + max(words, 14)), dtype=torch.int64)
+    for g, r in enumerate(rows[:16]):
+        key = "|".join(str(v) for v in r[:nk]).encode()[:8]
+        buf[g, 0] = int.from_bytes(key.ljust(8, b"\0"), "little", signed=True)
+        buf[g, 1] = 1
+        for k, v in enumerate(r[nk:]):
+            u = int(v.scaleb(-v.as_tuple().exponent)) if hasattr(v, "as_tuple") else int(v)
+            u &= (1 << 128) - 1
+            lo, hi = u & ((1 << 64) - 1), u >> 64
+            buf[g, 2 + 2 * k] = lo - (1 << 64) if lo >= (1 << 63) else lo
+            buf[g, 3 + 2 * k] = hi - (1 << 64) if hi >= (1 << 63) else hi
+    dev = buf.cuda()
+    parts = [torch.empty_like(dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, dev)
+    merged = {}
+    for p in parts:
+        for row in p.cpu().tolist():
+            if not row[1]:
+                continue
+            acc = merged.setdefault(row[0], [0] * (len(row) // 2 - 1))
+            for k in range(len(acc)):
+                acc[k] = (acc[k] + ((row[2 + 2 * k] & ((1 << 64) - 1)) | ((row[3 + 2 * k] & ((1 << 64) - 1)) << 64))) & ((1 << 128) - 1)
+    return merged
+
+
+class Q3:
+    """configs[3] / configs[4]: TPC-H Q3 (customer |><| orders |><| lineitem -> GROUP BY) at --sf, every table sliced over
+    the ranks; with N > 1 the joins go through the exchange operators (qurious_amd/exchange.py)."""
+
+    def __init__(self, args, ctx, rank, world, strategy, slice_of=None):
+        from qurious_amd import exchange
+        self.exchange, self.ctx, self.world, self.strategy, self.sf, self.skew = exchange, ctx, world, strategy, args.sf, args.skew
+        t0 = time.time()
+        r, w = slice_of if slice_of else (rank, world)
+        self.tabs = q3_memory_tables(args.sf, args.skew, r, w)
+        self.rows = [sum(b.num_rows for b in t.data) for t in self.tabs]
+        for t in self.tabs:
+            t.device_table()
+        log(f"q3: SF{args.sf} slice {r}/{w} {self.rows} rows generated + uploaded in {time.time() - t0:.1f}s")
+        self.slice_of = slice_of
+        self.plans = {}
+
+    def plan(self, strategy):
+        if strategy not in self.plans:
+            ex = self.exchange
+            if USE_DIST and strategy == "broadcast":
+                # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
+                p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, agg_cls=ex.DistributedHashAggregate)
+            else:
+                p = queries.q3(*self.tabs, join_cls=ex.DistributedHashJoinExec if USE_DIST else None)
+            if USE_DIST:
+                ex.prune_exchange_columns(p)   # the exchanges move only the columns the plan above them reads
+            self.plans[strategy] = p
+        return self.plans[strategy]
+
+    def step(self, strategy=None):
+        self.out = self.plan(strategy or self.strategy).execute_device()
+        return self.out
+
+    def totals(self, torch, dist):
+        vals = self.rows + [self.out.num_rows]
+        if USE_DIST:
+            t = torch.tensor(vals, dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)
+            vals = t.tolist()
+        return vals
+
+    def record(self, args, clock, torch, dist, with_cpu, strategy=None):
+        strategy = strategy or self.strategy
+        ex = self.exchange
+        if USE_DIST:
+            ex.exchange_stats(reset=True)
+        elapsed = clock.run(lambda: self.step(strategy), args.steps, args.warmup)
+        xg = ex.exchange_stats(reset=True) if USE_DIST else None
+        tot = self.totals(torch, dist)
+        ops = operator_stats(lambda: self.step(strategy), passes=3)
+        joins = [o for o in ops if o["operator"] == "hash_join"]
+        aggs = [o for o in ops if o["operator"] == "aggregate"]
+        kernels = []
+        for k, j in enumerate(joins):
+            pb = j["rows_in"] * j["bytes_per_row_read"]
+            t, src = pmc_traffic("q3", "qk_join_probe", j["rows_in"], j["bytes_per_row_read"])
+            kernels.append(dict(roofline("qk_join_probe", j["main_kernel_ms"], pb, t, src, kernel_bytes_per_row=j["bytes_per_row_read"],
+                                         rows_per_launch=j["rows_in"]), operator=f"join {k + 1} probe", pairs=j["groups"]))
+            bb = j["build_rows"] * j["build_bytes_per_row"] + j["table_capacity"] * 17.0   # key columns read + table and filter written
+            kernels.append(dict(roofline("qk_join_scatter + k_join_region_build", j["build_ms"], bb, None, "not profiled per launch",
+                                         rows_per_launch=j["build_rows"], table_slots=j["table_capacity"]), operator=f"join {k + 1} build"))
+        for a in aggs:
+            kernels.append(dict(roofline(a["main_kernel_name"], a["main_kernel_ms"], a["rows_in"] * a["bytes_per_row_read"], None,
+                                         "not profiled per launch", kernel_bytes_per_row=a["bytes_per_row_read"], rows_per_launch=a["rows_in"]),
+                                operator="aggregate", groups=a["groups"]))
+        dominant = max(kernels, key=lambda k: k["kernel_ms"]) if kernels else None
+        survey = tot[0] * Q3_SURVEY_BYTES["customer"] + tot[1] * Q3_SURVEY_BYTES["orders"] + tot[2] * Q3_SURVEY_BYTES["lineitem"]
+        cfg = "configs[4]" if self.skew > 0 else "configs[3]"
+        par = ("one GPU" if not USE_DIST else f"broadcast build sides, local probes, merged partial groups x{self.world}" if strategy == "broadcast"
+               else f"both join sides repartitioned by key hash (all-to-all) x{self.world}")
+        rec = {"workload": f"{cfg} q3: TPC-H Q3 (q3.slt:1-24) SF{self.sf} customer|><|orders|><|lineitem + GROUP BY, HBM-resident"
+                           + (f", join keys re-drawn from Zipf(s={self.skew})" if self.skew > 0 else "")
+                           + (f", slice {self.slice_of[0]}/{self.slice_of[1]} of every table on one GPU" if self.slice_of else "") + f"; {par}",
+               "value": tot[2] * args.steps / elapsed, "unit": "lineitem rows/s", "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
+               "rows": {"customer": tot[0], "orders": tot[1], "lineitem": tot[2]}, "groups": tot[3], "strategy": strategy if USE_DIST else None,
+               "roofline": dominant, "kernels": kernels,
+               "survey_algorithmic_bytes": survey, "survey_algorithmic_GBps_of_wall_time": survey / (elapsed / args.steps) / 1e9 / self.world,
+               "device_ms_per_query": {"join": [j["total_device_ms"] for j in joins], "aggregate_kernel": [a["main_kernel_ms"] for a in aggs]},
+               "cpu_baseline": None}
+        if xg:
+            nq = args.steps + args.warmup   # queries since the counters were reset
+            secs = max(xg.get("seconds", 0.0), 1e-12)
+            rec["exchange"] = {"bytes_sent_per_query": xg.get("bytes_sent", 0) / nq, "bytes_received_per_query": xg.get("bytes_received", 0) / nq,
+                               "seconds_per_query": xg.get("seconds", 0.0) / nq, "exchanges_per_query": xg.get("exchanges", 0) / nq,
+                               "send_GBps": xg.get("bytes_sent", 0) / secs / 1e9, "xgmi_peak_GBps": XGMI_PEAK_GBS,
+                               "frac_of_xgmi": xg.get("bytes_sent", 0) / secs / 1e9 / XGMI_PEAK_GBS, "note": "rank 0 only"}
+        if with_cpu:
+            rec["cpu_baseline"] = cpu_q3(min(self.sf, args.cpu_q3_sf))
+        return rec, elapsed
+
+    def table_stats(self):
+        """BASELINE configs[4]: LDS hash-table occupancy of the final aggregate (one extra, untimed, instrumented execution)"""
+        os.environ["QHIP_AGG_STATS"] = "1"
+        try:
+            self.step()
+            st = self.ctx.last_stats()
+        finally:
+            os.environ.pop("QHIP_AGG_STATS", None)
+        return {"lds_table_slots_per_workgroup": st["lds_table_slots"], "lds_occupancy": st["lds_occupancy"], "lds_spilled": bool(st["lds_spilled"]),
+                "hbm_table_slots": st["table_capacity"], "hbm_table_load": st["hbm_table_load"], "groups": st["groups"], "workgroups": st["workgroups"]}
+
+
+class FilterBench:
+    """The standalone Filter operator (physical/plan/filter.rs:28-44): predicate -> ballot mask -> scan -> selection vector ->
+    every column gathered, over the 7-column lineitem table; a ~98 % and a ~1 % selective predicate."""
+
+    def __init__(self, args, ctx, table):
+        import pyarrow as pa
+        from qurious_amd import BinaryExpr, CastExpr, Column, Literal, Operator, ScalarValue
+        self.ctx, self.table, self.rows = ctx, table, sum(b.num_rows for b in table.data)
+        day = lambda s: CastExpr(Literal(ScalarValue.Utf8(s)), pa.date32())   # noqa: E731
+        self.plans = {"keeps ~98 %": q.Filter(q.Scan(synth.LINEITEM_SCHEMA, table, None, None), BinaryExpr(Column("l_shipdate", 0), Operator.LtEq, day("1998-09-02"))),
+                      "keeps ~1 %": q.Filter(q.Scan(synth.LINEITEM_SCHEMA, table, None, None), BinaryExpr(Column("l_shipdate", 0), Operator.Lt, day("1992-01-27")))}
+
+    def record(self, args, clock):
+        out = {}
+        for name, plan in self.plans.items():
+            elapsed = clock.run(lambda: plan.execute_device(), max(3, args.steps // 2), 2)
+            steps = max(3, args.steps // 2)
+            qplan.STATS_SINK = None
+            res = plan.execute_device()
+            st = self.ctx.last_stats()
+            kept = res.num_rows
+            # bytes the operator moves: the predicate column once, then per kept row every column's value read and written + the
+            # 4-byte selection index read once per column
+            dev = self.table.device_table()
+            per_row_all = sum(dev.column_bytes(c) for c in range(dev.num_columns)) / max(1, self.rows)
+            moved = self.rows * 4 + self.rows / 8 * 2 + kept * 4 + kept * (2 * per_row_all + 4 * dev.num_columns)
+            out[name] = {"rows_in": self.rows, "rows_out": kept, "ms_per_call": elapsed / steps * 1e3, "rows_per_s": self.rows * steps / elapsed,
+                         "device_ms": st["total_device_ms"],
+                         "roofline": roofline("qk_pred_mask + scan + k_select_indices + k_gather_*", st["total_device_ms"], moved, None,
+                                              "not profiled per launch", bytes_are="read + written")}
+        return {"workload": f"standalone Filter (filter.rs:28-44) over {self.rows} lineitem rows x 7 columns, HBM-resident", "cases": out}
+
+
+# ---------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (configs[1]: 100M)")
+    ap.add_argument("--workload", default="metric", choices=["metric", "q1_mini", "q1_full", "q3", "filter"],
+                    help="metric (default): a step = Q1 at SF10 + Q3 at SF10; the others run one configuration as the step")
+    ap.add_argument("--rows", type=int, default=0, help="lineitem rows of the q1_* / filter workloads (whole job; default: 100 M for q1_mini, SF10's for q1_full)")
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
-    ap.add_argument("--workload", default="q1_mini", choices=["q1_mini", "q1_full", "q3"])
-    ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of the q3 workload (whole job, sliced over the ranks)")
+    ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of Q3 (whole job, sliced over the ranks)")
     ap.add_argument("--strategy", default="broadcast", choices=["broadcast", "repartition"],
-                    help="q3 on several GPUs: all-gather the small build sides (default) or repartition both sides of every join by key")
-    ap.add_argument("--skew", type=float, default=0.0, help="q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
-    ap.add_argument("--cpu-sample-rows", type=int, default=64 << 20, help="rows of the workload timed through the CPU oracle")
+                    help="Q3 on several GPUs: all-gather the small build sides (default) or repartition both sides of every join by key")
+    ap.add_argument("--skew", type=float, default=0.0, help="Q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
+    ap.add_argument("--slice", default="", help="Q3 on ONE GPU over rank R's 1/N slice of every table, as R/N (configs[4]: --sf 100 --skew 1.1 --slice 0/8)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=16 << 20, help="rows of a q1_* workload timed through the CPU oracle (per run)")
+    ap.add_argument("--cpu-q3-sf", type=float, default=2.0, help="scale factor of the Q3 sample timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU Q1 / Q3 measurements")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the q1_mini and Filter records")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -246,151 +463,110 @@ def main():
     # with ONE rank — the rehearsal of the N > 1 launch that fits a one-GPU box (tests/test_gpu_q3.py runs it)
     global USE_DIST
     USE_DIST = world > 1 or os.environ.get("QHIP_BENCH_FORCE_DIST") == "1"
+    rccl = None
     if USE_DIST:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-
-    def barrier():
-        if USE_DIST:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    log("torch imported")
-    if args.workload == "q3":
-        return bench_q3(args, ctx, rank, world, barrier, dist, torch)
-    # ---- synthetic input, resident in HBM before the timed region
-    t0 = time.time()
-    table = gen_table(rank * args.rows, args.rows, args.batch_rows)
-    t_gen = time.time() - t0
-    log(f"generated {args.rows} rows in {t_gen:.1f}s")
-    t0 = time.time()
-    dev = table.device_table()
-    t_upload = time.time() - t0
-    log(f"uploaded in {t_upload:.1f}s")
-    resident = sum(dev.column_bytes(c) for c in range(dev.num_columns))
-    plan = getattr(queries, args.workload)(table)
-
-    for _ in range(args.warmup):
-        plan.execute_device()
-        log(f"warmup step: kernel {ctx.last_stats()['main_kernel_ms']:.3f} ms")
-    barrier()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.execute_device()
-        kernel_ms.append(ctx.last_stats()["main_kernel_ms"])
-    ctx.synchronize()   # the result table of the last step is ordered on libqhip's stream
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if USE_DIST:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    stats = ctx.last_stats()
-    log(f"timed {args.steps} steps in {elapsed:.3f}s")
-
-    # ---- verification of the whole-job result (outside the timed region)
-    result = plan.execute()
-    partial = result_key(result)
-    if USE_DIST:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, partial)
-    else:
-        gathered = [partial]
-
-    if rank != 0:
-        dist.destroy_process_group()
-        return
-
-    merged = {}
-    for part in gathered:
-        for row in part:
-            nk = len(plan.group_exprs)
-            k = row[:nk]
-            if k not in merged:
-                merged[k] = list(row[nk:])
-            elif args.workload == "q1_mini":
-                merged[k] = [a + b for a, b in zip(merged[k], row[nk:])]
-
-    total_rows = args.rows * world
-    value = total_rows * args.steps / elapsed
-    mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    # SURVEY §8d's algorithmic bytes per row for the Arrow layout as uploaded — unless the kernel reads FEWER bytes (it
-    # skips the offsets of a Utf8 column whose every value is 1 byte long): the roofline is computed from what is read
-    bpr = min(ALGO_BYTES_PER_ROW[args.workload], stats.get("bytes_per_row_read") or ALGO_BYTES_PER_ROW[args.workload])
-    achieved = args.rows * bpr / (mean_kernel_ms * 1e-3) / 1e9
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(prof):
         try:
-            with open(prof) as f:
-                traffic = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
-            traffic = None
-
-    cpu_baseline = None
-    if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run item (rank 0 at N = 1 only)
-        from oracle import qoracle
-        n = min(args.cpu_sample_rows, args.rows)
-        sample = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, table.data[: max(1, n // args.batch_rows)])
-        cplan = getattr(queries, args.workload)(sample)
-        log(f"cpu baseline: oracle over {sum(b.num_rows for b in sample.data)} rows ...")
-        cres, cdt, crows = qoracle.scan_filter_aggregate_timed(cplan)
-        log(f"cpu baseline: {crows / cdt / 1e6:.2f} Mrows/s ({cdt:.1f}s)")
-        # same rows through the HIP path must agree bit-exactly with the oracle
-        assert result_key([cres]) == result_key(cplan.execute()), "HIP result differs from the CPU oracle on the baseline sample"
-        all_cores = None
-        try:   # context only: the same restatement on row ranges in parallel — NOT the reference, whose executor has no parallelism
-            all_cores = cpu_all_cores(args.workload, sample.data, min(16, os.cpu_count() or 1))
-            log(f"cpu baseline, {all_cores['threads']} threads (not the reference): {all_cores['value'] / 1e6:.1f} Mrows/s")
-        except Exception as e:
-            log(f"all-cores CPU figure not measured: {e}")
-        cpu_baseline = {"value": crows / cdt, "unit": "rows/s", "cores": 1, "kind": "port", "all_cores_context": all_cores,
-                        "sample": f"{crows} rows ({len(sample.data)} batches of {args.batch_rows}) of the same workload through "
-                                  f"oracle/qoracle.c qo_scan_filter_aggregate, 1 of {os.cpu_count()} host cores "
-                                  "(the reference executor is single-threaded)",
-                        "seconds": cdt}
-
-    stream_ceiling = None
-    if rank == 0:
-        try:
-            stream_ceiling = ctx.measure_stream_read(4 << 30, 5)
-        except Exception as e:   # a measurement aid only: never fail the bench line over it
-            log(f"stream-read ceiling not measured: {e}")
-    line = {
-        "metric": "rows/s on TPC-H Q1 scan+agg and Q3 hash-join, SF10, 1/2/4/8 MI355X",
-        "value": value,
-        "unit": "rows/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "i128",
-        "data": "synthetic",
-        "config": {"workload": f"configs[1] {args.workload}: filter+GROUP BY, {args.rows} synthetic lineitem rows per GPU in "
-                               f"{args.batch_rows}-row Arrow batches, HBM-resident",
-                   "rows_per_gpu": args.rows, "batch_rows": args.batch_rows, "groups": len(merged),
-                   "resident_bytes_per_gpu": resident, "parallelism": f"replicated-shards x{world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": stats["main_kernel_name"], "kernel_ms": mean_kernel_ms,
-                     "algorithmic_bytes_per_row": ALGO_BYTES_PER_ROW[args.workload], "kernel_bytes_per_row": bpr,
-                     # the achievable ceiling measured with a plain 16 B/lane streaming-read kernel, same run
-                     "stream_read_GBps": stream_ceiling,
-                     "frac_of_stream_read": (achieved / stream_ceiling) if stream_ceiling else None},
-        "cpu_baseline": cpu_baseline,
-        "device": ctx.device_name(),
-        "setup_s": {"generate": t_gen, "upload_h2d": t_upload, "h2d_GBps": resident / t_upload / 1e9},
-    }
-    if world == 1 and args.workload == "q1_mini" and not args.no_extra:
-        # the other two single-GPU configurations of BASELINE.json, reported beside the headline (not part of `value`)
-        line["extra"] = extra_single_gpu(args, ctx, table)
-    print(json.dumps(line))
+            rccl = None
+    clock = Clock(ctx, torch, dist)
+    with_cpu = not args.no_cpu_baseline and world == 1 and not USE_DIST
+    log("torch imported")
+    line = {"metric": METRIC, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "vs_baseline": None, "dtype": "i128", "data": "synthetic", "device": ctx.device_name()}
     if USE_DIST:
-        dist.destroy_process_group()
+        line["distributed"] = {"world_size": dist.get_world_size(), "backend": "nccl (RCCL)", "rccl_version": rccl}
+
+    def finish():
+        if rank == 0:
+            print(json.dumps(line))
+        if USE_DIST:
+            dist.destroy_process_group()
+
+    # ---- single-configuration modes (profiling / sweeps): the chosen configuration is the step
+    if args.workload in ("q1_mini", "q1_full"):
+        rows = args.rows or (100_000_000 if args.workload == "q1_mini" else SF10_LINEITEM_ROWS)
+        w = Q1(args, ctx, args.workload, rows, rank, world)
+        rec, elapsed = w.record(args, clock, with_cpu)
+        line.update(value=rec["value"], ms_per_step=rec["ms_per_step"], scaling="strong", roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"],
+                    config={"workload": rec["workload"], "rows": rows, "batch_rows": args.batch_rows, "groups": rec["groups"],
+                            "parallelism": f"row-range slices x{world}, partial groups merged"},
+                    setup_s={"generate": w.t_gen, "upload_h2d": w.t_upload, "h2d_GBps": w.resident / max(w.t_upload, 1e-9) / 1e9})
+        return finish()
+    if args.workload == "filter":
+        rows = args.rows or SF10_LINEITEM_ROWS
+        w = Q1(args, ctx, "q1_full", rows, rank, world)
+        rec = FilterBench(args, ctx, w.table).record(args, clock)
+        first = next(iter(rec["cases"].values()))
+        line.update(value=first["rows_per_s"], ms_per_step=first["ms_per_call"], scaling="strong", roofline=first["roofline"], cpu_baseline=None,
+                    config={"workload": rec["workload"]}, records={"filter_lineitem": rec})
+        return finish()
+    if args.workload == "q3":
+        slice_of = tuple(int(x) for x in args.slice.split("/")) if args.slice else None
+        w = Q3(args, ctx, rank, world, args.strategy, slice_of)
+        rec, elapsed = w.record(args, clock, torch, dist, with_cpu)
+        line.update(value=rec["value"], ms_per_step=rec["ms_per_step"], scaling="strong", roofline=rec["roofline"], cpu_baseline=rec["cpu_baseline"],
+                    config={"workload": rec["workload"], "rows": rec["rows"], "groups": rec["groups"]}, records={"q3": rec})
+        if args.skew > 0 or os.environ.get("QHIP_AGG_STATS"):
+            line["aggregate_table"] = w.table_stats()
+        if "exchange" in rec:
+            line["exchange"] = rec["exchange"]
+        return finish()
+
+    # ---- the metric: a step = Q1 at SF10 (configs[2]) + Q3 at SF10 (configs[3])
+    q1 = Q1(args, ctx, "q1_full", SF10_LINEITEM_ROWS, rank, world)
+    args.sf, args.skew = 10.0, 0.0
+    q3 = Q3(args, ctx, rank, world, args.strategy)
+
+    def step():
+        q1.step()
+        q3.step()
+
+    elapsed = clock.run(step, args.steps, args.warmup)
+    tot = q3.totals(torch, dist)
+    rows_step = SF10_LINEITEM_ROWS + tot[2]
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    records = {}
+    records["q1_sf10"], _ = q1.record(args, clock, with_cpu)
+    records["q3_sf10"], _ = q3.record(args, clock, torch, dist, with_cpu)
+    if USE_DIST:
+        other = "repartition" if args.strategy == "broadcast" else "broadcast"
+        records[f"q3_sf10_{other}"], _ = q3.record(args, clock, torch, dist, False, strategy=other)
+    cpu = None
+    if with_cpu:
+        c1, c3 = records["q1_sf10"]["cpu_baseline"], records["q3_sf10"]["cpu_baseline"]
+        # the step on the CPU: SF10's rows of each query at the rate measured on its sample
+        secs = SF10_LINEITEM_ROWS / c1["value"] + tot[2] / c3["value"]
+        cpu = {"value": rows_step / secs, "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": "the step's two queries at the rates of their bounded samples (records.q1_sf10.cpu_baseline, records.q3_sf10.cpu_baseline: "
+                         f"oracle/qoracle.c, 1 of {os.cpu_count()} host cores, 1 warm-up + median of 5 each)",
+               "parts": {"q1_sf10_rows_per_s": c1["value"], "q3_sf10_lineitem_rows_per_s": c3["value"]}}
+    line.update(value=rows_step * args.steps / elapsed, ms_per_step=elapsed / args.steps * 1e3, scaling="strong",
+                config={"workload": "configs[2] TPC-H Q1 (aggregate list, q1.slt:5-12) over SF10's 59986052 lineitem rows + configs[3] TPC-H Q3 "
+                                    "(q3.slt:1-24) at SF10, one pass of each per step; value = lineitem rows scanned by both / wall time; "
+                                    "synthetic Arrow tables (SURVEY §8d recipes), HBM-resident",
+                        "rows_per_step": {"q1_lineitem": SF10_LINEITEM_ROWS, "q3_customer": tot[0], "q3_orders": tot[1], "q3_lineitem": tot[2]},
+                        "batch_rows": args.batch_rows, "q1_groups": records["q1_sf10"]["groups"], "q3_groups": tot[3],
+                        "resident_bytes_per_gpu": q1.resident,
+                        "parallelism": "one GPU" if not USE_DIST else f"every table sliced over {world} ranks; Q1 partial groups merged by all-gather, "
+                                                                         f"Q3 joins: {args.strategy}"},
+                roofline=records["q1_sf10"]["roofline"], cpu_baseline=cpu, records=records,
+                setup_s={"q1_generate": q1.t_gen, "q1_upload_h2d": q1.t_upload, "h2d_GBps": q1.resident / max(q1.t_upload, 1e-9) / 1e9})
+    if "exchange" in records["q3_sf10"]:
+        line["exchange"] = records["q3_sf10"]["exchange"]
+    if world == 1 and not USE_DIST and not args.no_extra:
+        try:
+            records["filter_lineitem"] = FilterBench(args, ctx, q1.table).record(args, clock)
+            mini = Q1(args, ctx, "q1_mini", 100_000_000, rank, world)
+            records["q1_mini"], _ = mini.record(args, clock, with_cpu)
+            if rank == 0:
+                records["q1_mini"]["roofline"]["stream_read_GBps"] = ctx.measure_stream_read(4 << 30, 5)
+        except Exception as e:   # the headline line must not depend on the extras
+            records["extras_error"] = f"{type(e).__name__}: {e}"
+    finish()
 
 
 if __name__ == "__main__":

@@ -175,7 +175,12 @@ typedef struct qhip_exec_stats {
   int32_t workgroups;        /* grid size of the dominant kernel */
   double bytes_per_row_read; /* aggregate: bytes of column data the fused kernel reads per input row (value, offset and data
                               * buffers of the columns its expressions reference; the offsets of a Utf8 column whose every
-                              * value is 1 byte long are not read) — what a roofline figure must be computed from */
+                              * value is 1 byte long are not read) — what a roofline figure must be computed from.
+                              * Hash join: bytes the probe kernel reads per PROBE row (key + fused-filter columns). */
+  double build_ms;           /* hash join: key evaluation + table build, first launch .. probe kernel (main_kernel_ms is the
+                              * probe kernel alone, total_device_ms the whole call incl. pair emission) */
+  int64_t build_rows;        /* hash join: rows of the build side */
+  double build_bytes_per_row;/* hash join: bytes of build-side columns its key / fused-filter expressions read per row */
 } qhip_exec_stats;
 
 /* ---------------------------------------------------------------- context */

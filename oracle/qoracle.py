@@ -545,7 +545,10 @@ def _sort(node: "P.Sort") -> pa.RecordBatch:
 
 
 def _limit(batches: List[pa.RecordBatch], fetch: Optional[int], skip: int) -> List[pa.RecordBatch]:
-    """limit.rs:27-58, including the empty slice it emits when the window closes exactly on a batch boundary"""
+    """limit.rs:27-58, including the empty slice it emits when the window closes exactly on a batch boundary — and its
+    OFFSET quirk: `skip` is only ever decremented by whole skipped batches (limit.rs:39-42), never cleared after the batch
+    it was applied to (limit.rs:44), so with skip > 0 over several batches every LATER batch loses its first `skip` rows too
+    (or is dropped whole, shrinking `skip`, when it has no more rows than that). Restated as written, not as SQL means it."""
     max_fetch = fetch if fetch is not None else (1 << 64) - 1
     results, fetched = [], 0
     for batch in batches:
@@ -554,7 +557,6 @@ def _limit(batches: List[pa.RecordBatch], fetch: Optional[int], skip: int) -> Li
             skip -= rows
             continue
         new_batch = batch.slice(skip, rows - skip)
-        skip = 0
         remaining = max_fetch - fetched
         if new_batch.num_rows <= remaining:
             results.append(new_batch)

@@ -77,7 +77,7 @@ class qhip_exec_stats(C.Structure):
         ("rows_in", C.c_int64), ("rows_out", C.c_int64), ("groups", C.c_int64), ("table_capacity", C.c_int64),
         ("retries", C.c_int32), ("lds_table_slots", C.c_int32), ("main_kernel_name", C.c_char * 64),
         ("lds_occupancy", C.c_double), ("hbm_table_load", C.c_double), ("lds_spilled", C.c_int32), ("workgroups", C.c_int32),
-        ("bytes_per_row_read", C.c_double),
+        ("bytes_per_row_read", C.c_double), ("build_ms", C.c_double), ("build_rows", C.c_int64), ("build_bytes_per_row", C.c_double),
     ]
 
 

@@ -161,7 +161,7 @@ struct Module;  // jit.cpp
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // call begin / end, dominant kernel begin / end
   std::string last_error;
   std::string device_name;
   int num_cus = 256;

@@ -280,6 +280,7 @@ int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
     float ms = 0;
     if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.total_device_ms = ms;
     if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.main_kernel_ms = ms;
+    if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->stats.build_ms = ms;   // (hash join)
     else if (c->stats_timing_pending == 1) c->stats.main_kernel_ms = c->stats.total_device_ms;
     c->stats_timing_pending = 0;
   }

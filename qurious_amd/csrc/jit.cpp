@@ -42,12 +42,22 @@ static std::string default_cache_dir() {
   return "";
 }
 
+static const char* const kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+
+// what a cached code object depends on besides its source: the compiler (hiprtc version) and the options
+static std::string toolchain_tag() {
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  std::string t = "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+  for (const char* o : kCompileOptions) { t += ' '; t += o; }
+  return t;
+}
+
 std::vector<char> compile_to_code_object(const std::string& full_source, std::string* log_out) {
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, full_source.c_str(), "qhip_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     fail(QHIP_HIP_ERROR, "hiprtcCreateProgram failed");
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  hiprtcResult r = hiprtcCompileProgram(prog, 4, const_cast<const char**>(kCompileOptions));
   size_t ls = 0;
   hiprtcGetProgramLogSize(prog, &ls);
   std::string log(ls, '\0');
@@ -69,8 +79,19 @@ std::string full_source_for(const std::string& policy_source) { return std::stri
 
 std::string cache_path_for(const std::string& dir, const std::string& full_source) {
   char name[64];
-  snprintf(name, sizeof name, "/qk_%016llx_%zu.hsaco", (unsigned long long)fnv1a(full_source), full_source.size());
+  snprintf(name, sizeof name, "/qk_%016llx_%zu.hsaco", (unsigned long long)fnv1a(full_source, fnv1a(toolchain_tag())), full_source.size());
   return dir + name;
+}
+
+// tmp file + rename: another process never reads a partial code object
+static void write_atomically(const std::string& dir, const std::string& path, const std::vector<char>& code) {
+  (void)mkdir(dir.c_str(), 0755);
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  std::ofstream f(tmp, std::ios::binary);
+  if (!f) return;
+  f.write(code.data(), (std::streamsize)code.size());
+  f.close();
+  if (rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
 }
 
 std::shared_ptr<Module> get_module(Ctx* ctx, const std::string& policy_source, const std::string& kernel_name) {
@@ -89,22 +110,22 @@ std::shared_ptr<Module> get_module(Ctx* ctx, const std::string& policy_source, c
     std::ifstream f(path, std::ios::binary);
     if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
   }
-  if (code.empty()) {
-    code = compile_to_code_object(src, nullptr);
-    if (!path.empty()) {
-      (void)mkdir(dir.c_str(), 0755);
-      std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-      std::ofstream f(tmp, std::ios::binary);
-      if (f) {
-        f.write(code.data(), (std::streamsize)code.size());
-        f.close();
-        (void)rename(tmp.c_str(), path.c_str());
-      }
-    }
-  }
+  const bool from_cache = !code.empty();
   auto m = std::make_shared<Module>();
-  QHIP_HIP_CHECK(hipModuleLoadData(&m->mod, code.data()));
-  QHIP_HIP_CHECK(hipModuleGetFunction(&m->fn, m->mod, kernel_name.c_str()));
+  auto load = [&]() {
+    return hipModuleLoadData(&m->mod, code.data()) == hipSuccess && hipModuleGetFunction(&m->fn, m->mod, kernel_name.c_str()) == hipSuccess;
+  };
+  if (!from_cache || !load()) {
+    // nothing cached — or a cached object that does not load (truncated file, another ROCm): drop it and compile once
+    if (from_cache) {
+      if (m->mod) { (void)hipModuleUnload(m->mod); m->mod = nullptr; }
+      (void)unlink(path.c_str());
+    }
+    code = compile_to_code_object(src, nullptr);
+    if (!path.empty()) write_atomically(dir, path, code);
+    QHIP_HIP_CHECK(hipModuleLoadData(&m->mod, code.data()));
+    QHIP_HIP_CHECK(hipModuleGetFunction(&m->fn, m->mod, kernel_name.c_str()));
+  }
   // a long-lived context that keeps seeing new plans does not keep every code object loaded for ever: beyond 512 modules
   // the in-memory cache starts over (callers hold shared_ptrs to what they are running; the disk cache still has the rest)
   if (ctx->modules.size() >= 512) ctx->modules.clear();
@@ -123,11 +144,7 @@ extern "C" int qhip_jit_compile_to_cache(const char* policy_source, const char* 
     std::string l;
     std::vector<char> code = qhip::compile_to_code_object(src, &l);
     if (log && log_len) snprintf(log, log_len, "%s", l.c_str());
-    if (cache_dir && *cache_dir) {
-      (void)mkdir(cache_dir, 0755);
-      std::ofstream f(qhip::cache_path_for(cache_dir, src), std::ios::binary);
-      f.write(code.data(), (std::streamsize)code.size());
-    }
+    if (cache_dir && *cache_dir) qhip::write_atomically(cache_dir, qhip::cache_path_for(cache_dir, src), code);
     return QHIP_OK;
   } catch (const qhip::Error& e) {
     if (log && log_len) snprintf(log, log_len, "%s", e.what());

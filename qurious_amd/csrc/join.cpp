@@ -218,7 +218,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // probe-row order. LeftSemi / LeftAnti without a residual filter only need the visited bits: pass 1 sets them.
   DevBuf ent_slot((P + 1) * 4), ent_row((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
   uint64_t M = 0;
-  hipEventRecord(ctx->ev[2], s);
+  bool probe_timed = false;
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
   if (P > 0) {
@@ -247,7 +247,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     // earlier ones finish, so the tail is a fraction of one workgroup's share
     const uint64_t tpw = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::max<uint64_t>(std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 4), (ntiles + 4 * tpw - 1) / (4 * tpw)));
+    hipEventRecord(ctx->ev[2], s);
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    hipEventRecord(ctx->ev[3], s);
+    probe_timed = true;
     st[QS_WORDS] = 0;
     if (want_pairs) {
       exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, total.as<uint32_t>(), s);
@@ -282,7 +285,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
     check_build_status();   // (duplicates do not matter without probe rows)
   }
-  hipEventRecord(ctx->ev[3], s);
+  if (!probe_timed) { hipEventRecord(ctx->ev[2], s); hipEventRecord(ctx->ev[3], s); }
 
   // ---- residual JoinFilter (join/mod.rs:125-154): evaluate over an intermediate batch of the filter's columns, keep true rows
   bool filtered = false;
@@ -423,7 +426,23 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   ctx->stats.rows_out = (int64_t)total_rows;
   ctx->stats.groups = (int64_t)M;
   ctx->stats.table_capacity = nslots;
-  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "k_join_probe_count+write");
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_join_probe");
+  // bytes of column data the probe kernel / the build's key evaluation read per row (roofline figures)
+  auto bytes_per_row = [&](const qhip_table* t, const KernelBindings& b) {
+    double sum = 0;
+    for (int c : b.cols) {
+      const DevColumn& dc = t->cols[(size_t)c];
+      const int w = dtype_width(dc.type);
+      if (w > 0) sum += w;
+      else if (dc.type.id == QHIP_BOOL) sum += 0.125;
+      else if (dc.type.id == QHIP_UTF8) sum += 4.0 + (t->num_rows > 0 ? (double)dc.data_bytes / (double)t->num_rows : 0.0);
+      if (dc.null_count > 0) sum += 0.125;
+    }
+    return sum;
+  };
+  ctx->stats.bytes_per_row_read = bytes_per_row(R, rkp.bind);
+  ctx->stats.build_bytes_per_row = bytes_per_row(L, lkp.bind);
+  ctx->stats.build_rows = (int64_t)B;
   return out.release();
 }
 

@@ -142,26 +142,28 @@ qhip_table* limit_table(Ctx* ctx, const qhip_table* in, int64_t skip, int64_t fe
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats_timing_pending = 0;
   if (skip < 0) fail(QHIP_INVALID_ARGUMENT, "qhip_limit_execute: negative skip");
-  // limit.rs:31-55, batch by batch
+  // limit.rs:31-55, batch by batch — including its OFFSET quirk: `skip` is decremented by whole skipped batches only
+  // (limit.rs:39-42) and never cleared after the batch it was applied to (limit.rs:44), so every later batch loses its
+  // first `skip` rows too (or is dropped whole, shrinking `skip`). The output is therefore a list of row segments.
   const uint64_t max_fetch = fetch < 0 ? ~0ULL : (uint64_t)fetch;
   uint64_t fetched = 0, to_skip = (uint64_t)skip;
-  int64_t first_row = -1;
+  struct Seg { int64_t first; uint64_t rows; };
+  std::vector<Seg> segs;
   std::vector<int64_t> offs = {0};
   for (int64_t b = 0; b < in->num_batches(); ++b) {
     const uint64_t rows = (uint64_t)(in->offsets()[(size_t)b + 1] - in->offsets()[(size_t)b]);
     if (rows <= to_skip) { to_skip -= rows; continue; }
     const uint64_t new_rows = rows - to_skip;
-    if (first_row < 0) first_row = in->offsets()[(size_t)b] + (int64_t)to_skip;
-    to_skip = 0;
+    const int64_t first = in->offsets()[(size_t)b] + (int64_t)to_skip;
     const uint64_t remaining = max_fetch - fetched;
-    if (new_rows <= remaining) {
-      fetched += new_rows;
-      offs.push_back((int64_t)fetched);
-    } else {
-      fetched += remaining;
-      offs.push_back((int64_t)fetched);   // possibly an empty batch (remaining == 0), like the reference's slice(0, 0)
-      break;
+    const uint64_t take = new_rows <= remaining ? new_rows : remaining;
+    if (take) {
+      if (!segs.empty() && segs.back().first + (int64_t)segs.back().rows == first) segs.back().rows += take;
+      else segs.push_back({first, take});
     }
+    fetched += take;
+    offs.push_back((int64_t)fetched);   // possibly an empty batch (remaining == 0), like the reference's slice(0, 0)
+    if (new_rows > remaining) break;
   }
   std::unique_ptr<qhip_table> out(new qhip_table());
   out->ctx = ctx;
@@ -169,11 +171,15 @@ qhip_table* limit_table(Ctx* ctx, const qhip_table* in, int64_t skip, int64_t fe
   out->nullable = in->nullable;
   out->num_rows = (int64_t)fetched;
   out->batch_offsets = offs;
-  if (first_row <= 0 && (int64_t)fetched == in->num_rows) {
+  if ((int64_t)fetched == in->num_rows) {
     out->cols = in->cols;   // the whole table: column buffers are shared
   } else {
     auto idx = std::make_shared<DevBuf>((fetched + 1) * 4);
-    launch_iota_u32(idx->as<uint32_t>(), fetched, ctx->stream, (uint32_t)std::max<int64_t>(first_row, 0));
+    uint64_t at = 0;
+    for (const Seg& sg : segs) {
+      launch_iota_u32(idx->as<uint32_t>() + at, sg.rows, ctx->stream, (uint32_t)sg.first);
+      at += sg.rows;
+    }
     defer_gather(ctx, in->cols, idx, fetched, false, out->cols);
   }
   ctx->stats.rows_in = in->num_rows;

@@ -117,6 +117,17 @@ class Scan(PhysicalPlan):
         return super().execute()
 
 
+# Instrumented executions (bench.py's per-kernel roofline records): while a list is installed here every device operator
+# appends (operator label, qhip_exec_stats of the call). Reading the stats waits for the operator's events, so this is for
+# separate, untimed passes only.
+STATS_SINK: Optional[list] = None
+
+
+def _record_stats(ctx, label: str):
+    if STATS_SINK is not None:
+        STATS_SINK.append((label, ctx.last_stats()))
+
+
 def _filter_device(table: DeviceTable, predicate: Optional[PhysicalExpr], projection: Optional[List[int]]) -> DeviceTable:
     ctx = table.ctx
     ea = ExprArray()
@@ -174,6 +185,7 @@ def _aggregate_device(table: DeviceTable, predicate: Optional[PhysicalExpr], gro
     arr, n, pred, groups, n_groups, aggs, n_aggs, cnames, _keep = lowered or _lower_aggregate(predicate, group_exprs, aggregate_exprs, names)
     out = C.c_void_p()
     ctx.check(ctx.lib.qhip_hash_aggregate_execute(ctx.handle, table.handle, arr, n, pred, groups, n_groups, aggs, n_aggs, cnames, C.byref(out)))
+    _record_stats(ctx, "aggregate")
     return DeviceTable(ctx, out)
 
 
@@ -495,4 +507,5 @@ class HashJoinExec(PhysicalPlan):
         out = C.c_void_p()
         ctx.check(ctx.lib.qhip_hash_join_execute(ctx.handle, lt.handle, rt.handle, int(self.join_type), la, ln, ra, rn, on_l, on_r, n_on,
                                                  fa, fn, froot, fsides, fcols, n_fcols, lp, rp, C.byref(out)))
+        _record_stats(ctx, "hash_join")
         return DeviceTable(ctx, out)

@@ -44,6 +44,16 @@ def q1_full(table: MemoryTable) -> HashAggregate:
     return HashAggregate(schema, scan, [Column("l_returnflag", 1), Column("l_linestatus", 2)], aggs)
 
 
+def q1_partial(table: MemoryTable) -> HashAggregate:
+    """Q1 over ONE RANK's slice of lineitem, as mergeable partials: the four SUMs of q1_full plus SUM(l_discount) and COUNT —
+    AVG(x) of the whole table is SUM of the ranks' sums / SUM of their counts (avg.rs:91-116 applied after the merge)."""
+    full = q1_full(table)
+    aggs = full.aggregate_exprs[:4] + [SumAggregateExpr(Column("l_discount", 5), DEC), full.aggregate_exprs[7]]
+    names = ["l_returnflag", "l_linestatus", "sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "sum_disc", "count_order"]
+    types = [pa.string(), pa.string(), DEC, DEC, pa.decimal128(38, 4), pa.decimal128(38, 6), DEC, pa.int64()]
+    return HashAggregate(pa.schema([pa.field(n, t) for n, t in zip(names, types)]), full.input, full.group_exprs, aggs)
+
+
 def q3(customer, orders, lineitem, join_cls=None, agg_cls=None):
     """configs[3]: TPC-H Q3 (tests/tpch/q3.slt:2-24) up to the HashAggregate output, in the plan shape the reference's
     optimizer produces: filters pushed into the scans, build side = left child, no side swapping.

@@ -193,15 +193,26 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
                        env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and r.stdout.count("equal to the single-process plan") == 2, r.stdout[-2000:] + r.stderr[-4000:]
     env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    for extra in (["--rows", "3000000", "--no-extra", "--no-cpu-baseline"], ["--workload", "q3", "--sf", "0.2", "--no-cpu-baseline"],
-                  ["--workload", "q3", "--sf", "0.2", "--strategy", "repartition", "--no-cpu-baseline"]):
+    # (1) exactly the command the driver's scaling run issues per rank (default workload: the metric's step = Q1 at SF10 +
+    # Q3 at SF10), with the multi-rank branch forced on: Q1 partial groups merged through an all-gather, Q3 through both
+    # exchange strategies; (2) single-configuration modes at small sizes
+    for extra in ([], ["--workload", "q1_full", "--rows", "3000000"], ["--workload", "q3", "--sf", "0.2"],
+                  ["--workload", "q3", "--sf", "0.2", "--strategy", "repartition"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"] + extra,
-                           env=env, capture_output=True, text=True, timeout=600)
+                           env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-4000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
-        assert line["value"] > 0 and line["n_gpus"] == 1
+        assert line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "strong"
+        assert line["distributed"]["world_size"] == 1 and line["cpu_baseline"] is None   # (the CPU baseline is an N = 1 item)
+        if not extra:
+            rec = line["records"]
+            assert set(rec) >= {"q1_sf10", "q3_sf10", "q3_sf10_repartition"} and "configs[2]" in line["config"]["workload"]
+            assert rec["q1_sf10"]["rows"] == 59986052 and rec["q1_sf10"]["groups"] == 4
+            assert rec["q3_sf10"]["groups"] == rec["q3_sf10_repartition"]["groups"] > 100000
+            assert rec["q3_sf10"]["exchange"]["exchanges_per_query"] > 0 and line["exchange"]["bytes_sent_per_query"] >= 0
+            assert line["roofline"]["kernel"] == "qk_filter_agg" and 0 < line["roofline"]["frac"] < 1
         if "q3" in extra:
-            assert line["exchange"]["exchanges"] > 0
+            assert line["exchange"]["exchanges_per_query"] > 0
 
 
 def test_repartitioned_join_equals_plain_join(ctx, oracle):

@@ -92,10 +92,15 @@ def test_oracle_limit_batch_structure():
     assert sizes(q.Limit(scan, None, 0)) == [2, 3, 1]
     assert sizes(q.Limit(scan, 5, 0)) == [2, 3, 0]
     assert sizes(q.Limit(scan, 3, 2)) == [3, 0]
-    assert sizes(q.Limit(scan, 2, 3)) == [2, 0]
+    assert sizes(q.Limit(scan, 2, 3)) == [2]      # (the one-row third batch is dropped by the skip = 1 that was never cleared)
     assert sizes(q.Limit(scan, 0, 0)) == [0]
     assert sizes(q.Limit(scan, None, 6)) == []
-    assert sizes(q.Limit(scan, 100, 4)) == [1, 1]
+    # limit.rs:39-44: `skip` is never cleared after the batch it was applied to — OFFSET 4 skips [1, 2], takes 3 and 4 off the
+    # second batch (leaving 5) and then, still holding skip = 2, drops the one-row third batch whole. (SQL would return 5, 6.)
+    assert sizes(q.Limit(scan, 100, 4)) == [1]
+    assert rows_of(qoracle.execute(q.Limit(scan, 100, 4))) == [(5,)]
+    wide = table_scan(schema, [b([1, 2, 3]), b([4, 5, 6, 7]), b([8, 9, 10])])
+    assert rows_of(qoracle.execute(q.Limit(wide, None, 1))) == [(2,), (3,), (5,), (6,), (7,), (9,), (10,)]   # every batch loses its first row
 
 
 def test_oracle_lexsort_null_and_float_order():
@@ -194,7 +199,7 @@ def test_gpu_sort_and_limit_edge_cases():
         for plan in (q.Sort(key, src), q.Sort([], src), q.Limit(src, 3, 0), q.Limit(src, None, 1)):
             _batches_equal(plan.execute(), qoracle.execute(plan))
     scan = table_scan(schema, [batch.slice(0, 100), batch.slice(100, 150), batch.slice(250, 50)])
-    for fetch, skip in ((None, 0), (250, 0), (150, 100), (10, 95), (0, 0), (None, 300), (1000, 120), (None, 299)):
+    for fetch, skip in ((None, 0), (250, 0), (150, 100), (10, 95), (0, 0), (None, 300), (1000, 120), (None, 299), (None, 30), (140, 30), (None, 60)):
         plan = q.Limit(scan, fetch, skip)
         _batches_equal(plan.execute(), qoracle.execute(plan))
     # ORDER BY ... LIMIT n OFFSET m the way the planner lowers it (top-N sort of skip + fetch rows, then the window)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""profiles/rNN_pmc_summary.json from what tools/pmc_passes.sh left under <dir> for the tags q1_mini, q1_full, q3
+(each tag = `bench.py --workload <tag>`): HBM bytes per launch of the workload's kernels,
+
+    hbm_bytes_per_launch = FETCH_SIZE (KB) x 1024 x 2 + WRITE_SIZE (KB) x 1024
+
+(gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, WRITE_SIZE is exact; separate --pmc passes — MI355X_MICROARCH.md,
+HBM / rocprofv3 PMC slots), next to the rows and bytes per row the kernel was launched on (from the bench line of the same
+pass), which is what bench.py checks before it quotes the figure as `roofline.traffic`.
+
+    python tools/make_pmc_summary.py <dir> <out.json> [round label]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def bench_line(src, tag):
+    for name in (f"bench_{tag}.json", f"pmc_{tag}_0.json"):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            return json.loads(open(p).read().strip().splitlines()[-1])
+    raise SystemExit(f"no bench line for {tag} under {src}")
+
+
+def main():
+    src, out_path = sys.argv[1], sys.argv[2]
+    label = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    summary = {}
+    for tag in ("q1_mini", "q1_full", "q3"):
+        pmc_json = os.path.join(src, f"{tag}_pmc.json")
+        if not os.path.exists(pmc_json):
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), src, tag, pmc_json], stdout=subprocess.DEVNULL)
+        pmc = load(pmc_json)["kernels"]
+        line = bench_line(src, tag)
+        wanted = []   # (kernel name, rows, bytes per row, operator)
+        if tag == "q3":
+            for k in line["records"]["q3"]["kernels"]:
+                if k["kernel"] in ("qk_join_probe", "qk_filter_agg"):
+                    wanted.append((k["kernel"], k["rows_per_launch"], k.get("kernel_bytes_per_row"), k.get("operator")))
+        else:
+            r = line["roofline"]
+            wanted.append((r["kernel"], r["rows_per_launch"], r["kernel_bytes_per_row"], tag))
+        kernels = []
+        for name in sorted(set(w[0] for w in wanted)):
+            have = sorted([v for v in pmc.values() if v["kernel"] == name and "FETCH_SIZE" in v], key=lambda v: v["grid_size"])
+            want = sorted([w for w in wanted if w[0] == name], key=lambda w: w[1])
+            # the profiled process also launches the kernel on small inputs (CPU-sample checks are off in these passes, but the
+            # aggregate of a join output is small): pair the LARGEST grids with the wanted launches, ascending
+            have = have[-len(want):]
+            for h, w in zip(have, want):
+                kernels.append({"kernel": name, "operator": w[3], "grid_size": h["grid_size"], "rows": w[1], "kernel_bytes_per_row": w[2],
+                                "bytes_read_by_construction": w[1] * w[2] if w[2] else None,
+                                "FETCH_SIZE_KB_raw": h["FETCH_SIZE"], "WRITE_SIZE_KB_raw": h.get("WRITE_SIZE"),
+                                "hbm_bytes_per_launch": h["hbm_bytes_per_launch"], "launches": h["launches_seen"],
+                                "mean_us_under_pmc": h["mean_us_under_pmc"],
+                                "traffic_over_bytes_read": (h["hbm_bytes_per_launch"] / (w[1] * w[2])) if w[2] else None})
+        summary[tag] = {"collected": label, "correction": "gfx950: FETCH_SIZE x 2 (128-byte requests tallied at 64 bytes), WRITE_SIZE exact; "
+                                                           "separate --pmc passes (MI355X_MICROARCH.md)",
+                        "command": f"tools/pmc_passes.sh <dir> {tag} --workload {tag} ... (rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py)",
+                        "kernels": kernels}
+    with open(out_path, "w") as f:
+        json.dump(summary, f, indent=1)
+        f.write("\n")
+    for tag, v in summary.items():
+        for k in v["kernels"]:
+            print(tag, k["operator"], k["kernel"], f"rows={k['rows']}", f"hbm={k['hbm_bytes_per_launch'] / 1e6:.1f} MB",
+                  f"ratio={k['traffic_over_bytes_read']:.3f}" if k["traffic_over_bytes_read"] else "", f"{k['mean_us_under_pmc']:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -19,8 +19,10 @@ GROUPS_=(
   "TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_UTCL1_REQUEST_sum"
   "GRBM_GUI_ACTIVE GRBM_COUNT"
 )
+# PMC_ONLY="0 1 4": only these groups (indices above); default: all
 i=0
 for g in "${GROUPS_[@]}"; do
+  if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then i=$((i+1)); continue; fi
   timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -o $TAG -- python3 bench.py "$@" > $OUT/pmc_${TAG}_$i.json 2> $OUT/pmc_${TAG}_$i.err
   echo "pmc pass $i ($g) exit $?"
   i=$((i+1))
