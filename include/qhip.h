@@ -314,6 +314,9 @@ int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int3
  * plan above the exchange never reads is neither gathered nor sent (the reference's join gathers every column,
  * utils/batch.rs:18-61; on one GPU the deferred gathers already avoid that). */
 int qhip_table_keep_columns(qhip_ctx* ctx, const qhip_table* t, const int32_t* keep, int32_t n_cols, qhip_table** out);
+/* Every `stride`-th row of `t` (rows 0, stride, 2 stride, ...) as a one-batch table of deferred gathers: the sample a
+ * repartitioned join counts its probe keys on to find heavy hitters before it decides where rows go. */
+int qhip_table_stride_sample(qhip_ctx* ctx, const qhip_table* t, int64_t stride, qhip_table** out);
 int qhip_table_pack(qhip_ctx* ctx, const qhip_table* t, void* device_dst, int64_t dst_bytes);
 int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols,
                              const int64_t* metas /* n x (2 + 2 * n_cols) */, const void* const* device_images,

@@ -233,7 +233,7 @@ int qhip_ctx_create(int device_index, qhip_ctx** out) {
     QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     g_live_contexts[c->device & 31].fetch_add(1);
     for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
-    c->status.alloc(QS_WORDS * sizeof(uint32_t));
+    c->status.alloc(4 * QS_WORDS * sizeof(uint32_t));   // (a hash join uses three blocks: build status, probe status, pair total)
     c->pinned_bytes = 256 * 1024;
     QHIP_HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
     memset(&c->stats, 0, sizeof(c->stats));

@@ -351,6 +351,25 @@ int qhip_table_keep_columns(qhip_ctx* ctx, const qhip_table* t, const int32_t* k
   return guarded(ctx, [&] { *out = table_keep_columns(ctx, t, keep); });
 }
 
+int qhip_table_stride_sample(qhip_ctx* ctx, const qhip_table* t, int64_t stride, qhip_table** out) {
+  if (!ctx || !t || !out || stride < 1 || stride > 0x7fffffff) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t m = ((uint64_t)t->num_rows + (uint64_t)stride - 1) / (uint64_t)stride;
+    std::unique_ptr<qhip_table> o(new qhip_table());
+    o->ctx = ctx;
+    o->names = t->names;
+    o->nullable = t->nullable;
+    o->num_rows = (int64_t)m;
+    o->batch_offsets = {0, (int64_t)m};
+    auto idx = std::make_shared<DevBuf>((m + 1) * 4);
+    launch_iota_stride_u32(idx->as<uint32_t>(), m, (uint32_t)stride, ctx->stream);
+    defer_gather(ctx, t->cols, idx, m, false, o->cols);
+    *out = o.release();
+  });
+}
+
 int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta) {
   if (!ctx || !t || !meta || n_meta != (int32_t)(2 + 2 * t->cols.size())) return QHIP_INVALID_ARGUMENT;
   return guarded(ctx, [&] { table_wire_meta(ctx, t, meta); });

@@ -86,7 +86,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
-  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
+  // device status block of the call: [build status words | probe status words | pair total]: cleared once, read back once
+  uint32_t* const dstat = ctx->status.as<uint32_t>();
+  QHIP_HIP_CHECK(hipMemsetAsync(dstat, 0, (2 * QS_WORDS + 1) * 4, s));
   // The build's status (key-evaluation errors, duplicate keys?) is needed before the probe only to choose between the
   // unique-key and the CSR layout. Unique keys are the rule (every FK -> PK join), so unless this build side is known to
   // have had duplicates the probe is launched on that assumption and the build status is read together with the probe's:
@@ -175,15 +177,15 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   uint32_t max_count = 0;
   // read-backs land in the context's page-locked scratch: a D2H copy into pageable memory is a stream round trip of its
   // own, so two of them plus the synchronize cost three waits where one does
-  uint32_t* const st = (uint32_t*)ctx->pinned;          // [status words | pair total | build status words]
-  uint32_t* const st_build = st + 16;
+  uint32_t* const st_build = (uint32_t*)ctx->pinned;    // pinned mirror of the device status block: [build | probe | pair total]
+  uint32_t* const st = st_build + QS_WORDS;
   auto check_build_status = [&] {
     check_status_words(st_build);
     if (st_build[QS_OVERFLOW]) fail(QHIP_HIP_ERROR, "join build table overflow (internal error)");
     max_count = st_build[QS_MAXCOUNT];
   };
-  QHIP_HIP_CHECK(hipMemcpyAsync(st_build, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, s));   // key evaluation + build
   if (!speculate) {
+    QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));   // key evaluation + build
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
     check_build_status();
   }
@@ -227,7 +229,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     DevBuf strlit;
     fill_kargs(ctx, R, rkp.bind, ka, strlit);
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
-    DevBuf tile_tot((ntiles + 1) * 4), tile_nent((ntiles + 1) * 4), total(4);
+    DevBuf tile_tot((ntiles + 1) * 4), tile_nent((ntiles + 1) * 4);
     HProbeLaunch pl;
     pl.table = table; pl.bloom = bloom; pl.count = count; pl.start = start_ptr; pl.rows = rows_ptr;
     pl.ent_slot = ent_slot.as<uint32_t>();
@@ -235,11 +237,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.tile_nent = tile_nent.as<uint32_t>();
     pl.tile_total = tile_tot.as<uint32_t>();
     pl.visited = (mark_in_probe && !want_pairs) ? visited.as<uint32_t>() : nullptr;
-    pl.status = ctx->status.as<uint32_t>();
+    pl.status = dstat + QS_WORDS;
     pl.nslots = nslots; pl.bloom_mask = filter_words - 1;
     pl.n_regions = n_regions; pl.slot_bits = slot_bits; pl.bword_bits = bword_bits;
     pl.dbg = (uint32_t)env_int("QHIP_PROBE_DBG", 0);
-    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, s));
     void* args[] = {&ka, &pl};
     // ~12 tiles per wavefront once every CU has work: each wavefront pays three trips to fill and drain its pipeline,
     // and the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of exactly
@@ -251,12 +252,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     hipEventRecord(ctx->ev[3], s);
     probe_timed = true;
-    st[QS_WORDS] = 0;
-    if (want_pairs) {
-      exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, total.as<uint32_t>(), s);
-      QHIP_HIP_CHECK(hipMemcpyAsync(st + QS_WORDS, total.ptr, 4, hipMemcpyDeviceToHost, s));
-    }
-    QHIP_HIP_CHECK(hipMemcpyAsync(st, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
+    if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, dstat + 2 * QS_WORDS, s);
+    // ONE read-back: build status (needed only now under speculation), probe status and the pair total
+    QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, (2 * QS_WORDS + 1) * 4, hipMemcpyDeviceToHost, s));
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
     if (speculate) {
       check_build_status();
@@ -282,6 +280,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     }
     visited_done = mark_in_probe;
   } else if (speculate) {
+    QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
     QHIP_HIP_CHECK(hipStreamSynchronize(s));
     check_build_status();   // (duplicates do not matter without probe rows)
   }

@@ -26,6 +26,7 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s);
 void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipStream_t s);
 void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first = 0);
+void launch_iota_stride_u32(uint32_t* out, uint64_t n, uint32_t stride, hipStream_t s);   // out[i] = i * stride
 void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s);
 void launch_lookup_u32(const uint32_t* off, const uint64_t* rows, uint32_t n, uint64_t nrows, uint32_t total, uint32_t* out, hipStream_t s);
 

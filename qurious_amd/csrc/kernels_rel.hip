@@ -342,7 +342,12 @@ __global__ __launch_bounds__(QH_REGION_BLOCK) void k_join_region_build(const u64
                                                                         u32 rows_per_wg, u64* table, u64* bloom, u32 slot_bits,
                                                                         u32 bword_bits, u32* status) {
   constexpr int RB = QH_REGION_BLOCK;
-  const u32 S = 1u << slot_bits, BW = 1u << bword_bits, reg = blockIdx.x, tid = threadIdx.x;
+  const u32 S = 1u << slot_bits, BW = 1u << bword_bits, tid = threadIdx.x;
+  // XCD-aware region order: workgroups b, b + 8, b + 16, ... share an XCD (and its L2), so they take CONSECUTIVE regions. A
+  // step-1 workgroup's entries of neighbouring regions lie next to each other (4 regions per 128-byte line, 16 per line
+  // of `first`): with the plain order every line was fetched by 4 to 8 different L2s.
+  const u32 per_xcd = (n_regions + 7) / 8, reg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (reg >= n_regions) return;               // (workgroup-uniform; the grid is 8 * per_xcd)
   u64* lt = (u64*)qh_dyn_lds;                 // [S][1 + W]
   u64* lb = lt + (size_t)S * (1 + W);         // [BW]
   __shared__ u32 total;
@@ -575,6 +580,9 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_u32_nullable(const u32* inn
 __global__ __launch_bounds__(QH_BLOCK) void k_iota_u32(u32* out, u64 n, u32 first) {
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = first + (u32)i;
 }
+__global__ __launch_bounds__(QH_BLOCK) void k_iota_stride_u32(u32* out, u64 n, u32 stride) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (u32)(i * stride);
+}
 __global__ __launch_bounds__(QH_BLOCK) void k_fill_u32(u32* out, u64 n, u32 v) {
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = v;
 }
@@ -751,6 +759,9 @@ void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelG
 void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first) {
   if (n) hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, first);
 }
+void launch_iota_stride_u32(uint32_t* out, uint64_t n, uint32_t stride, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_iota_stride_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, stride);
+}
 void launch_fill_u32(uint32_t* out, uint64_t n, uint32_t v, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n)), dim3(QH_BLOCK), 0, s, (u32*)out, (u64)n, v);
 }
@@ -780,7 +791,7 @@ void launch_join_region_build(int W, const uint64_t* entries, const uint32_t* fi
                               uint64_t* bloom, uint32_t n_regions, uint32_t slot_bits, uint32_t bword_bits, uint32_t* status, hipStream_t s) {
   if (!n_regions) return;
   const size_t lds = ((size_t)8 * (1 + (size_t)W) << slot_bits) + ((size_t)8 << bword_bits);
-  DISPATCH_W(W, hipLaunchKernelGGL(k_join_region_build<KW>, dim3(n_regions), dim3(QH_REGION_BLOCK), lds, s, (const u64*)entries, (const u32*)first,
+  DISPATCH_W(W, hipLaunchKernelGGL(k_join_region_build<KW>, dim3(8 * ((n_regions + 7) / 8)), dim3(QH_REGION_BLOCK), lds, s, (const u64*)entries, (const u32*)first,
                                    n_wgs, n_regions, rows_per_wg, (u64*)table, (u64*)bloom, slot_bits, bword_bits, (u32*)status));
 }
 void launch_join_full_counts(int W, const uint64_t* table, uint32_t nslots, uint32_t* count, hipStream_t s) {

@@ -21,6 +21,8 @@ second strategy keeps it where it is (SURVEY §8e's option):
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -47,7 +49,7 @@ def _exchange_world(dist) -> int:
 
 
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
-_STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0}
+_STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0, "heavy_keys": 0, "probe_rows_received": 0}
 
 
 def exchange_stats(reset: bool = True) -> dict:
@@ -55,7 +57,7 @@ def exchange_stats(reset: bool = True) -> dict:
     out = dict(_STATS)
     out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
     if reset:
-        _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0)
+        _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0, heavy_keys=0, probe_rows_received=0)
     return out
 
 
@@ -316,6 +318,86 @@ class DeviceSource(PhysicalPlan):
         return self.table
 
 
+# ---------------------------------------------------------------- heavy hitters of a repartitioned join
+# Repartitioning by key hash sends every row of one key to one rank: with skewed probe keys (BASELINE configs[4]: Zipf 1.1)
+# a handful of keys would give one rank most of the probe side. Keys holding more than 1 / (4 n) of the probe rows are
+# therefore found on a SAMPLE first; their probe rows stay where they are and their (few) build rows are broadcast.
+HEAVY_SAMPLE_STRIDE = 64      # every 64th probe row is counted
+HEAVY_CANDIDATES = 64         # per rank: its most frequent sampled keys (a globally heavy key is among the top 4 n <= 32 somewhere)
+
+
+def heavy_keys(local_top: Sequence[Tuple[object, int]], local_sample_rows: int, group=None) -> List[object]:
+    """The globally heavy keys, identical on every rank: every rank contributes its most frequent sampled keys with their
+    counts and its sample size (one small all-gather of Python objects); a key is heavy when the sum of its reported counts
+    exceeds total sample / (4 world). (A key not among some rank's candidates is under-counted there by less than that
+    rank's 1/HEAVY_CANDIDATES share: only keys right at the threshold can be missed, and missing one costs balance only.)"""
+    dist = _dist()
+    world = dist.get_world_size(group)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (list(local_top), int(local_sample_rows)), group=group)
+    total = sum(n for _, n in gathered)
+    counts = {}
+    for top, _ in gathered:
+        for key, c in top:
+            if key is not None:
+                counts[key] = counts.get(key, 0) + int(c)
+    limit = total / (4.0 * world)
+    return sorted(k for k, c in counts.items() if c > limit)
+
+
+def _key_literal(value, dtype):
+    import pyarrow as pa
+    from .datatypes import ScalarValue
+    from .expr import CastExpr, Literal
+    if pa.types.is_int64(dtype):
+        return Literal(ScalarValue.Int64(int(value)))
+    if pa.types.is_int32(dtype):
+        return Literal(ScalarValue.Int32(int(value)))
+    if pa.types.is_date32(dtype):
+        return CastExpr(Literal(ScalarValue.Int32(int(value))), pa.date32())
+    if pa.types.is_string(dtype):
+        return Literal(ScalarValue.Utf8(str(value)))
+    return None
+
+
+def heavy_split_predicates(key: PhysicalExpr, dtype, keys: Sequence[object]):
+    """(is-heavy, is-not-heavy) predicates over one key expression. A NULL key is not heavy: it takes the ordinary path
+    (IS NULL OR (key <> h1 AND key <> h2 ...)), so the two predicates split a table exactly."""
+    from .datatypes import Operator
+    from .expr import BinaryExpr, IsNull
+    lits = [_key_literal(k, dtype) for k in keys]
+    if not lits or any(l is None for l in lits):
+        return None, None
+    heavy, light = None, None
+    for l in lits:
+        eq, ne = BinaryExpr(key, Operator.Eq, l), BinaryExpr(key, Operator.NotEq, l)
+        heavy = eq if heavy is None else BinaryExpr(heavy, Operator.Or, eq)
+        light = ne if light is None else BinaryExpr(light, Operator.And, ne)
+    return heavy, BinaryExpr(IsNull(key), Operator.Or, light)
+
+
+def _local_top_keys(table: DeviceTable, schema, key: PhysicalExpr, dtype):
+    """[(key value, count)] of the most frequent keys among every HEAVY_SAMPLE_STRIDE-th row of `table`, and the sample size:
+    a GROUP BY key / COUNT over the sample, top-N by count — all on the device, HEAVY_CANDIDATES rows come back."""
+    import pyarrow as pa
+    from .expr import Column, CountAggregateExpr, Literal
+    from .datatypes import ScalarValue
+    from .plan import HashAggregate, Limit, PhysicalSortExpr, Sort, SortOptions
+    ctx = table.ctx
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_table_stride_sample(ctx.handle, table.handle, HEAVY_SAMPLE_STRIDE, C.byref(out)))
+    sample = DeviceTable(ctx, out)
+    if sample.num_rows == 0:
+        return [], 0
+    gschema = pa.schema([pa.field("k", dtype), pa.field("n", pa.int64())])
+    agg = HashAggregate(gschema, DeviceSource(schema, sample), [key], [CountAggregateExpr(Literal(ScalarValue.Int64(1)))])
+    top = Limit(Sort([PhysicalSortExpr(Column("n", 1), SortOptions(True, False))], agg, HEAVY_CANDIDATES), HEAVY_CANDIDATES, 0)
+    rows = []
+    for b in top.execute():
+        rows.extend(zip(b.column(0).to_pylist(), b.column(1).to_pylist()))
+    return [(k, c) for k, c in rows if k is not None], sample.num_rows
+
+
 class DistributedHashJoinExec(HashJoinExec):
     """HashJoinExec whose inputs are this rank's slices: both sides are repartitioned by the join key across the ranks of
     ``torch.distributed``'s default group, then joined locally. Row order across ranks is not the single-process order
@@ -328,16 +410,42 @@ class DistributedHashJoinExec(HashJoinExec):
         ls, rs = self.left.schema(), self.right.schema()
         lneed, rneed = self._needed_per_side()
         # columns nothing above this join reads are dropped BEFORE the partitioning: never gathered, never sent
-        lparts = partition_by_key(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), [l for l, _ in self.on], world)
-        rparts = partition_by_key(keep_columns(self.right.execute_device(), _keep_mask(len(rs), rneed)), [r for _, r in self.on], world)
-        lt = exchange_device_tables(lparts, _wire_schema(ls, lneed))
-        rt = exchange_device_tables(rparts, _wire_schema(rs, rneed))
+        left = keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed))
+        right = keep_columns(self.right.execute_device(), _keep_mask(len(rs), rneed))
+        lw, rw = _wire_schema(ls, lneed), _wire_schema(rs, rneed)
+        heavy_l = heavy_r = None
+        # heavy hitters (one key column, join types in which a result row belongs to exactly one probe row): their probe rows
+        # stay on this rank, their build rows go to every rank; everything else is repartitioned by key hash
+        if len(self.on) == 1 and self.join_type in (JoinType.Inner, JoinType.Right) and os.environ.get("QHIP_EXCHANGE_NO_HEAVY") != "1":
+            from .plan import _filter_device
+            lkey, rkey = self.on[0]
+            rdtype = _expr_type(rkey, rs)
+            if rdtype is not None:
+                top, n_sample = _local_top_keys(right, rw, rkey, rdtype)
+                keys = heavy_keys(top, n_sample)
+                hl, ll = heavy_split_predicates(lkey, _expr_type(lkey, ls), keys) if keys else (None, None)
+                hr, lr = heavy_split_predicates(rkey, rdtype, keys) if keys else (None, None)
+                if hl is not None and hr is not None:
+                    heavy_l, left = all_gather_device_table(_filter_device(left, hl, None), lw), _filter_device(left, ll, None)
+                    heavy_r, right = _filter_device(right, hr, None), _filter_device(right, lr, None)
+                    _STATS["heavy_keys"] = _STATS.get("heavy_keys", 0) + len(keys)
+        lt = exchange_device_tables(partition_by_key(left, [l for l, _ in self.on], world), lw)
+        rt = exchange_device_tables(partition_by_key(right, [r for _, r in self.on], world), rw)
+        _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + rt.num_rows + (heavy_r.num_rows if heavy_r is not None else 0)
+        if heavy_l is not None:
+            lt, rt = concat_tables([lt, heavy_l]), concat_tables([rt, heavy_r])
         return self._join_tables(lt, rt)
 
     @staticmethod
     def try_new(left, right, join_type, on, filter=None) -> "DistributedHashJoinExec":
         base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
         return DistributedHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)
+
+
+def _expr_type(e: PhysicalExpr, schema):
+    """Arrow type of a key expression that is a plain column (what heavy-hitter handling supports), else None"""
+    from .expr import Column
+    return schema.field(e.index).type if isinstance(e, Column) and 0 <= e.index < len(schema) else None
 
 
 def all_gather_device_table(table: DeviceTable, schema, group=None) -> DeviceTable:

@@ -43,7 +43,8 @@ def _ipc(batch: pa.RecordBatch) -> bytes:
 
 
 def _unipc(buf: bytes) -> pa.RecordBatch:
-    return pa.ipc.open_stream(buf).read_all().combine_chunks().to_batches()[0]
+    t = pa.ipc.open_stream(buf).read_all().combine_chunks()
+    return t.to_batches()[0] if t.num_rows else pa.RecordBatch.from_arrays([pa.array([], type=f.type) for f in t.schema], schema=t.schema)
 
 
 def _worker(rank, world, port, out_dir):
@@ -200,3 +201,96 @@ def test_exchange_column_pruning_analysis_on_q3():
     # an un-annotated plan keeps everything
     plain = queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)
     assert plain.input._needed_per_side() == (None, None)
+
+
+# ---------------------------------------------------------------- heavy hitters of the repartitioned join
+def _skew_tables(s, n_probe=24000, domain=300, seed=5):
+    from qurious_amd import synth
+    rng = np.random.default_rng(seed)
+    ls = pa.schema([pa.field("bk", I64), pa.field("bv", I64)])
+    rs = pa.schema([pa.field("pk", I64), pa.field("pv", I64)])
+    lb = pa.RecordBatch.from_arrays([pa.array(np.arange(1, domain + 1), type=I64), pa.array(rng.integers(0, 10**6, domain), type=I64)], schema=ls)
+    pk = synth.zipf_ranks(0, n_probe, domain, s, 5)
+    rb = pa.RecordBatch.from_arrays([pa.array(pk, type=I64, mask=rng.random(n_probe) < 0.01), pa.array(np.arange(n_probe), type=I64)], schema=rs)
+    return (ls, lb), (rs, rb)
+
+
+def _worker_heavy(rank, world, port, out_dir, s):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import collections
+    import torch
+    import torch.distributed as dist
+    from oracle import qoracle
+    from qurious_amd import exchange
+    from qurious_amd.exchange import all_to_all_bytes
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (ls, lb), (rs, rb) = _skew_tables(s)
+        mine = lambda b: b.slice(b.num_rows * rank // world, b.num_rows * (rank + 1) // world - b.num_rows * rank // world)   # noqa: E731
+        build, probe = mine(lb), mine(rb)
+
+        def shuffle(batch, key):
+            pid = qoracle.partition_ids([batch.column(key)], world)
+            send = [torch.frombuffer(bytearray(_ipc(batch.filter(pa.array(pid == r)))), dtype=torch.uint8) for r in range(world)]
+            return pa.concat_batches([_unipc(bytes(t.numpy().tobytes())) for t in all_to_all_bytes(send)])
+
+        # (a) blind repartitioning: how many probe rows land here
+        blind = shuffle(probe, "pk").num_rows
+        # (b) the operator's flow (exchange.DistributedHashJoinExec) with the oracle as the local engine: count a strided
+        # sample, agree on the heavy keys, keep their probe rows, broadcast their build rows, repartition the rest
+        stride = 8
+        sample = probe.column("pk").to_pylist()[::stride]
+        top = collections.Counter(k for k in sample if k is not None).most_common(exchange.HEAVY_CANDIDATES)
+        keys = exchange.heavy_keys(top, len(sample))
+        assert keys, "Zipf keys must produce heavy hitters"
+        hb, lb_pred = exchange.heavy_split_predicates(col("bk", 0), I64, keys)
+        hp, lp_pred = exchange.heavy_split_predicates(col("pk", 0), I64, keys)
+        filt = lambda schema, batch, pred: pa.concat_batches(qoracle.execute(q.Filter(table_scan(schema, [batch]), pred)))   # noqa: E731
+        heavy_probe, light_probe = filt(rs, probe, hp), filt(rs, probe, lp_pred)
+        assert heavy_probe.num_rows + light_probe.num_rows == probe.num_rows      # the predicates split the table exactly (NULL keys are light)
+        heavy_build_local, light_build = filt(ls, build, hb), filt(ls, build, lb_pred)
+        send = [torch.frombuffer(bytearray(_ipc(heavy_build_local)), dtype=torch.uint8)] * world                               # all-gather
+        heavy_build = pa.concat_batches([_unipc(bytes(t.numpy().tobytes())) for t in all_to_all_bytes(send)])
+        lpart = pa.concat_batches([shuffle(light_build, "bk"), heavy_build])
+        rpart = pa.concat_batches([shuffle(light_probe, "pk"), heavy_probe])
+        plan = q.HashJoinExec.try_new(table_scan(ls, [lpart]), table_scan(rs, [rpart]), JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
+        local = rows_of(qoracle.execute(plan))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (local, blind, rpart.num_rows, keys))
+        if rank == 0:
+            full = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb]), JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
+            want = sorted(rows_of(qoracle.execute(full)), key=repr)
+            got_rows = sorted([r for part, _, _, _ in gathered for r in part], key=repr)
+            assert got_rows == want and len(want) > 20000
+            assert all(g[3] == keys for g in gathered)                            # every rank agreed on the same heavy keys
+            blind_rows, handled = [g[1] for g in gathered], [g[2] for g in gathered]
+            mean = rb.num_rows / world
+            open(os.path.join(out_dir, "ok"), "w").write(f"{max(blind_rows) / mean:.3f} {max(handled) / mean:.3f} {max(blind_rows) / rb.num_rows:.3f}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,s", [(2, 1.5), (3, 1.1)])
+def test_heavy_hitters_keep_the_repartitioned_join_balanced(tmp_path, world, s):
+    """Zipf-skewed probe keys: blind hash partitioning gives one rank far more than its share (world 2, Zipf 1.5: > 60 % of
+    the probe rows); with the heavy keys' probe rows kept local and their build rows broadcast every rank stays within 1.3x
+    of the mean, every rank derives the same heavy keys, and the union of the ranks' joins is the single-process join."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_heavy, args=(world, port, str(tmp_path), s), nprocs=world, join=True)
+    blind, handled, blind_share = (float(x) for x in open(os.path.join(str(tmp_path), "ok")).read().split())
+    assert handled <= 1.3 and handled < blind
+    if world == 2:
+        assert blind_share > 0.6
+
+
+def test_heavy_split_predicates_partition_every_row():
+    """is-heavy / is-not-heavy must split a table exactly, NULL keys on the not-heavy side (they take the ordinary path)"""
+    from oracle import qoracle
+    from qurious_amd import exchange
+    schema = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+    batch = pa.RecordBatch.from_arrays([pa.array([1, 2, None, 3, 2, 2, None, 7], type=I64), pa.array(range(8), type=I64)], schema=schema)
+    heavy, light = exchange.heavy_split_predicates(col("k", 0), I64, [2, 7])
+    run = lambda pred: rows_of(qoracle.execute(q.Filter(table_scan(schema, [batch]), pred)))   # noqa: E731
+    assert [r[1] for r in run(heavy)] == [1, 4, 5, 7] and [r[1] for r in run(light)] == [0, 2, 3, 6]
+    assert exchange.heavy_split_predicates(col("k", 0), pa.float64(), [1.5]) == (None, None)   # unsupported key type: no split

@@ -192,6 +192,11 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2"],
                        env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and r.stdout.count("equal to the single-process plan") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+    # ... and with Zipf(1.1) join keys: the repartitioned joins detect the heavy keys on a sample, keep their probe rows local and
+    # broadcast their build rows (exchange.DistributedHashJoinExec); the ranks' probe sides stay within 1.3x of the mean
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2", "--skew", "1.1"],
+                       env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and "heavy keys per rank" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     # (1) exactly the command the driver's scaling run issues per rank (default workload: the metric's step = Q1 at SF10 +
     # Q3 at SF10), with the multi-rank branch forced on: Q1 partial groups merged through an all-gather, Q3 through both

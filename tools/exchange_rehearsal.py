@@ -28,7 +28,7 @@ def rows_of(batches):
     return sorted(out, key=repr)
 
 
-def two_rank_worker(rank, world, port, sf, out_dir):
+def two_rank_worker(rank, world, port, sf, out_dir, skew=0.0):
     """`world` PROCESSES sharing the one GPU, each with its own libqhip context and its slice of the tables, exchanging over
     gloo (device tensors staged through the host): partition -> wire images -> transport between different ranks ->
     unpack + concat -> join / merge. The union of the ranks' results must equal the single-process plan over all rows."""
@@ -39,7 +39,7 @@ def two_rank_worker(rank, world, port, sf, out_dir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        c, o, l = synth.q3_tables(sf, rank, world)
+        c, o, l = synth.q3_tables_skewed(sf, skew, rank, world) if skew > 0 else synth.q3_tables(sf, rank, world)
         mine = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
                 q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
         results = {}
@@ -50,20 +50,27 @@ def two_rank_worker(rank, world, port, sf, out_dir):
             local = rows_of(plan.execute_device().to_batches())
             st = exchange.exchange_stats()
             gathered = [None] * world
-            dist.all_gather_object(gathered, (local, st["bytes_sent"]))
+            dist.all_gather_object(gathered, (local, st["bytes_sent"], st["heavy_keys"], st["probe_rows_received"]))
             results[name] = gathered
         if rank == 0:
-            cc, oo, ll = synth.q3_tables(sf)
+            cc, oo, ll = synth.q3_tables_skewed(sf, skew) if skew > 0 else synth.q3_tables(sf)
             whole = queries.q3(q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, cc), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, oo),
                                q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, ll))
             want = rows_of(whole.execute())
             for name, gathered in results.items():
-                got = sorted((r for part, _ in gathered for r in part), key=repr)
+                got = sorted((r for part, *_ in gathered for r in part), key=repr)
                 keys = [r[0] for r in got]
                 assert got == want and len(keys) == len(set(keys)) and len(want) > 100, f"{name}: union of the ranks differs from the single-process plan"
-                assert all(sent > 0 for _, sent in gathered)            # every rank really sent rows to the others
-                print(f"[rehearsal] {world} processes, {name}: {len(got)} groups in all ({[len(p) for p, _ in gathered]} per rank) equal to the "
-                      f"single-process plan; bytes sent per rank {[s for _, s in gathered]}")
+                assert all(g[1] > 0 for g in gathered)            # every rank really sent rows to the others
+                print(f"[rehearsal] {world} processes, {name}: {len(got)} groups in all ({[len(g[0]) for g in gathered]} per rank) equal to the "
+                      f"single-process plan; bytes sent per rank {[g[1] for g in gathered]}")
+                if skew > 0 and name == "repartition":
+                    # Zipf keys: the repartitioned joins found heavy hitters, kept their probe rows local, and the ranks'
+                    # probe sides stay balanced
+                    recv = [g[3] for g in gathered]
+                    assert all(g[2] > 0 for g in gathered), "no heavy keys found on skewed data"
+                    assert max(recv) <= 1.3 * (sum(recv) / len(recv)), recv
+                    print(f"[rehearsal] skew {skew}: heavy keys per rank {[g[2] for g in gathered]}, probe rows joined per rank {recv}")
             open(os.path.join(out_dir, "ok_two_rank"), "w").write(str(len(want)))
         ctx.synchronize()
     finally:
@@ -74,6 +81,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sf", type=float, default=0.2)
     ap.add_argument("--world", type=int, default=1, help="> 1: that many processes share the GPU and exchange over gloo")
+    ap.add_argument("--skew", type=float, default=0.0, help="with --world > 1: join keys re-drawn from Zipf(s) (heavy-hitter handling)")
     args = ap.parse_args()
     if args.world > 1:
         import socket
@@ -83,7 +91,7 @@ def main():
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         with tempfile.TemporaryDirectory() as d:
-            mp.spawn(two_rank_worker, args=(args.world, port, args.sf, d), nprocs=args.world, join=True)
+            mp.spawn(two_rank_worker, args=(args.world, port, args.sf, d, args.skew), nprocs=args.world, join=True)
             assert os.path.exists(os.path.join(d, "ok_two_rank"))
         print("REHEARSAL OK")
         return
