@@ -26,6 +26,16 @@ def catalog_sources():
     for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table))):
         scan = plan.input
         out.append((name + " filter+aggregate", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
+    # ... and their narrow variants: what an execution over the synthetic lineitem compiles once it has the columns' |value|
+    # statistics (quantity 13 bits, price 24, discount / tax 4): 32 / 64-bit multiplies, 64-bit lane accumulators
+    import os
+    os.environ["QHIP_PLAN_VALUE_BITS"] = "3:13,4:24,5:4,6:4"
+    try:
+        for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table))):
+            scan = plan.input
+            out.append((name + " filter+aggregate, bounded values", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
+    finally:
+        os.environ.pop("QHIP_PLAN_VALUE_BITS", None)
     # Q3: build-side key words (+ fused scan filter), fused probe kernels, the aggregate over the second join's output
     tabs = (MemoryTable.try_new(CUSTOMER_SCHEMA, []), MemoryTable.try_new(ORDERS_SCHEMA, []), MemoryTable.try_new(LINEITEM_Q3_SCHEMA, []))
     agg = queries.q3(*tabs)

@@ -159,11 +159,18 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   resolve_referenced(ctx, in, exprs, n_exprs);
   std::vector<InputCol> icols = input_cols_of(in);
   ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
+  // |value| bounds of the Int64 / Decimal128 columns (cached per column; computed only on inputs big enough to pay for the
+  // reduction): the generated code multiplies and accumulates in 32 / 64 bits where the bounds allow
+  if (env_int("QHIP_AGG_NO_BOUNDS", 0) == 0) ensure_value_bounds(ctx, in, exprs, n_exprs, icols, (int64_t)1 << 22);
   // lowered plans are cached per context: a repeated query (same expression PODs over the same column signature) skips
   // typing and code generation; literal VALUES are part of the key because they are bound into the plan's KernelBindings
   std::string key = "agg|";
   auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
-  for (auto& ic : icols) { const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0}; put(v, sizeof v); }
+  for (auto& ic : icols) {
+    const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0};
+    put(&ic.value_maxabs, sizeof ic.value_maxabs);   // (a whole number of bits, see ensure_value_bounds)
+    put(v, sizeof v);
+  }
   for (int k = 0; k < n_exprs; ++k) {
     qhip_expr e = exprs[k];
     const char* str = e.lit_str; const int64_t len = e.lit_len;

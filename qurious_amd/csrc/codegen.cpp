@@ -289,13 +289,30 @@ void ExprGen::emit(int k, std::string& out) {
             };
             o << "    const double " << v << " = " << tof(l, lv) << " / " << tof(r, rv) << ";\n";
           } else if (n.op == QHIP_OP_MUL) {
-            o << "    const i128 " << v << " = " << (raw_ ? "qh_mul_i128(" : "qh_mul_i128_plain(") << lv << ", " << rv << ");\n";
+            // operand magnitudes known from the columns' statistics (ENode::maxabs): a 32 x 32 -> 64 or 64 x 64 -> 128
+            // multiply written out, instead of the generic 128-bit product behind wave-uniform "do all lanes fit" tests
+            const u128 b31 = (u128)1 << 31, b63 = (u128)1 << 63;
+            if (l.maxabs < b31 && r.maxabs < b31)
+              o << "    const i128 " << v << " = (i128)((i64)(int)(u32)(u128)" << lv << " * (i64)(int)(u32)(u128)" << rv << ");\n";
+            else if (l.maxabs < b63 && r.maxabs < b63)
+              o << "    const i128 " << v << " = qh_mul_i64_i128((i64)(u64)(u128)" << lv << ", (i64)(u64)(u128)" << rv << ");\n";
+            else
+              o << "    const i128 " << v << " = " << (raw_ ? "qh_mul_i128(" : "qh_mul_i128_plain(") << lv << ", " << rv << ");\n";
           } else {
             const int s = n.type.scale;
-            std::string a = "(u128)" + lv, b = "(u128)" + rv;
-            if (s > l.type.scale) a = "(" + a + " * (u128)" + i128_const(pow10_i128(s - l.type.scale)) + ")";
-            if (s > r.type.scale) b = "(" + b + " * (u128)" + i128_const(pow10_i128(s - r.type.scale)) + ")";
-            o << "    const i128 " << v << " = (i128)(" << a << (n.op == QHIP_OP_ADD ? " + " : " - ") << b << ");\n";
+            if (n.maxabs < ((u128)1 << 63)) {
+              // the result (hence both rescaled operands) fits 63 bits: the sum in 64-bit arithmetic, sign-extended
+              auto k64 = [&](int e) { return std::to_string((unsigned long long)(u128)pow10_i128(e)) + "ULL"; };
+              std::string a = "(u64)(u128)" + lv, b = "(u64)(u128)" + rv;
+              if (s > l.type.scale) a = "(" + a + " * " + k64(s - l.type.scale) + ")";
+              if (s > r.type.scale) b = "(" + b + " * " + k64(s - r.type.scale) + ")";
+              o << "    const i128 " << v << " = (i128)(i64)(" << a << (n.op == QHIP_OP_ADD ? " + " : " - ") << b << ");\n";
+            } else {
+              std::string a = "(u128)" + lv, b = "(u128)" + rv;
+              if (s > l.type.scale) a = "(" + a + " * (u128)" + i128_const(pow10_i128(s - l.type.scale)) + ")";
+              if (s > r.type.scale) b = "(" + b + " * (u128)" + i128_const(pow10_i128(s - r.type.scale)) + ")";
+              o << "    const i128 " << v << " = (i128)(" << a << (n.op == QHIP_OP_ADD ? " + " : " - ") << b << ");\n";
+            }
           }
         } else if (dtype_is_float(n.type)) {
           if (n.op == QHIP_OP_MOD) o << "    const " << T << " " << v << " = (" << T << ")fmod((double)" << lv << ", (double)" << rv << ");\n";
@@ -617,10 +634,28 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   int off = 0;
   for (auto& c : P.cells) { c.off = off; off += c.words; }
   P.slot_words = 1 + P.W + off;
+  // Decimal128 arguments whose magnitude is known (ENode::maxabs) travel and accumulate narrower: a value below 2^63 is kept
+  // as i64 in the Row; a SUM over values below 2^39 is accumulated per lane in 64 bits (a lane sees at most 2^24 of a
+  // table's < 2^32 rows, so the lane sum stays below 2^63) and widened when the lanes are reduced at the end of the kernel
+  std::vector<bool> arg64(P.args.size(), false), arg_acc64(P.args.size(), false);
+  for (size_t a = 0; a < P.args.size(); ++a) {
+    const ENode& nd = es.at(P.args[a].root);
+    arg64[a] = nd.type.id == QHIP_DECIMAL128 && nd.maxabs < ((u128)1 << 63);
+    arg_acc64[a] = nd.type.id == QHIP_DECIMAL128 && nd.maxabs < ((u128)1 << 39);
+  }
+  auto cell_acc64 = [&](const CellDesc& c) { return c.kind == CELL_SUM_I128 && arg_acc64[(size_t)c.arg]; };
   // hot-key cache size: lane-private accumulators for KC keys must fit the register file next to R rows
   int part_regs = 0;
-  for (auto& c : P.cells) if (c.kind != CELL_ROWS) part_regs += 2 * c.words - (c.kind == CELL_MAXORD128 ? 2 : 0);
+  for (auto& c : P.cells) if (c.kind != CELL_ROWS) part_regs += cell_acc64(c) ? 2 : 2 * c.words - (c.kind == CELL_MAXORD128 ? 2 : 0);
   P.KC = P.W == 0 ? 0 : (part_regs * 4 <= 96 ? 4 : part_regs * 2 <= 96 ? 2 : 0);
+  // every SUM narrow (64-bit lane accumulators): a cached key then costs its compare plus two VALU instructions per cell and
+  // row, and what counts is the number of PASSES over the tile's rows. Measured on TPC-H Q1's list (5 narrow sums, 4 groups
+  // of 49 / 25 / 25 / 1 % of the rows; kernel time for SF10's rows): KC 0 0.680 ms, 1 0.648, 2 0.641 (R = 3), 3 0.717,
+  // 4 0.719 — two cached keys and the LDS table for the rest beat four passes; a single narrow sum (q1_mini) still wants
+  // every group cached (KC 3-4 0.323 ms, KC 2 0.403).
+  bool all_narrow = P.W > 0 && !P.cells.empty();
+  for (auto& c : P.cells) if (c.kind != CELL_ROWS && !cell_acc64(c)) all_narrow = false;
+  if (all_narrow && part_regs > 0) P.KC = std::max(1, std::min(4, 24 / part_regs));
   if (const char* kc = getenv("QHIP_AGG_KC")) { if (*kc && P.W > 0) P.KC = atoi(kc); }   // tuning experiments only
   if (P.R <= 0) {
     // rows per thread per tile: all loads of a tile are in flight together, so more rows = more memory-level
@@ -630,10 +665,10 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     for (size_t a = 0; a < P.args.size(); ++a) {
       bool value_needed = false;
       for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
-      if (value_needed) row_regs += std::max(1, dtype_width(P.args[a].type) / 4);
+      if (value_needed) row_regs += arg64[a] ? 2 : std::max(1, dtype_width(P.args[a].type) / 4);
       if (P.args[a].nullable) row_regs += 1;
     }
-    P.R = std::max(1, std::min(4, (144 - P.KC * part_regs) / row_regs));
+    P.R = std::max(1, std::min(4, ((all_narrow ? 72 : 144) - P.KC * part_regs) / row_regs));   // (narrow Q1: R = 3, 0.641 ms; 2: 0.666; 4: 0.659)
   }
 
   // ---- source
@@ -655,7 +690,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     const ArgDesc& ad = P.args[a];
     bool value_needed = false;
     for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
-    if (value_needed) s << "    " << ExprGen::ctype(ad.type) << " a" << a << ";\n";
+    if (value_needed) s << "    " << (arg64[a] ? std::string("i64") : ExprGen::ctype(ad.type)) << " a" << a << ";\n";
     if (ad.nullable) s << "    bool h" << a << ";\n";
   }
   s << "  };\n";
@@ -690,7 +725,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     ev << code;
     bool value_needed = false;
     for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
-    if (value_needed) ev << "    r.a" << a << " = " << g.val(P.args[a].root) << ";\n";
+    if (value_needed) ev << "    r.a" << a << " = " << (arg64[a] ? "(i64)(u64)(u128)" : "") << g.val(P.args[a].root) << ";\n";
     if (P.args[a].nullable) ev << "    r.h" << a << " = " << g.ok(P.args[a].root) << ";\n";
   }
   s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
@@ -700,36 +735,59 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "  __device__ static __forceinline__ void part_init(Part& p) {\n";
   for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";
   s << "  }\n";
-  // part_add
+  // part_add / acc_add
   // ROWS = false: the caller knows the row count from ballot popcounts (part_set_rows) and saves the per-lane adds.
   // Sums are written as `if (take) acc += v` so that the compiler can run the adds under the EXEC mask instead of
-  // paying a v_cndmask per dword on top of every add.
-  s << "  template <bool ROWS> __device__ static __forceinline__ void part_add(Part& p, const Row& r, const bool m) {\n";
-  for (size_t c = 0; c < P.cells.size(); ++c) {
-    const CellDesc& cd = P.cells[c];
-    const std::string C = "p.c" + std::to_string(c);
-    if (cd.kind == CELL_ROWS) { s << "    if (ROWS) " << C << " += m ? 1ULL : 0ULL;\n"; continue; }
-    const ArgDesc& ad = P.args[(size_t)cd.arg];
-    const std::string A = "r.a" + std::to_string(cd.arg);
-    const std::string take = ad.nullable ? "(m && r.h" + std::to_string(cd.arg) + ")" : std::string("m");
-    switch (cd.kind) {
-      case CELL_SUM_I128: s << "    if (" << take << ") " << C << " = (i128)((u128)" << C << " + (u128)" << A << ");\n"; break;
-      case CELL_SUM_U64: s << "    if (" << take << ") " << C << " += (u64)" << A << ";\n"; break;
-      case CELL_SUM_F64: s << "    if (" << take << ") " << C << " += (double)" << A << ";\n"; break;
-      case CELL_CNT: s << "    " << C << " += " << take << " ? 1ULL : 0ULL;\n"; break;
-      case CELL_MAXORD64: {
-        const std::string o = std::string(cd.is_min ? "~" : "") + ord64(ad.type, A);
-        s << "    { const u64 o = " << take << " ? " << o << " : 0ULL; " << C << " = o > " << C << " ? o : " << C << "; }\n";
-        break;
+  // paying a v_cndmask per dword on top of every add. Acc = the lane-private accumulators of the hot-key cache (and of the
+  // ungrouped aggregate): Part with the narrow SUM cells in 64 bits.
+  for (int narrow = 0; narrow < 2; ++narrow) {
+    if (narrow) {
+      s << "  struct Acc {\n";
+      for (size_t c = 0; c < P.cells.size(); ++c) {
+        const char* t = "u64";
+        if (P.cells[c].kind == CELL_SUM_I128) t = cell_acc64(P.cells[c]) ? "i64" : "i128";
+        else if (P.cells[c].kind == CELL_SUM_F64) t = "double";
+        else if (P.cells[c].kind == CELL_MAXORD128) t = "u128";
+        s << "    " << t << " c" << c << ";\n";
       }
-      case CELL_MAXORD128: {
-        const std::string o = std::string(cd.is_min ? "~" : "") + "((u128)" + A + " ^ ((u128)1 << 127))";
-        s << "    { const u128 o = " << take << " ? " << o << " : (u128)0; " << C << " = o > " << C << " ? o : " << C << "; }\n";
-        break;
+      s << "  };\n";
+      s << "  __device__ static __forceinline__ void acc_init(Acc& p) {\n";
+      for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = 0;\n";
+      s << "  }\n";
+      s << "  __device__ static __forceinline__ void acc_to_part(const Acc& a, Part& p) {\n";
+      for (size_t c = 0; c < P.cells.size(); ++c) s << "    p.c" << c << " = " << (cell_acc64(P.cells[c]) ? "(i128)" : "") << "a.c" << c << ";\n";
+      s << "  }\n";
+    }
+    s << "  template <bool ROWS> __device__ static __forceinline__ void " << (narrow ? "acc_add(Acc& p" : "part_add(Part& p") << ", const Row& r, const bool m) {\n";
+    for (size_t c = 0; c < P.cells.size(); ++c) {
+      const CellDesc& cd = P.cells[c];
+      const std::string C = "p.c" + std::to_string(c);
+      if (cd.kind == CELL_ROWS) { s << "    if (ROWS) " << C << " += m ? 1ULL : 0ULL;\n"; continue; }
+      const ArgDesc& ad = P.args[(size_t)cd.arg];
+      const std::string A = "r.a" + std::to_string(cd.arg);
+      const std::string take = ad.nullable ? "(m && r.h" + std::to_string(cd.arg) + ")" : std::string("m");
+      switch (cd.kind) {
+        case CELL_SUM_I128:
+          if (narrow && cell_acc64(cd)) s << "    if (" << take << ") " << C << " = (i64)((u64)" << C << " + (u64)" << A << ");\n";
+          else s << "    if (" << take << ") " << C << " = (i128)((u128)" << C << " + (u128)(i128)" << A << ");\n";
+          break;
+        case CELL_SUM_U64: s << "    if (" << take << ") " << C << " += (u64)" << A << ";\n"; break;
+        case CELL_SUM_F64: s << "    if (" << take << ") " << C << " += (double)" << A << ";\n"; break;
+        case CELL_CNT: s << "    " << C << " += " << take << " ? 1ULL : 0ULL;\n"; break;
+        case CELL_MAXORD64: {
+          const std::string o = std::string(cd.is_min ? "~" : "") + ord64(ad.type, A);
+          s << "    { const u64 o = " << take << " ? " << o << " : 0ULL; " << C << " = o > " << C << " ? o : " << C << "; }\n";
+          break;
+        }
+        case CELL_MAXORD128: {
+          const std::string o = std::string(cd.is_min ? "~" : "") + "((u128)(i128)" + A + " ^ ((u128)1 << 127))";
+          s << "    { const u128 o = " << take << " ? " << o << " : (u128)0; " << C << " = o > " << C << " ? o : " << C << "; }\n";
+          break;
+        }
       }
     }
+    s << "  }\n";
   }
-  s << "  }\n";
   // part_reduce
   s << "  __device__ static __forceinline__ void part_set_rows(Part& p, const u64 n) { p.c0 = n; }\n";
   s << "  template <bool ROWS> __device__ static __forceinline__ void part_reduce(Part& p) {\n";

@@ -94,6 +94,10 @@ struct DevColumn {
   std::shared_ptr<DevBuf> data;      // utf8 bytes
   int64_t data_bytes = 0;
   mutable int32_t utf8_max_len = -1;   // cached longest value (bytes), computed on first use as a key column
+  // cached upper bound of |value| of an Int64 / Decimal128 column (0 = not computed, ~0 = some value needs more than 63
+  // bits), computed on first use as an aggregate argument of a big input: lets the generated code multiply and accumulate
+  // in 32 / 64 bits where the data allows (an upper bound stays one under gathering, like utf8_max_len)
+  mutable uint64_t value_maxabs = 0;
   // A join / filter output column may be DEFERRED: (source column, row index vector), gathered only when somebody reads
   // it (an expression that references it, an export, an exchange). The reference gathers every column of every join
   // output (utils/batch.rs:18-61) although most are never looked at downstream (Q3: c_mktsegment, o_custkey, ...).

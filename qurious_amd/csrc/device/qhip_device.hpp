@@ -151,6 +151,8 @@ __device__ __forceinline__ i128 qh_mul_i128(i128 a, i128 b) {
   return (i128)((u128)a * (u128)b);
 }
 __device__ __forceinline__ i128 qh_mul_i128_plain(i128 a, i128 b) { return (i128)((u128)a * (u128)b); }   // branch-free form
+// 64 x 64 -> 128 signed product (operands known to fit 63 bits from the columns' statistics)
+__device__ __forceinline__ i128 qh_mul_i64_i128(i64 a, i64 b) { return qh_mk128((u64)a * (u64)b, __mul64hi(a, b)); }
 __device__ __forceinline__ i128 qh_pow10(int e) { i128 r = 1; for (int k = 0; k < e; ++k) r *= 10; return r; }
 
 // ------------------------------------------------------------------ wavefront primitives (wave64)
@@ -432,13 +434,13 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     __syncthreads();
   }
 
-  typename P::Part acc;   // W == 0: whole-kernel per-thread accumulator
-  if (W == 0) P::part_init(acc);
+  typename P::Acc acc;    // W == 0: whole-kernel per-thread accumulator
+  if (W == 0) P::acc_init(acc);
   u32 err = 0;            // QS_* bits raised by this thread, reported once at the end
   // wave-resident hot-key cache (wave-uniform bookkeeping lives in SGPRs)
   constexpr int KC = P::KC;
   u64 ck[KC > 0 ? KC : 1][W > 0 ? W : 1];
-  typename P::Part cacc[KC > 0 ? KC : 1];
+  typename P::Acc cacc[KC > 0 ? KC : 1];   // (narrow SUM cells in 64 bits, widened at the end of the kernel)
   u64 crows[KC > 0 ? KC : 1];
   int nc = 0, singles = 0;
   bool cache_on = KC > 0, use_cache = true;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     }
     if (W == 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) P::template part_add<true>(acc, row[r], row[r].pass);
+      for (int r = 0; r < R; ++r) P::template acc_add<true>(acc, row[r], row[r].pass);
       continue;
     }
     // ---- wave-resident hot-key accumulators
@@ -491,7 +493,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
           bool m = pend[r];
 #pragma unroll
           for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == ck[k][w]);
-          P::template part_add<false>(cacc[k], row[r], m);
+          P::template acc_add<false>(cacc[k], row[r], m);
           const u32 c = (u32)__builtin_popcountll(qh_ballot(m));
           crows[k] += c;
           tile_hits += c;
@@ -536,10 +538,10 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
             if (k == nc) {
 #pragma unroll
               for (int w = 0; w < W; ++w) ck[k][w] = lk[w];
-              P::part_init(cacc[k]);
+              P::acc_init(cacc[k]);
               crows[k] = cnt;
 #pragma unroll
-              for (int r = 0; r < R; ++r) { P::template part_add<false>(cacc[k], row[r], mm[r]); pend[r] = pend[r] && !mm[r]; }
+              for (int r = 0; r < R; ++r) { P::template acc_add<false>(cacc[k], row[r], mm[r]); pend[r] = pend[r] && !mm[r]; }
             }
           }
           ++nc;
@@ -569,15 +571,19 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     if (k < nc) {
-      P::template part_reduce<false>(cacc[k]);
-      P::part_set_rows(cacc[k], crows[k]);
-      if (lane == 0) qh_update_group<P>(ltable, L, ck[k], cacc[k], err);
+      typename P::Part part;
+      P::acc_to_part(cacc[k], part);
+      P::template part_reduce<false>(part);
+      P::part_set_rows(part, crows[k]);
+      if (lane == 0) qh_update_group<P>(ltable, L, ck[k], part, err);
     }
   }
   qh_report(L.status, err);
   if (W == 0) {
-    P::template part_reduce<true>(acc);
-    if (lane == 0) P::template slot_update<MemHbm>(L.gtable, acc);
+    typename P::Part part;
+    P::acc_to_part(acc, part);
+    P::template part_reduce<true>(part);
+    if (lane == 0) P::template slot_update<MemHbm>(L.gtable, part);
     return;
   }
   // ---- merge this workgroup's LDS table into the HBM table

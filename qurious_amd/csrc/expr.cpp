@@ -321,6 +321,53 @@ void ExprSet::build(const qhip_expr* ex, int n, const std::vector<InputCol>& inp
       default:
         fail(QHIP_INVALID_ARGUMENT, "unknown expression kind " + std::to_string(e.kind));
     }
+    // ---- value bound (integers and decimals; saturating)
+    {
+      auto sat_mul = [](u128 a, u128 b) -> u128 {
+        if (a == kUnbounded || b == kUnbounded) return kUnbounded;
+        if (a == 0 || b == 0) return 0;
+        if (a > ((u128)1 << 100) / b) return kUnbounded;
+        return a * b;
+      };
+      auto sat_add = [](u128 a, u128 b) -> u128 {
+        if (a == kUnbounded || b == kUnbounded) return kUnbounded;
+        const u128 r = a + b;
+        return r >= ((u128)1 << 100) ? kUnbounded : r;
+      };
+      auto p10 = [](int e) -> u128 { return e < 0 ? kUnbounded : e > 30 ? kUnbounded : (u128)pow10_i128(e); };
+      nd.maxabs = kUnbounded;
+      const bool numeric = is_intlike(nd.type) || nd.type.id == QHIP_DECIMAL128;
+      if (numeric) {
+        if (nd.kind == QHIP_EXPR_COLUMN) {
+          const uint64_t m = input[(size_t)nd.column].value_maxabs;
+          i128 lo, hi;
+          if (m != 0 && m != ~0ULL) nd.maxabs = m;
+          else if (int_range(nd.type, lo, hi) && dtype_width(nd.type) <= 4) nd.maxabs = (u128)(hi > -lo ? hi : -lo);
+        } else if (nd.kind == QHIP_EXPR_LITERAL) {
+          if (!nd.lit_null) {
+            const i128 v = nd.type.id == QHIP_DECIMAL128 ? lit_i128(nd) : (nd.type.id == QHIP_UINT64 ? (i128)(u128)nd.lo : (i128)(int64_t)nd.lo);
+            nd.maxabs = v < 0 ? (u128)0 - (u128)v : (u128)v;
+          } else nd.maxabs = 0;
+        } else if (nd.kind == QHIP_EXPR_BINARY && nd.type.id == QHIP_DECIMAL128) {
+          const ENode& l = nodes[(size_t)nd.left];
+          const ENode& r = nodes[(size_t)nd.right];
+          if (nd.op == QHIP_OP_MUL) nd.maxabs = sat_mul(l.maxabs, r.maxabs);
+          else if (nd.op == QHIP_OP_ADD || nd.op == QHIP_OP_SUB)
+            nd.maxabs = sat_add(sat_mul(l.maxabs, p10(nd.type.scale - l.type.scale)), sat_mul(r.maxabs, p10(nd.type.scale - r.type.scale)));
+        } else if (nd.kind == QHIP_EXPR_NEGATIVE) {
+          nd.maxabs = nodes[(size_t)nd.left].maxabs;
+        } else if (nd.kind == QHIP_EXPR_CAST) {
+          const ENode& ch = nodes[(size_t)nd.left];
+          if (is_intlike(ch.type) && nd.type.id == QHIP_DECIMAL128) nd.maxabs = sat_mul(ch.maxabs, p10(nd.type.scale));
+          else if (ch.type.id == QHIP_DECIMAL128 && nd.type.id == QHIP_DECIMAL128 && nd.type.scale >= ch.type.scale)
+            nd.maxabs = sat_mul(ch.maxabs, p10(nd.type.scale - ch.type.scale));
+          else if (is_intlike(ch.type) && is_intlike(nd.type)) nd.maxabs = ch.maxabs;
+        } else if (nd.kind == QHIP_EXPR_IF) {
+          const u128 a = nodes[(size_t)nd.right].maxabs, b = nodes[(size_t)nd.third].maxabs;
+          nd.maxabs = a > b ? a : b;
+        }
+      }
+    }
     if (nd.kind == QHIP_EXPR_LITERAL) {
       char buf[96];
       snprintf(buf, sizeof buf, ":%d:%llx:%llx:%a:", nd.lit_null ? 1 : 0, (unsigned long long)nd.lo, (unsigned long long)nd.hi, nd.f);

@@ -20,13 +20,18 @@ struct ENode {
   std::string s;
   DType cast_to;           // CAST target
   std::string canon;       // structural identity (for common-subexpression sharing)
+  // upper bound of |value| over all rows for integer / Decimal128 nodes (the unscaled integer), from the columns' cached
+  // statistics, the literals' values and the operators; kUnbounded = nothing better than the type is known
+  u128 maxabs = ~(u128)0;
 };
+constexpr u128 kUnbounded = ~(u128)0;
 
 struct InputCol {
   DType type;
   bool has_nulls = false;  // null_count > 0 in the table actually being executed
   int utf8_max_len = -1;   // longest value of a Utf8 column in bytes when known (sizes packed join / group keys)
   bool utf8_fixed1 = false;   // every value of the Utf8 column is exactly 1 byte long: offsets[i] == i, nothing to load for them
+  uint64_t value_maxabs = 0;  // DevColumn::value_maxabs (0 = unknown)
 };
 
 struct ExprSet {

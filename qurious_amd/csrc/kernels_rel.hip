@@ -240,6 +240,28 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
   if (qh_lane() == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
+// largest |value| of an Int64 (WORDS = 1) / Decimal128 (WORDS = 2) column: out[0] = max |v| over the values that fit 63 bits,
+// out[1] != 0 when some value does not. NULL slots count too (an upper bound is all the callers need). One atomic per
+// wavefront, none when it would change nothing.
+template <int WORDS>
+__global__ __launch_bounds__(QH_BLOCK) void k_value_maxabs(const u64* v, u64 n, u64* out) {
+  u64 m = 0;
+  u32 big = 0;
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    const u64 lo = v[(size_t)i * WORDS];
+    const u64 hi = WORDS == 2 ? v[(size_t)i * WORDS + 1] : (u64)((i64)lo >> 63);
+    const bool fits = hi == (u64)((i64)lo >> 63);
+    const u64 a = (lo >> 63) ? (u64)0 - lo : lo;
+    if (fits && a < (1ULL << 63)) m = a > m ? a : m; else big = 1;
+  }
+  m = qh_wave_max_u64(m);
+  const u64 anybig = qh_ballot(big != 0);
+  if (qh_lane() == 0) {
+    if (m > __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)__hip_atomic_fetch_max(&out[0], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (anybig && !__hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)__hip_atomic_fetch_or(&out[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ================================================================ hash join
 // JoinHashMap (physical/plan/join/hash_join.rs:39-107) keeps `hash -> last row + 1` and a `next` chain, built in
 // reverse so that chains ascend. Here: an open-addressing table keyed by the REAL key words (so there is no
@@ -754,6 +776,12 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
 }
 void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_utf8_max_len, dim3(grid_for(n, QH_BLOCK, 1024)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (u64)n, (u32*)out);
+}
+void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s) {
+  if (!n) return;
+  const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);
+  if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
+  else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
 }
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, (u32*)p, v); }
 void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first) {

@@ -12,6 +12,16 @@ using namespace qhip;
 static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_nulls, int n) {
   std::vector<InputCol> v;
   for (int k = 0; k < n; ++k) { InputCol c; c.type = DType(t[k]); c.has_nulls = has_nulls && has_nulls[k]; v.push_back(c); }
+  // QHIP_PLAN_VALUE_BITS="3:13,4:24": |value| of column 3 fits 13 bits, ... — the column statistic an execution would find
+  // (relops.cpp ensure_value_bounds), so that the catalog can pre-compile the narrow variants of the benchmark kernels
+  if (const char* e = getenv("QHIP_PLAN_VALUE_BITS")) {
+    int col = 0, bits = 0, used = 0;
+    while (*e && sscanf(e, "%d:%d%n", &col, &bits, &used) == 2) {
+      if (col >= 0 && col < n && bits >= 1 && bits <= 63) v[(size_t)col].value_maxabs = (1ULL << bits) - 1;
+      e += used;
+      if (*e == ',') ++e;
+    }
+  }
   return v;
 }
 static int give(const std::string& s, char* buf, size_t buflen, size_t* needed) {

@@ -2,6 +2,8 @@
 // (JIT), mask -> selection vector (scan + ballot rank), row gather of whole columns, key-word evaluation (JIT).
 #include "relops.hpp"
 
+#include <algorithm>
+
 #include <hip/hip_runtime_api.h>
 
 #include "device/qhip_status.h"
@@ -71,6 +73,28 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
   }
 }
 
+void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
+  for (int k = 0; k < n_exprs; ++k) {
+    const qhip_expr& e = exprs[k];
+    if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
+    const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
+    if (col.type.id != QHIP_DECIMAL128 && col.type.id != QHIP_INT64) continue;
+    if (col.value_maxabs == 0 && col.length >= min_rows && col.values) {
+      DevBuf out(16);
+      QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, 16, ctx->stream));
+      launch_value_maxabs(col.values->ptr, (uint64_t)col.length, col.type.id == QHIP_DECIMAL128 ? 2 : 1, out.as<uint64_t>(), ctx->stream);
+      uint64_t h[2] = {0, 0};
+      copy_sync(ctx->stream, h, out.ptr, 16, hipMemcpyDeviceToHost);
+      col.value_maxabs = h[1] ? ~0ULL : std::max<uint64_t>(h[0], 1);
+    }
+    // the bound enters lowered-plan cache keys: rounded up to a whole number of bits so that plans are shared by data
+    // of the same magnitude
+    uint64_t m = col.value_maxabs;
+    if (m != 0 && m != ~0ULL) { int bits = 1; while (bits < 63 && (m >> bits)) ++bits; m = (1ULL << bits) - 1; }
+    icols[(size_t)e.column].value_maxabs = m;
+  }
+}
+
 DevColumn materialize_upload(Ctx* ctx, const DeferredUpload& u);   // table.cpp
 
 const DevColumn& resolved(Ctx* ctx, const DevColumn& col) {
@@ -95,6 +119,7 @@ const DevColumn& resolved(Ctx* ctx, const DevColumn& col) {
     d.idx.reset();
   }
   if (col.utf8_max_len >= 0 && d.result.utf8_max_len < 0) d.result.utf8_max_len = col.utf8_max_len;
+  if (col.value_maxabs != 0 && d.result.value_maxabs == 0) d.result.value_maxabs = col.value_maxabs;
   // the table keeps the gathered column from now on (tables are immutable to their users; this only fills in a value
   // that was owed). Other tables sharing the DeferredGather find the cached result.
   DevColumn r = d.result;
@@ -114,6 +139,7 @@ void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::share
     o.type = c.type;
     o.length = (int64_t)m;
     o.utf8_max_len = c.utf8_max_len;
+    o.value_maxabs = c.value_maxabs;
     auto d = std::make_shared<DeferredGather>();
     d->m = m;
     if (c.deferred && !c.deferred->done) {
@@ -153,6 +179,7 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, 
   out.type = col.type;
   out.length = (int64_t)m;
   out.utf8_max_len = col.utf8_max_len;   // an upper bound stays an upper bound under gathering
+  out.value_maxabs = col.value_maxabs;
   if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return out; }
   DevBuf counter(4);
   if (col.null_count > 0 || idx_may_be_null) {

@@ -34,6 +34,9 @@ void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, i
 // table and copied into icols (packed key words are sized from it)
 void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,
                              std::vector<InputCol>& icols);
+// |value| bounds of the Int64 / Decimal128 columns the expressions reference (DevColumn::value_maxabs -> icols): computed
+// (one reduction + one read-back per column, cached on the column) only for inputs of `min_rows` rows or more
+void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 // key words [W][N] + validity bitmap of the key expressions `roots`
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
                     KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false);

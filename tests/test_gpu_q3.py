@@ -93,8 +93,14 @@ def test_broadcast_strategy_pieces_on_one_gpu(ctx, oracle):
     keys = [col("l_orderkey", 6)]
     src = exchange.DeviceSource(j2.schema(), joined)
     whole = q.HashAggregate(schema, src, keys, aggs)
-    halves = [q.HashAggregate(schema, q.Limit(src, n // 2, 0), keys, aggs).execute_device(),
-              q.HashAggregate(schema, q.Limit(src, None, n // 2), keys, aggs).execute_device()]
+    # two disjoint parts of the join output that both hold rows of the same groups: by the parity of l_shipdate's day number
+    # (a Limit with OFFSET over this many-batch input would not do: the reference's Limit drops rows of every batch behind the
+    # offset, limit.rs:39-44)
+    from qurious_amd import Operator
+    parity = q.BinaryExpr(q.CastExpr(col("l_shipdate", 7), pa.int32()), Operator.Mod, q.Literal(q.ScalarValue.Int32(2)))
+    part = lambda k: q.Filter(src, q.BinaryExpr(parity, Operator.Eq, q.Literal(q.ScalarValue.Int32(k))))   # noqa: E731
+    halves = [q.HashAggregate(schema, part(0), keys, aggs).execute_device(), q.HashAggregate(schema, part(1), keys, aggs).execute_device()]
+    assert halves[0].num_rows > 10 and halves[1].num_rows > 10
     both = exchange.concat_tables(halves)
     merged = q.HashAggregate(schema, exchange.DeviceSource(schema, both), [col("l_orderkey", 0)], exchange.merge_aggregate_exprs(aggs, 1))
     assert sorted(rows_of(merged.execute())) == sorted(rows_of(whole.execute())) == sorted(rows_of(oracle.execute(q.HashAggregate(schema, j2, keys, aggs))))
