@@ -44,8 +44,21 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
   DevBuf mask, wave, sel;
   hipEventRecord(ctx->ev[0], ctx->stream);
   run_pred_mask(ctx, in, es, icols, root, mask, wave);
-  const uint32_t m = select_from_mask(ctx, mask, wave, in->num_rows, sel);
-  for (int c : cols) out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
+  // rows kept (the one read-back that sizes the output), then every column compacted:
+  //  * a predicate that keeps a good part of the rows (>= 1/8): MASK-DRIVEN — each column is read in row order and its kept
+  //    values written in runs (k_compact_fixed); no selection vector exists unless a column's layout needs one (nullable,
+  //    Boolean, Utf8 of more than 1 byte);
+  //  * a selective predicate: the selection vector (rank inside the ballot word + scanned wave offset) and an index gather
+  //    per column, which reads only the kept values.
+  const uint32_t m = count_from_mask(ctx, wave, in->num_rows);
+  const bool mask_driven = in->num_rows > 0 && (uint64_t)m * 8 >= (uint64_t)in->num_rows && env_int("QHIP_FILTER_NO_COMPACT", 0) == 0;
+  bool have_sel = false;
+  for (int c : cols) {
+    DevColumn oc;
+    if (mask_driven && compact_column(ctx, in->cols[(size_t)c], mask, wave, in->num_rows, m, oc)) { out->cols.push_back(std::move(oc)); continue; }
+    if (!have_sel) { indices_from_mask(ctx, mask, wave, in->num_rows, m, sel); have_sel = true; }
+    out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
+  }
   hipEventRecord(ctx->ev[1], ctx->stream);
   // output batch boundaries = kept rows before each input batch start
   const size_t nb1 = in->offsets().size();

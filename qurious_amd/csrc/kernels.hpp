@@ -19,6 +19,8 @@ void launch_mask_prefix_at(const uint64_t* mask, const uint32_t* wave_offset, co
                            uint32_t* out, hipStream_t s);
 void launch_mask_from_bits(const uint32_t* bits, uint64_t nrows, int want_set, uint64_t* mask, uint32_t* wave_count, hipStream_t s);
 void launch_gather_fixed(const void* in, const uint32_t* idx, void* out, uint64_t m, int width, hipStream_t s);
+// out[wave_offset[j] + rank] = in[64 j + lane] for the set bits of mask word j (mask-driven compaction, row order kept)
+void launch_compact_fixed(const void* in, const uint64_t* mask, const uint32_t* wave_offset, void* out, uint64_t nrows, int width, hipStream_t s);
 void launch_gather_bits(const uint8_t* bitmap, const uint32_t* idx, uint64_t m, uint64_t* out_words, uint32_t* set_count, hipStream_t s);
 void launch_gather_utf8_lengths(const int32_t* offsets, const uint32_t* idx, uint64_t m, uint32_t* out_len, hipStream_t s);
 void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const uint32_t* idx, uint64_t m, const uint32_t* out_off,

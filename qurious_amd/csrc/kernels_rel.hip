@@ -177,6 +177,34 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_fixed(const T* in, const u3
     out[k] = v;
   }
 }
+// Mask-driven compaction of a fixed-width column (Filter with a predicate that keeps a good part of the rows): wavefront
+// word j of the keep mask covers rows 64 j .. 64 j + 63; a kept row's value goes to wave_offset[j] + its rank inside the
+// word. The input is read in row order (fully coalesced, the dropped rows' bytes ride along), the output is written in
+// runs — no selection vector is read per column (the index gather reads 4 bytes of index per kept value and column).
+template <class T>
+__global__ __launch_bounds__(QH_BLOCK) void k_compact_fixed(const T* in, const u64* mask, const u32* wave_offset, T* out, u64 nrows) {
+  const u64 nwords = (nrows + 63) / 64;
+  const u64 wave_global = ((u64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64)gridDim.x * QH_BLOCK) >> 6;
+  const int lane = qh_lane();
+  constexpr int U = 4;   // mask words per trip: their loads are issued together
+  for (u64 j0 = wave_global * U; j0 < nwords; j0 += nwaves * U) {
+    u64 m[U];
+    u32 off[U];
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u64 j = j0 + u < nwords ? j0 + u : nwords - 1;
+      m[u] = j0 + u < nwords ? mask[j] : 0ULL;
+      off[u] = wave_offset[j];
+      const u64 i = j * 64 + lane;
+      v[u] = in[i < nrows ? i : nrows - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((m[u] >> lane) & 1) out[off[u] + (u32)qh_rank(m[u])] = v[u];
+  }
+}
 // validity (or Boolean values) of the gathered rows as one ballot word per 64 output rows, plus the set count
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_bits(const u8* bitmap /* null = all set */, const u32* idx, u64 m, u64* out_words,
                                                          u32* set_count) {
@@ -757,6 +785,17 @@ void launch_gather_fixed(const void* in, const uint32_t* idx, void* out, uint64_
     case 4: hipLaunchKernelGGL(k_gather_fixed<u32>, g, b, 0, s, (const u32*)in, (const u32*)idx, (u32*)out, (u64)m); break;
     case 8: hipLaunchKernelGGL(k_gather_fixed<u64>, g, b, 0, s, (const u64*)in, (const u32*)idx, (u64*)out, (u64)m); break;
     default: hipLaunchKernelGGL(k_gather_fixed<u128>, g, b, 0, s, (const u128*)in, (const u32*)idx, (u128*)out, (u64)m); break;
+  }
+}
+void launch_compact_fixed(const void* in, const uint64_t* mask, const uint32_t* wave_offset, void* out, uint64_t nrows, int width, hipStream_t s) {
+  if (!nrows) return;
+  const dim3 g(grid_for((nrows + 63) / 64 * 64, QH_BLOCK * 4, 8192)), b(QH_BLOCK);
+  switch (width) {
+    case 1: hipLaunchKernelGGL(k_compact_fixed<u8>, g, b, 0, s, (const u8*)in, (const u64*)mask, (const u32*)wave_offset, (u8*)out, (u64)nrows); break;
+    case 2: hipLaunchKernelGGL(k_compact_fixed<u16>, g, b, 0, s, (const u16*)in, (const u64*)mask, (const u32*)wave_offset, (u16*)out, (u64)nrows); break;
+    case 4: hipLaunchKernelGGL(k_compact_fixed<u32>, g, b, 0, s, (const u32*)in, (const u64*)mask, (const u32*)wave_offset, (u32*)out, (u64)nrows); break;
+    case 8: hipLaunchKernelGGL(k_compact_fixed<u64>, g, b, 0, s, (const u64*)in, (const u64*)mask, (const u32*)wave_offset, (u64*)out, (u64)nrows); break;
+    default: hipLaunchKernelGGL(k_compact_fixed<u128>, g, b, 0, s, (const u128*)in, (const u64*)mask, (const u32*)wave_offset, (u128*)out, (u64)nrows); break;
   }
 }
 void launch_gather_bits(const uint8_t* bitmap, const uint32_t* idx, uint64_t m, uint64_t* out_words, uint32_t* set_count, hipStream_t s) {

@@ -38,16 +38,63 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
   check_status_words(status);
 }
 
-uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel) {
+uint32_t count_from_mask(Ctx* ctx, DevBuf& wave_count, int64_t nrows) {
   const uint64_t nwords = (uint64_t)(nrows + 63) / 64;
-  if (nrows == 0) { sel.alloc(0); return 0; }
+  if (nrows == 0) return 0;
   DevBuf total(4);
   exclusive_scan_u32(wave_count.as<uint32_t>(), wave_count.as<uint32_t>(), nwords, total.as<uint32_t>(), ctx->stream);
   uint32_t m = 0;
   copy_sync(ctx->stream, &m, total.ptr, 4, hipMemcpyDeviceToHost);
+  return m;
+}
+
+void indices_from_mask(Ctx* ctx, const DevBuf& mask, const DevBuf& wave_offset, int64_t nrows, uint32_t m, DevBuf& sel) {
   sel.alloc((size_t)m * 4);
-  launch_select_indices(mask.as<uint64_t>(), wave_count.as<uint32_t>(), (uint64_t)nrows, sel.as<uint32_t>(), ctx->stream);
+  if (nrows) launch_select_indices(mask.as<uint64_t>(), wave_offset.as<uint32_t>(), (uint64_t)nrows, sel.as<uint32_t>(), ctx->stream);
+}
+
+uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel) {
+  if (nrows == 0) { sel.alloc(0); return 0; }
+  const uint32_t m = count_from_mask(ctx, wave_count, nrows);
+  indices_from_mask(ctx, mask, wave_count, nrows, m, sel);
   return m;   // consumers run on the same stream: no synchronisation needed here
+}
+
+bool compact_column(Ctx* ctx, const DevColumn& col_in, const DevBuf& mask, const DevBuf& wave_offset, int64_t nrows, uint32_t m, DevColumn& out) {
+  const DevColumn& col = resolved(ctx, col_in);
+  if (col.null_count > 0 || col.type.id == QHIP_BOOL) return false;
+  out = DevColumn();
+  out.type = col.type;
+  out.length = (int64_t)m;
+  out.utf8_max_len = col.utf8_max_len;
+  out.value_maxabs = col.value_maxabs;
+  if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return true; }
+  const int w = dtype_width(col.type);
+  if (w > 0) {
+    out.values = std::make_shared<DevBuf>((size_t)m * w);
+    launch_compact_fixed(col.values->ptr, mask.as<uint64_t>(), wave_offset.as<uint32_t>(), out.values->ptr, (uint64_t)nrows, w, ctx->stream);
+    return true;
+  }
+  if (col.type.id == QHIP_UTF8) {
+    // every value exactly one byte long (TPC-H flags): the data bytes are a 1-byte column, the offsets 0, 1, 2, ...
+    if (col.utf8_max_len < 0) {
+      DevBuf mx(4);
+      QHIP_HIP_CHECK(hipMemsetAsync(mx.ptr, 0, 4, ctx->stream));
+      launch_utf8_max_len(col.values->as<int32_t>(), (uint64_t)col.length, mx.as<uint32_t>(), ctx->stream);
+      uint32_t v = 0;
+      copy_sync(ctx->stream, &v, mx.ptr, 4, hipMemcpyDeviceToHost);
+      col.utf8_max_len = (int32_t)v;
+      out.utf8_max_len = col.utf8_max_len;
+    }
+    if (!(col.utf8_max_len == 1 && col.data_bytes == col.length)) return false;
+    out.values = std::make_shared<DevBuf>(((size_t)m + 1) * 4);
+    launch_iota_u32(out.values->as<uint32_t>(), (uint64_t)m + 1, ctx->stream, 0);
+    out.data = std::make_shared<DevBuf>((size_t)m + 64);
+    out.data_bytes = (int64_t)m;
+    launch_compact_fixed(col.data->ptr, mask.as<uint64_t>(), wave_offset.as<uint32_t>(), out.data->ptr, (uint64_t)nrows, 1, ctx->stream);
+    return true;
+  }
+  return false;
 }
 
 void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,

@@ -19,6 +19,13 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
                    DevBuf& wave_count);
 // wave_count is scanned in place into per-wave output offsets; sel receives the kept row indices; returns their number
 uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel);
+// ... in two steps: count_from_mask scans and returns the number of kept rows, indices_from_mask fills `sel` when (and if)
+// somebody needs the selection vector
+uint32_t count_from_mask(Ctx* ctx, DevBuf& wave_count, int64_t nrows);
+void indices_from_mask(Ctx* ctx, const DevBuf& mask, const DevBuf& wave_offset, int64_t nrows, uint32_t m, DevBuf& sel);
+// Mask-driven compaction of one column (null when the column's layout needs the selection vector: nullable, Boolean,
+// Utf8 with values of more than one byte): out[k] = the k-th kept row's value, read in row order
+bool compact_column(Ctx* ctx, const DevColumn& col, const DevBuf& mask, const DevBuf& wave_offset, int64_t nrows, uint32_t m, DevColumn& out);
 // out[k] = col[idx[k]] (device u32 indices, kNullIdx -> NULL when idx_may_be_null)
 DevColumn gather_column(Ctx* ctx, const DevColumn& col, const uint32_t* idx, uint64_t m, bool idx_may_be_null);
 // The column itself, gathered now if it was deferred (the result is cached in the column's DeferredGather).
