@@ -183,7 +183,13 @@ void ExprGen::emit(int k, std::string& out) {
         {
           // streaming (non-temporal) loads when asked for: column values are read once; Decimal128 goes through a 4 x u32
           // vector (the builtin takes integer / float / vector types)
-          const std::string addr = "((const " + ctype(n.type) + "*)a.c[" + S + "].v" + base_ + ")[" + idx_ + "]";
+          // tile-relative indexing (uniform 64-bit tile base + 32-bit lane offset): the lane offset is turned into BYTES in 32
+          // bits, so that the load is `global_load v, v_offset32, s[base]` — one VALU instruction for the address instead of a
+          // 64-bit shift-add per column and row (a tile is far smaller than 4 GB / 16)
+          const std::string T = ctype(n.type);
+          const std::string addr = base_.empty() ? "((const " + T + "*)a.c[" + S + "].v)[" + idx_ + "]"
+                                                 : "(*(const " + T + "*)((const char*)((const " + T + "*)a.c[" + S + "].v" + base_ + ") + (size_t)((u32)(" + idx_ +
+                                                       ") * (u32)sizeof(" + T + "))))";
           std::string rhs = addr;
           if (nt_ && n.type.id == QHIP_DECIMAL128) rhs = "qh_nt_load_i128(&" + addr + ")";
           else if (nt_) rhs = "__builtin_nontemporal_load(&" + addr + ")";

@@ -885,7 +885,8 @@ __device__ __forceinline__ void qh_probe_stage2(const KArgs& a, const ProbeLaunc
     x.at[r] = (c.regions ? reg << L.slot_bits : 0u) + ((u32)h & c.smask);
     x.fm[r] = c.regions ? qh_rfilter_mask(h, L.slot_bits, L.bword_bits) : qh_filter_mask((u32)h);
     const u32 word = c.regions ? (reg << L.bword_bits) + qh_rfilter_word(h, L.slot_bits, L.bword_bits) : qh_filter_word(h, L.bloom_mask);
-    x.fw[r] = L.bloom[(x.ok[r] && !(L.dbg & 4u)) ? word : 0u];
+    // (32-bit byte offset from the scalar base: the filter holds < 2^29 words)
+    x.fw[r] = *(const u64*)((const char*)L.bloom + (size_t)(((x.ok[r] && !(L.dbg & 4u)) ? word : 0u) << 3));
   }
 }
 // stage 3: filter test, issue the home-slot loads of the rows that pass

@@ -57,6 +57,18 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
     DevColumn oc;
     if (mask_driven && compact_column(ctx, in->cols[(size_t)c], mask, wave, in->num_rows, m, oc)) { out->cols.push_back(std::move(oc)); continue; }
     if (!have_sel) { indices_from_mask(ctx, mask, wave, in->num_rows, m, sel); have_sel = true; }
+    {
+      // (a Utf8 column's longest value decides whether its gather needs a length scan: found once per column, cached)
+      const DevColumn& src = resolved(ctx, in->cols[(size_t)c]);
+      if (src.type.id == QHIP_UTF8 && src.utf8_max_len < 0 && src.length > 0) {
+        DevBuf mx(4);
+        QHIP_HIP_CHECK(hipMemsetAsync(mx.ptr, 0, 4, ctx->stream));
+        launch_utf8_max_len(src.values->as<int32_t>(), (uint64_t)src.length, mx.as<uint32_t>(), ctx->stream);
+        uint32_t v = 0;
+        copy_sync(ctx->stream, &v, mx.ptr, 4, hipMemcpyDeviceToHost);
+        src.utf8_max_len = (int32_t)v;
+      }
+    }
     out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
   }
   hipEventRecord(ctx->ev[1], ctx->stream);

@@ -3,6 +3,7 @@
 //   Arrow layout on the path, and the hash-join build / probe kernels.
 // Reference operators they replace are cited per kernel (paths relative to /root/reference/qurious/src).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -391,7 +392,7 @@ template <int W>
 __global__ __launch_bounds__(QH_REGION_BLOCK) void k_join_region_build(const u64* entries, const u32* first, u32 n_wgs, u32 n_regions,
                                                                         u32 rows_per_wg, u64* table, u64* bloom, u32 slot_bits,
                                                                         u32 bword_bits, u32* status) {
-  constexpr int RB = QH_REGION_BLOCK;
+  constexpr u32 RB = QH_REGION_BLOCK;
   const u32 S = 1u << slot_bits, BW = 1u << bword_bits, tid = threadIdx.x;
   // XCD-aware region order: workgroups b, b + 8, b + 16, ... share an XCD (and its L2), so they take CONSECUTIVE regions. A
   // step-1 workgroup's entries of neighbouring regions lie next to each other (4 regions per 128-byte line, 16 per line

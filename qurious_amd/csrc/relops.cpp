@@ -247,6 +247,14 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, 
     out.values = std::make_shared<DevBuf>(((m + 63) / 64) * 8 + 8);
     QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 4, ctx->stream));
     launch_gather_bits(col.values->as<uint8_t>(), idx, m, out.values->as<uint64_t>(), counter.as<uint32_t>(), ctx->stream);
+  } else if (col.type.id == QHIP_UTF8 && !idx_may_be_null && col.utf8_max_len == 1 && col.data_bytes == col.length) {
+    // every value exactly one byte long (TPC-H flags; known once the column was a key or went through a Filter): the data
+    // bytes gather like a 1-byte column, the offsets are 0, 1, 2, ... — no length scan, no read-back of the byte total
+    out.values = std::make_shared<DevBuf>((size_t)(m + 1) * 4);
+    launch_iota_u32(out.values->as<uint32_t>(), m + 1, ctx->stream, 0);
+    out.data = std::make_shared<DevBuf>((size_t)m + 64);
+    out.data_bytes = (int64_t)m;
+    launch_gather_fixed(col.data->ptr, idx, out.data->ptr, m, 1, ctx->stream);
   } else if (col.type.id == QHIP_UTF8) {
     out.values = std::make_shared<DevBuf>((size_t)(m + 1) * 4);
     uint32_t* off = out.values->as<uint32_t>();
