@@ -70,7 +70,9 @@ typedef enum qhip_status {
   QHIP_HIP_ERROR = 3,        /* HIP runtime / hiprtc failure, or no usable gfx950 device */
   QHIP_OUT_OF_MEMORY = 4,
   QHIP_EXEC_ERROR = 5,       /* data-dependent failure the reference also reports (divide by zero, cast overflow, AVG overflow) */
-  QHIP_RCCL_ERROR = 6
+  QHIP_RCCL_ERROR = 6,
+  QHIP_RETRY = 7             /* a hash join below ran without waiting for its output size (qhip_ctx_allow_deferred_sizes) and the
+                              * room it had assumed did not hold: the hint has been dropped, execute the input plan again */
 } qhip_status;
 
 typedef struct qhip_ctx qhip_ctx;
@@ -196,6 +198,22 @@ int qhip_device_available(void);
  * device pointers (qhip_table_column_buffer) to another stream or library. Downloads (qhip_table_to_arrow) wait by themselves. */
 int qhip_ctx_synchronize(qhip_ctx* ctx);
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out);
+/* Host waits on the device (stream / event synchronisations) this process has made through the library so far: the
+ * "host round trips" a plan costs = the difference around its execution. */
+uint64_t qhip_ctx_sync_count(const qhip_ctx* ctx);
+/* Deferred sizing. A hash join normally waits for its pair total to size its output (one host round trip per join). It
+ * also remembers, per join (expressions, join type, probe rows — not the data), how many pairs it produced. While
+ * deferred sizes are allowed, an Inner join with such a hint does NOT wait: its output is allocated for the remembered
+ * count plus headroom, the real count stays on the device (the kernels of HashAggregate and of a hash join's build side
+ * read it there) and the join's status words + total go to page-locked memory, checked by the plan's next natural
+ * synchronisation (the aggregate / join above). More pairs than the room, or duplicate build keys: the hint is dropped and
+ * THAT call returns QHIP_RETRY — discard its input and execute the input plan again (it will wait this time). Because
+ * the check happens in the CONSUMER's call, allow it only around the execution of a child whose output goes straight
+ * into qhip_hash_aggregate_execute (input) or qhip_hash_join_execute (left / build side) with nothing executed in
+ * between: delta = +1 before the child, -1 after it (the host mirrors do this); delta = 0 resets (after an error).
+ * Any other consumer of such a table (Filter, Sort, export, ...) first waits and makes the row count exact by itself.
+ * No reference counterpart. */
+int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta);
 int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
 
 /* ---------------------------------------------------------------- tables (Vec<RecordBatch> in HBM) */

@@ -222,6 +222,11 @@ struct PhysicalPlan {
   // the batches stay in HBM between two accelerated operators
   virtual DeviceTableRef execute_device() const = 0;
   virtual std::vector<std::shared_ptr<const PhysicalPlan>> children() const { return {}; }
+  // the context of the first table below this node (null when there is none)
+  virtual ContextRef context() const {
+    for (const auto& c : children()) if (ContextRef x = c->context()) return x;
+    return nullptr;
+  }
   // PhysicalPlan::execute (physical/plan/mod.rs:27): the whole result as host batches
   std::vector<RecordBatch> execute() const {
     DeviceTableRef t = execute_device();
@@ -258,6 +263,24 @@ inline DeviceTableRef wrap(const ContextRef& ctx, int rc, qhip_table* t) {
   ctx->check(rc);
   return std::make_shared<DeviceTable>(ctx, t);
 }
+// Deferred sizing (qhip.h: qhip_ctx_allow_deferred_sizes). feed(): execute `node` as the input of an operator that reads a
+// device-side row count (HashAggregate's input, a hash join's build side); the consumer runs right after, inside retrying().
+inline DeviceTableRef feed(const PhysicalPlan& node) {
+  struct Allow {
+    ContextRef c;
+    explicit Allow(ContextRef x) : c(std::move(x)) { if (c) qhip_ctx_allow_deferred_sizes(c->raw(), +1); }
+    ~Allow() { if (c) qhip_ctx_allow_deferred_sizes(c->raw(), -1); }
+  } allow(node.context());
+  return node.execute_device();
+}
+// run() = execute the input(s), then the operator. QHIP_RETRY: a join of deferred size below had too little room and has
+// forgotten its hint — the second run waits for the size.
+template <class F> DeviceTableRef retrying(F&& run) {
+  for (int attempt = 0;; ++attempt) {
+    try { return run(); }
+    catch (const Error& e) { if (e.code != QHIP_RETRY || attempt == 2) throw; }
+  }
+}
 inline DeviceTableRef filter(const DeviceTableRef& in, const ExprRef& predicate) {
   ExprArray ea;
   const int root = predicate ? predicate->lower(ea) : -1;
@@ -273,6 +296,7 @@ struct Scan : PhysicalPlan {   // scan.rs + MemoryTable::scan (memory.rs:69-98):
   DeviceTableRef execute_device() const override {
     return filter ? detail::filter(datasource->device_table(), filter) : datasource->device_table();
   }
+  ContextRef context() const override { return datasource->ctx(); }
 };
 struct Filter : PhysicalPlan {   // filter.rs:12-48
   PlanRef input; ExprRef predicate;
@@ -300,11 +324,12 @@ struct HashAggregate : PhysicalPlan {   // aggregate/hash.rs:110-176; a Scan(fil
   PlanRef input; std::vector<ExprRef> group_exprs; std::vector<AggregateExpr> aggregate_exprs; std::vector<std::string> names;
   HashAggregate(std::vector<std::string> n, PlanRef i, std::vector<ExprRef> g, std::vector<AggregateExpr> a)
       : input(std::move(i)), group_exprs(std::move(g)), aggregate_exprs(std::move(a)), names(std::move(n)) {}
-  DeviceTableRef execute_device() const override {
+  DeviceTableRef execute_device() const override { return detail::retrying([&] { return execute_once(); }); }
+  DeviceTableRef execute_once() const {
     DeviceTableRef in;
     ExprRef pred;
     if (auto scan = dynamic_cast<const Scan*>(input.get()); scan && scan->filter) { in = scan->datasource->device_table(); pred = scan->filter; }
-    else in = input->execute_device();
+    else in = detail::feed(*input);
     ExprArray ea;
     const int proot = pred ? pred->lower(ea) : -1;
     std::vector<int32_t> groups;
@@ -338,7 +363,8 @@ struct HashJoinExec : PhysicalPlan {   // join/hash_join.rs:110-384 — build = 
     j->left = std::move(l); j->right = std::move(r); j->join_type = jt; j->on = std::move(on); j->filter = std::move(f);
     return j;
   }
-  DeviceTableRef execute_device() const override {
+  DeviceTableRef execute_device() const override { return detail::retrying([&] { return execute_once(); }); }
+  DeviceTableRef execute_once() const {
     // an Inner join takes Scan(filter) children as (unfiltered table, predicate): the filter is fused into the key kernels
     auto side = [&](const PlanRef& p, ExprRef& pred) -> DeviceTableRef {
       if (auto scan = dynamic_cast<const Scan*>(p.get()); scan && scan->filter && join_type == QHIP_JOIN_INNER) {
@@ -348,7 +374,12 @@ struct HashJoinExec : PhysicalPlan {   // join/hash_join.rs:110-384 — build = 
       return p->execute_device();
     };
     ExprRef lpred, rpred;
-    DeviceTableRef lt = side(left, lpred), rt = side(right, rpred);
+    // the build side may arrive with a device-side row count when nothing executes between it and this join: the probe
+    // side is a table access (a Scan: fused, or without a filter)
+    const Scan* rscan = dynamic_cast<const Scan*>(right.get());
+    const bool right_is_table = rscan && (!rscan->filter || join_type == QHIP_JOIN_INNER);
+    DeviceTableRef lt = right_is_table && !dynamic_cast<const Scan*>(left.get()) ? detail::feed(*left) : side(left, lpred);
+    DeviceTableRef rt = side(right, rpred);
     ExprArray le, re, fe;
     std::vector<int32_t> on_l, on_r, fsides, fcols;
     for (auto& kv : on) { on_l.push_back(kv.first->lower(le)); on_r.push_back(kv.second->lower(re)); }

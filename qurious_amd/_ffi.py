@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqhip.so")
 
 # status codes (include/qhip.h)
-QHIP_OK, QHIP_INVALID_ARGUMENT, QHIP_UNSUPPORTED, QHIP_HIP_ERROR, QHIP_OUT_OF_MEMORY, QHIP_EXEC_ERROR, QHIP_RCCL_ERROR = range(7)
+QHIP_OK, QHIP_INVALID_ARGUMENT, QHIP_UNSUPPORTED, QHIP_HIP_ERROR, QHIP_OUT_OF_MEMORY, QHIP_EXEC_ERROR, QHIP_RCCL_ERROR, QHIP_RETRY = range(8)
 
 
 class QuriousError(Exception):
@@ -44,7 +44,14 @@ class HipError(QuriousError):
     pass
 
 
+class RetryInput(QuriousError):
+    """QHIP_RETRY: a hash join below ran without waiting for its output size and its room did not hold — the operator
+    that reports it re-executes its input (plan.py: `_retrying`); never reaches a caller of ``execute()``."""
+
+
 def _raise(code: int, msg: str):
+    if code == QHIP_RETRY:
+        raise RetryInput(code, msg)
     if code == QHIP_UNSUPPORTED:
         raise UnsupportedError(code, msg)
     if code in (QHIP_HIP_ERROR, QHIP_OUT_OF_MEMORY, QHIP_RCCL_ERROR):
@@ -125,6 +132,8 @@ def load_library() -> C.CDLL:
             "qhip_device_available": (C.c_int, []),
             "qhip_ctx_last_stats": (C.c_int, [vp, P(qhip_exec_stats)]),
             "qhip_ctx_synchronize": (C.c_int, [vp]),
+            "qhip_ctx_sync_count": (C.c_uint64, [vp]),
+            "qhip_ctx_allow_deferred_sizes": (C.c_int, [vp, i32]),
             "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
@@ -192,6 +201,13 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.qhip_ctx_synchronize(self.handle))
+
+    def sync_count(self) -> int:
+        """Host waits on the device made through the library so far (the difference around a plan = its round trips)."""
+        return int(self.lib.qhip_ctx_sync_count(self.handle))
+
+    def allow_deferred_sizes(self, delta: int):
+        self.lib.qhip_ctx_allow_deferred_sizes(self.handle, int(delta))
 
     def measure_stream_read(self, nbytes: int = 1 << 32, iters: int = 5) -> float:
         """Achieved GB/s of a plain streaming-read kernel over `nbytes` of HBM (the practical bandwidth ceiling)."""

@@ -63,7 +63,7 @@ DevColumn upload_host_column(Ctx* ctx, const DeferredUpload& u) {
   } else if (hc.type.id != QHIP_NULL) {
     dc.values = up(hc.values.data(), hc.values.size());
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the host vectors may go away with the DeferredUpload
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the host vectors may go away with the DeferredUpload
   return dc;
 }
 
@@ -117,6 +117,7 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
     QHIP_HIP_CHECK(hipMemcpyAsync(strlit_dev.ptr, b.strlits.data(), b.strlits.size(), hipMemcpyHostToDevice, ctx->stream));
   a.strlit = (const uint8_t*)strlit_dev.ptr;
   a.nrows = t->num_rows;
+  a.nrows_dev = t->rows_dev;   // (a join output whose size the host has not waited for: aggregate / join build only)
 }
 
 void check_status_words(const uint32_t* st) {
@@ -210,13 +211,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     nullable.push_back(true);
   }
   const bool zero_batches_in = in->no_batches();
-  if (n_groups > 0 && zero_batches_in) {
-    // hash.rs:146-148: no input batches -> no output batches
+  auto no_batches_out = [&] {   // hash.rs:146-148: no input batches -> no output batches
     std::vector<HostColumn> cols((size_t)(n_groups + n_aggs));
     for (int k = 0; k < n_groups; ++k) cols[(size_t)k].init_fixed(plan.keys[(size_t)k].type, 0);
     for (int k = 0; k < n_aggs; ++k) cols[(size_t)(n_groups + k)].init_fixed(plan.aggs[(size_t)k].ret, 0);
     return table_from_host(ctx, names, nullable, cols, 0, true);
-  }
+  };
+  if (n_groups > 0 && zero_batches_in) return no_batches_out();
 
   std::shared_ptr<Module> mod = get_module(ctx, plan.source, plan.kernel_name);
   HKArgs ka;
@@ -287,7 +288,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   uint32_t G = 0, guess = 0;
   std::vector<uint64_t> slots;
   // dense slots fetched together with the status words (one sync), through the context's page-locked scratch
-  const uint32_t PRE = (uint32_t)std::min<size_t>(256, (ctx->pinned_bytes - 64 - 8 - 1024) / (size_t)slot_bytes);
+  // (256 of them, or what the plan produced last time plus a quarter while that stays a host-side result)
+  const size_t pre_want = plan.last_groups > 4096 ? 256 : std::max<size_t>(256, std::min<size_t>(4096, (size_t)plan.last_dense + (size_t)plan.last_dense / 4));
+  const uint32_t PRE = (uint32_t)std::min<size_t>(pre_want, (ctx->pinned_bytes - 64 - 8 - 1024) / (size_t)slot_bytes);
   uint32_t* status_pinned = (uint32_t*)ctx->pinned;
   uint64_t* pre_host = (uint64_t*)((uint8_t*)ctx->pinned + 64);
   uint32_t* fin_pinned = (uint32_t*)((uint8_t*)ctx->pinned + ctx->pinned_bytes - 1024);   // [status words (8) | null counts (<= 248)]
@@ -372,9 +375,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned + QS_WORDS, F.nulls_dev.ptr, (size_t)ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
   };
   // (call after the stream has been synchronised at least up to the read-backs above)
-  auto finish_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t groups) -> qhip_table* {
+  auto finish_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t groups, bool synced) -> qhip_table* {
     const int ncols = n_groups + n_aggs;
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!synced) QHIP_HIP_CHECK(sync_stream(ctx->stream));   // (the speculative launch sat in front of the call's one wait)
     if (fin_pinned[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
     F.out->num_rows = groups;
     F.out->batch_offsets = {0, (int64_t)groups};
@@ -396,7 +399,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         launch_agg_utf8_key_bytes(dense, groups, plan.slot_words, F.fc[(size_t)k].src_word, off, col.data->as<uint8_t>(), ctx->stream);
       }
     }
-    if (F.has_utf8) QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the dense slots are released on return
+    if (F.has_utf8) QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the dense slots are released on return
     return F.out.release();
   };
 
@@ -494,7 +497,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       uint32_t* first = (uint32_t*)((uint8_t*)ctx->pinned + 128);
       QHIP_HIP_CHECK(hipMemcpy2DAsync(first, 4, hist.ptr, (size_t)g1 * 4, 4, n_bins, hipMemcpyDeviceToHost, s));
       QHIP_HIP_CHECK(hipMemcpyAsync(first + n_bins, hist.as<uint32_t>() + n_hist, 4, hipMemcpyDeviceToHost, s));
-      QHIP_HIP_CHECK(hipStreamSynchronize(s));
+      QHIP_HIP_CHECK(sync_stream(s));
+      verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
       // work items: a bin, or a slice of a big one (a heavy key's bin is aggregated by several workgroups, each merging
       // its LDS table into the HBM table: the key is merged once per slice, not once per row)
       const uint32_t max_item = (uint32_t)std::max(4096, env_int("QHIP_AGG_PARTITION_ITEM", 32768));
@@ -512,7 +516,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         void* rargs[] = {&rl, &L};
         const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 4);
         QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, s, rargs, nullptr));
-        QHIP_HIP_CHECK(hipStreamSynchronize(s));   // hist / records / items go back to the pool here; item_first is pageable
+        QHIP_HIP_CHECK(sync_stream(s));   // hist / records / items go back to the pool here; item_first is pageable
       }
 
     } else if (N > 0)
@@ -557,13 +561,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       QHIP_HIP_CHECK(hipMemsetAsync(arena->ptr, 0, zero_bytes, ctx->stream));
       plan.arena_clean = true;
       mark("launched");
-      QHIP_HIP_CHECK(hipEventSynchronize(ctx->ev[2]));
+      QHIP_HIP_CHECK(sync_event(ctx->ev[2]));
     } else {
       mark("launched");
-      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      QHIP_HIP_CHECK(sync_stream(ctx->stream));
     }
     memcpy(status, status_pinned, sizeof(status));
     mark("synchronised");
+    verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
+    // a join of deferred size that turned out to have produced nothing has no output batches (hash_join.rs:363-372)
+    if (in->rows_dev && in->rows_host && *in->rows_host == 0 && n_groups > 0) return no_batches_out();
     QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;
@@ -582,6 +589,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     slots.assign(pre_host, pre_host + plan.slot_words);
   } else {
     G = (uint32_t)pre_host[0];
+    plan.last_dense = G;
     const uint32_t total_slots = cap * replicas;
     if (G > guess) {
       // more groups than the speculative buffer holds: compact again with the exact size
@@ -590,12 +598,12 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
       dense_dev = dense.as<uint64_t>();
       launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
-      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      QHIP_HIP_CHECK(sync_stream(ctx->stream));
     }
     if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
       // the speculative device-side assembly is the result
       plan.last_groups = G;
-      qhip_table* result = finish_device_finalize(spec, dense_dev + 1, G);
+      qhip_table* result = finish_device_finalize(spec, dense_dev + 1, G, true);
       ctx->stats.main_kernel_ms = main_ms;
       ctx->stats.total_device_ms = main_ms;
       ctx->stats.rows_in = N;
@@ -691,7 +699,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe
     DevFinal fin;
     enqueue_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, nullptr);
-    qhip_table* result = finish_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G);
+    qhip_table* result = finish_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, false);
     set_stats();
     return result;
   }
@@ -819,5 +827,17 @@ extern "C" int qhip_hash_aggregate_execute(qhip_ctx* ctx, const qhip_table* inpu
                                            int32_t n_aggs, const char* const* out_names, qhip_table** out) {
   if (!ctx || !input || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = hash_aggregate(ctx, input, exprs, n_exprs, predicate_root, group_roots, n_groups, aggs, n_aggs, out_names); });
+  return guarded(ctx, [&] {
+    try {
+      std::unique_ptr<qhip_table> r(hash_aggregate(ctx, input, exprs, n_exprs, predicate_root, group_roots, n_groups, aggs, n_aggs, out_names));
+      if (!ctx->pending_sizes.empty()) {   // (a path that never waited: the joins of deferred size below are checked all the same)
+        QHIP_HIP_CHECK(sync_stream(ctx->stream));
+        verify_pending_sizes(ctx);
+      }
+      *out = r.release();
+    } catch (...) {
+      ctx->pending_sizes.clear();
+      throw;
+    }
+  });
 }

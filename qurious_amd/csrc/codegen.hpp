@@ -90,6 +90,7 @@ struct AggPlan {
   std::string source;          // policy struct + extern "C" kernel, to be appended to the device header
   std::string kernel_name;
   mutable uint32_t last_groups = 0;   // groups the plan produced the last time it ran (sizes the first table attempt)
+  mutable uint32_t last_dense = 0;    // ... and the occupied slots over all table replicas (sizes the one read-back)
   // the small replicated first-attempt table of a plan that keeps producing few groups is kept between calls, zeroed at
   // the END of a call (off the critical path): [status words | dense counter | table | dense slots]
   mutable std::shared_ptr<void> arena;

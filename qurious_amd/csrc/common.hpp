@@ -77,11 +77,17 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
 };
 
+// Every host wait on the device goes through these two (counted: qhip_ctx_sync_count, the "host round trips" of a plan)
+uint64_t& sync_counter();
+void note_sync();   // counts; QHIP_SYNC_TRACE=1 prints who waits (ctx.cpp)
+inline hipError_t sync_stream(hipStream_t s) { note_sync(); return hipStreamSynchronize(s); }
+inline hipError_t sync_event(hipEvent_t e) { note_sync(); return hipEventSynchronize(e); }
+
 // Copy ordered after everything queued on `s` (the context's stream is non-blocking: a plain hipMemcpy on the null stream
 // would NOT wait for it), and complete on return.
 inline void copy_sync(hipStream_t s, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
   if (n) QHIP_HIP_CHECK(hipMemcpyAsync(dst, src, n, kind, s));
-  QHIP_HIP_CHECK(hipStreamSynchronize(s));
+  QHIP_HIP_CHECK(sync_stream(s));
 }
 
 // One column of a device table, concatenated over all batches, Arrow layout.
@@ -156,7 +162,19 @@ struct qhip_table {
   mutable std::shared_ptr<qhip::DevBuf> offsets_dev;
   int64_t num_batches() const { return (int64_t)offsets().size() - 1; }
   bool no_batches() const { return !pending_offsets && batch_offsets.size() <= 1; }   // the empty Vec<RecordBatch>
+  // Deferred sizing (hash join, join.cpp): the join did not wait for its pair total. num_rows is then a CAPACITY, the real
+  // count is *rows_dev on the device (*rows_host once the stream has been synchronised) and rows [count, num_rows) repeat
+  // row 0 of both sides (valid to gather, never counted). HashAggregate and a hash join's build side read such a table as
+  // it is (their kernels stop at *rows_dev); every other reader calls settle_rows() first.
+  mutable std::shared_ptr<qhip::DevBuf> rows_blk;   // the join's own status block [build | probe | pair total]
+  mutable const uint32_t* rows_dev = nullptr;       // -> the pair total inside rows_blk
+  mutable const uint32_t* rows_host = nullptr;      // -> its page-locked copy
 };
+namespace qhip {
+// Make num_rows exact: wait for the stream, check the deferred joins' status words (verify_pending_sizes; may throw
+// QHIP_RETRY) and shrink the table to its real row count. No-op for ordinary tables.
+void settle_rows(const qhip_table* t);
+}
 
 namespace qhip {
 
@@ -174,6 +192,19 @@ struct Ctx {
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
   std::unordered_set<uint64_t> join_dup_builds;   // build sides (key policy x row count) seen with duplicate keys: no speculation
+  // Deferred sizing. A hash join remembers how many pairs it produced (keyed by its expressions, type and probe rows, NOT
+  // by the data). The next time the same join runs under a consumer that can read a device-side row count
+  // (allow_deferred_sizes > 0: HashAggregate's input, a hash join's build side) it does not wait for its pair total: the
+  // output is allocated for that many pairs plus headroom, the count stays on the device, and the status block + total
+  // are copied to a page-locked slot (PendingSize) that the plan's next natural synchronisation checks
+  // (verify_pending_sizes): more pairs than the capacity / duplicate build keys -> the hint is dropped and the consumer
+  // returns QHIP_RETRY (its input is re-executed, this time waiting).
+  std::unordered_map<uint64_t, uint64_t> join_size_hints;
+  struct PendingSize { uint32_t* slot; uint64_t key; uint64_t capacity; uint64_t dup_hint; };
+  std::vector<PendingSize> pending_sizes;
+  uint32_t* size_slots = nullptr;   // page-locked ring: kSizeSlots x 32 words
+  int size_slot_next = 0;
+  int allow_deferred_sizes = 0;
   void* pinned = nullptr;            // small page-locked scratch for status / result read-backs (truly asynchronous D2H)
   size_t pinned_bytes = 0;
   // two page-locked 8 MB slots through which uploads of MANY SMALL batches are coalesced (table.cpp), made on first use
@@ -207,6 +238,11 @@ template <class F> int guarded(qhip_ctx* c, F&& f) {
     return QHIP_INVALID_ARGUMENT;
   }
 }
+constexpr int kSizeSlots = 64;
+// After a stream synchronisation: check what the deferred-size joins left behind. Throws QHIP_RETRY (and forgets the
+// hint) when a join produced more pairs than it had room for or met duplicate build keys — what was computed from its
+// output is then garbage and the consumer's input runs again; key / filter errors surface as they would have in the join.
+void verify_pending_sizes(Ctx* ctx);
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;

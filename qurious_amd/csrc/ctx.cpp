@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <atomic>
+#include <execinfo.h>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -13,6 +14,52 @@
 #include "device/qhip_status.h"
 
 namespace qhip {
+
+uint64_t& sync_counter() { static uint64_t n = 0; return n; }
+void note_sync() {
+  ++sync_counter();
+  static const bool trace = env_int("QHIP_SYNC_TRACE", 0) != 0;
+  if (trace) {
+    void* frames[6];
+    const int n = backtrace(frames, 6);
+    fprintf(stderr, "[qhip] host wait #%llu\n", (unsigned long long)sync_counter());
+    backtrace_symbols_fd(frames + 1, n - 1, 2);
+  }
+}
+
+void verify_pending_sizes(Ctx* ctx) {
+  if (ctx->pending_sizes.empty()) return;
+  std::vector<Ctx::PendingSize> pend;
+  pend.swap(ctx->pending_sizes);
+  std::string why;
+  for (const Ctx::PendingSize& p : pend) {
+    const uint32_t* build = p.slot;                    // [build status | probe status | pair total]
+    const uint64_t total = p.slot[2 * QS_WORDS];
+    if (build[QS_MAXCOUNT] > 1) {                      // duplicate build keys after all: remember, run again the careful way
+      if (ctx->join_dup_builds.size() > 4096) ctx->join_dup_builds.clear();
+      ctx->join_dup_builds.insert(p.dup_hint);
+      ctx->join_size_hints.erase(p.key);
+      why = "duplicate build keys";
+      continue;
+    }
+    if (build[QS_OVERFLOW]) { ctx->join_size_hints.erase(p.key); why = "build table overflow"; continue; }
+    if (total > p.capacity) {
+      ctx->join_size_hints.erase(p.key);
+      why = std::to_string(total) + " pairs, room for " + std::to_string(p.capacity);
+      continue;
+    }
+    ctx->join_size_hints[p.key] = total;
+  }
+  if (!why.empty()) fail(QHIP_RETRY, "a hash join that did not wait for its size has to run again (" + why + ")");
+  // data-dependent errors of the key / filter expressions surface exactly as they would have in the join's own call
+  for (const Ctx::PendingSize& p : pend)
+    for (const uint32_t* st : {(const uint32_t*)p.slot, (const uint32_t*)p.slot + QS_WORDS}) {
+      if (st[QS_KEY_TOO_LONG]) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than its packed key words (expression keys: 7 bytes)");
+      if (st[QS_DIV_ZERO]) fail(QHIP_EXEC_ERROR, "Arrow error: Divide by zero error");
+      if (st[QS_CAST_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Cast error: value out of range for the target type");
+      if (st[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "Arrow error: Arithmetic overflow: Overflow happened on integer division");
+    }
+}
 
 static std::mutex g_err_mu;
 static std::string g_err;
@@ -269,7 +316,16 @@ const char* qhip_last_error(const qhip_ctx* ctx) {
 
 int qhip_ctx_synchronize(qhip_ctx* ctx) {
   if (!ctx) return QHIP_INVALID_ARGUMENT;
-  return guarded(ctx, [&] { QHIP_HIP_CHECK(hipSetDevice(ctx->device)); QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream)); });
+  return guarded(ctx, [&] { QHIP_HIP_CHECK(hipSetDevice(ctx->device)); QHIP_HIP_CHECK(sync_stream(ctx->stream)); });
+}
+
+uint64_t qhip_ctx_sync_count(const qhip_ctx*) { return qhip::sync_counter(); }
+
+int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta) {
+  if (!ctx) return QHIP_INVALID_ARGUMENT;
+  if (delta == 0) { ctx->allow_deferred_sizes = 0; ctx->pending_sizes.clear(); }   // reset (after an error above a deferred join)
+  else ctx->allow_deferred_sizes = std::max(0, ctx->allow_deferred_sizes + (int)delta);
+  return QHIP_OK;
 }
 
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
@@ -278,7 +334,7 @@ int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
     // operators do not wait for their last kernels just to time them: the events are read here
     qhip_ctx* c = const_cast<qhip_ctx*>(ctx);
     float ms = 0;
-    if (hipEventSynchronize(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.total_device_ms = ms;
+    if (sync_event(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.total_device_ms = ms;
     if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.main_kernel_ms = ms;
     if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->stats.build_ms = ms;   // (hash join)
     else if (c->stats_timing_pending == 1) c->stats.main_kernel_ms = c->stats.total_device_ms;
@@ -299,7 +355,7 @@ int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[2], ctx->stream));
     for (int k = 0; k < iters; ++k) launch_stream_read(buf.ptr, (uint64_t)bytes, sink.as<uint32_t>(), blocks, ctx->stream);
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[3], ctx->stream));
-    QHIP_HIP_CHECK(hipEventSynchronize(ctx->ev[3]));
+    QHIP_HIP_CHECK(sync_event(ctx->ev[3]));
     float ms = 0;
     QHIP_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     *gb_per_s = (double)bytes * iters / ((double)ms * 1e-3) / 1e9;

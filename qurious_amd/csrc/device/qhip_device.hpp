@@ -40,7 +40,15 @@ struct KArgs {
   const u8* strlit;      // concatenated Utf8 literals
   int stroff[QH_MAXL + 1];
   i64 nrows;
+  const u32* nrows_dev;  // when set: the table's row count lives on the device (a hash join whose output size the host has
+                         // not waited for) and nrows is its capacity — the kernels that accept such inputs (qh_rows) stop there
 };
+// rows of the input: nrows, or the device-side count of a join output the host did not wait for (never above nrows)
+__device__ __forceinline__ i64 qh_rows(const KArgs& a) {
+  i64 n = a.nrows;
+  if (a.nrows_dev) { const i64 d = (i64)*a.nrows_dev; n = d < n ? d : n; }
+  return n;
+}
 
 // status word indices (QS_*): qhip_status.h, prepended to this file when it is embedded for hiprtc
 
@@ -447,7 +455,8 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   u64 seen_pass = 0, seen_hits = 0;
 
   const i64 tile_rows = (i64)QH_BLOCK * R;
-  const i64 ntiles = (a.nrows + tile_rows - 1) / tile_rows;
+  const i64 nrows = qh_rows(a);
+  const i64 ntiles = (nrows + tile_rows - 1) / tile_rows;
   for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
     // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (the load is
     // issued with the tile's loads and consumed at the end of the iteration, wave-uniform)
@@ -460,13 +469,13 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       // phase 1: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
       // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
       const u32 o = (u32)r * QH_BLOCK + (u32)tid;
-      const bool inb = tb + (i64)o < a.nrows;
-      P::load(a, tb, inb ? o : (u32)(a.nrows - 1 - tb), raw[r]);
+      const bool inb = tb + (i64)o < nrows;
+      P::load(a, tb, inb ? o : (u32)(nrows - 1 - tb), raw[r]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // phase 2: predicate, key words and aggregate arguments of each row (may branch)
-      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < a.nrows;
+      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < nrows;
       u32 e = 0;
       P::eval(a, raw[r], row[r], e);
       row[r].pass = row[r].pass && inb;
@@ -631,7 +640,8 @@ __device__ __forceinline__ void qh_agg_part_body(const KArgs& a, const PartLaunc
   for (u32 b = tid; b < L.n_bins; b += QH_BLOCK) cnt[b] = SCATTER ? L.hist[(size_t)b * gridDim.x + blockIdx.x] : 0u;
   __syncthreads();
   const i64 first = (i64)blockIdx.x * L.rows_per_wg;
-  const i64 last = first + L.rows_per_wg < a.nrows ? first + L.rows_per_wg : a.nrows;
+  const i64 nrows = qh_rows(a);
+  const i64 last = first + L.rows_per_wg < nrows ? first + L.rows_per_wg : nrows;
   u32 err = 0;
   // PR rows per thread and iteration, in phases like the fused kernel: all loads of the tile first (their latencies
   // overlap), then evaluation and the LDS rank, then the record stores
@@ -1020,7 +1030,8 @@ __device__ __forceinline__ void qh_join_scatter_body(const KArgs& a, const Scatt
   for (u32 r = tid; r <= nr; r += TB) cnt[r] = 0;
   __syncthreads();
   const i64 first = (i64)blockIdx.x * L.rows_per_wg;
-  const i64 last = first + L.rows_per_wg < a.nrows ? first + L.rows_per_wg : a.nrows;
+  const i64 nrows = qh_rows(a);
+  const i64 last = first + L.rows_per_wg < nrows ? first + L.rows_per_wg : nrows;
   u32 err = 0;
   for (int pass = 0; pass < 2; ++pass) {
     for (i64 tb = first; tb < last; tb += (i64)TB * R) {

@@ -155,7 +155,7 @@ qhip_table* table_concat(Ctx* ctx, const qhip_table* const* ts, int n) {
     }
     out->cols.push_back(assemble_column(ctx, first->cols[c].type, secs));
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));
   return out.release();
 }
 
@@ -221,7 +221,7 @@ void table_pack(Ctx* ctx, const qhip_table* t, void* dst, int64_t dst_bytes) {
     put(lay[c].validity_off, lay[c].validity_bytes, t->cols[c].validity);
     put(lay[c].data_off, lay[c].data_bytes, t->cols[c].data);
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(s));   // the transport reads the image on its own stream
+  QHIP_HIP_CHECK(sync_stream(s));   // the transport reads the image on its own stream
 }
 
 qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int n_cols, const int64_t* metas,
@@ -263,7 +263,7 @@ qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_d
     out->names.push_back(names && names[c] ? names[c] : ("c" + std::to_string(c)));
     out->nullable.push_back(true);
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the caller frees the images when this returns
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the caller frees the images when this returns
   return out.release();
 }
 
@@ -321,7 +321,7 @@ qhip_table* table_from_device(Ctx* ctx, const char* const* names, const qhip_dev
     t->names.push_back(names && names[c] ? names[c] : ("c" + std::to_string(c)));
     t->nullable.push_back(true);
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(s));
+  QHIP_HIP_CHECK(sync_stream(s));
   return t.release();
 }
 
@@ -333,7 +333,7 @@ int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input, const qhip_exp
                           int32_t n_keys, int32_t n_parts, qhip_table** out_parts) {
   if (!ctx || !input || !out_parts) return QHIP_INVALID_ARGUMENT;
   for (int p = 0; p < n_parts; ++p) out_parts[p] = nullptr;
-  int rc = guarded(ctx, [&] { partition_by_key(ctx, input, exprs, n_exprs, key_roots, n_keys, n_parts, out_parts); });
+  int rc = guarded(ctx, [&] { settle_rows(input); partition_by_key(ctx, input, exprs, n_exprs, key_roots, n_keys, n_parts, out_parts); });
   if (rc != QHIP_OK)
     for (int p = 0; p < n_parts; ++p) { if (out_parts[p]) { delete out_parts[p]; out_parts[p] = nullptr; } }
   return rc;
@@ -342,13 +342,13 @@ int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input, const qhip_exp
 int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n, qhip_table** out) {
   if (!ctx || !tables || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = table_concat(ctx, tables, n); });
+  return guarded(ctx, [&] { for (int k = 0; k < n; ++k) settle_rows(tables[k]); *out = table_concat(ctx, tables, n); });
 }
 
 int qhip_table_keep_columns(qhip_ctx* ctx, const qhip_table* t, const int32_t* keep, int32_t n_cols, qhip_table** out) {
   if (!ctx || !t || !keep || !out || n_cols != (int32_t)t->cols.size()) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = table_keep_columns(ctx, t, keep); });
+  return guarded(ctx, [&] { settle_rows(t); *out = table_keep_columns(ctx, t, keep); });
 }
 
 int qhip_table_stride_sample(qhip_ctx* ctx, const qhip_table* t, int64_t stride, qhip_table** out) {
@@ -356,6 +356,7 @@ int qhip_table_stride_sample(qhip_ctx* ctx, const qhip_table* t, int64_t stride,
   *out = nullptr;
   return guarded(ctx, [&] {
     QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+    settle_rows(t);
     const uint64_t m = ((uint64_t)t->num_rows + (uint64_t)stride - 1) / (uint64_t)stride;
     std::unique_ptr<qhip_table> o(new qhip_table());
     o->ctx = ctx;
@@ -372,12 +373,12 @@ int qhip_table_stride_sample(qhip_ctx* ctx, const qhip_table* t, int64_t stride,
 
 int qhip_table_wire_meta(qhip_ctx* ctx, const qhip_table* t, int64_t* meta, int32_t n_meta) {
   if (!ctx || !t || !meta || n_meta != (int32_t)(2 + 2 * t->cols.size())) return QHIP_INVALID_ARGUMENT;
-  return guarded(ctx, [&] { table_wire_meta(ctx, t, meta); });
+  return guarded(ctx, [&] { settle_rows(t); table_wire_meta(ctx, t, meta); });
 }
 
 int qhip_table_pack(qhip_ctx* ctx, const qhip_table* t, void* device_dst, int64_t dst_bytes) {
   if (!ctx || !t || (!device_dst && dst_bytes > 0)) return QHIP_INVALID_ARGUMENT;
-  return guarded(ctx, [&] { table_pack(ctx, t, device_dst, dst_bytes); });
+  return guarded(ctx, [&] { settle_rows(t); table_pack(ctx, t, device_dst, dst_bytes); });
 }
 
 int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols, const int64_t* metas,
@@ -389,9 +390,9 @@ int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip
 
 int qhip_table_column_buffer(const qhip_table* t, int64_t col, int32_t which, void** device_ptr, int64_t* n_bytes) {
   if (!t || col < 0 || col >= (int64_t)t->cols.size() || !device_ptr || !n_bytes) return QHIP_INVALID_ARGUMENT;
-  if (t->cols[(size_t)col].deferred) {
+  if (t->cols[(size_t)col].deferred || t->rows_dev) {
     if (!t->ctx) return QHIP_INVALID_ARGUMENT;
-    const int rc = guarded(static_cast<qhip_ctx*>(t->ctx), [&] { QHIP_HIP_CHECK(hipSetDevice(t->ctx->device)); (void)resolved(t->ctx, t->cols[(size_t)col]); });
+    const int rc = guarded(static_cast<qhip_ctx*>(t->ctx), [&] { QHIP_HIP_CHECK(hipSetDevice(t->ctx->device)); settle_rows(t); (void)resolved(t->ctx, t->cols[(size_t)col]); });
     if (rc != QHIP_OK) return rc;
   }
   const DevColumn& c = t->cols[(size_t)col];

@@ -100,5 +100,5 @@ extern "C" int qhip_filter_execute(qhip_ctx* ctx, const qhip_table* input, const
                                    const int32_t* projection, int32_t n_projection, qhip_table** out) {
   if (!ctx || !input || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = filter_execute(ctx, input, exprs, n_exprs, predicate_root, projection, n_projection); });
+  return guarded(ctx, [&] { settle_rows(input); *out = filter_execute(ctx, input, exprs, n_exprs, predicate_root, projection, n_projection); });
 }

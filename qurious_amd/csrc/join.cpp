@@ -56,6 +56,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if (L->num_rows >= (int64_t)kNullIdx - 1 || R->num_rows >= (int64_t)kNullIdx - 1)
     fail(QHIP_UNSUPPORTED, "join inputs of 2^32 - 2 rows or more are not supported");
   hipStream_t s = ctx->stream;
+  // a probe side of deferred size is made exact first; a build side of deferred size is read as it is when the region
+  // build takes it (qk_join_scatter stops at the device-side row count), else it is made exact too (below)
+  settle_rows(R);
   const uint64_t B = (uint64_t)L->num_rows, P = (uint64_t)R->num_rows;
   const bool semi_anti = join_type == QHIP_JOIN_LEFT_SEMI || join_type == QHIP_JOIN_LEFT_ANTI;
   const bool pad_right = join_type == QHIP_JOIN_RIGHT || join_type == QHIP_JOIN_FULL;
@@ -86,27 +89,44 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
-  // device status block of the call: [build status words | probe status words | pair total]: cleared once, read back once
-  uint32_t* const dstat = ctx->status.as<uint32_t>();
-  QHIP_HIP_CHECK(hipMemsetAsync(dstat, 0, (2 * QS_WORDS + 1) * 4, s));
   // The build's status (key-evaluation errors, duplicate keys?) is needed before the probe only to choose between the
   // unique-key and the CSR layout. Unique keys are the rule (every FK -> PK join), so unless this build side is known to
   // have had duplicates the probe is launched on that assumption and the build status is read together with the probe's:
   // one host round trip less per join. A wrong guess is memory-safe (a slot's state word always names a valid build row),
   // is detected below, remembered, and the join runs again the careful way.
   // (the hint identifies the build side by its key / filter expressions and row count)
-  uint64_t dup_hint = B * 0x9E3779B97F4A7C15ULL + (uint64_t)(lpred + 1);
-  for (int k = 0; k < nlex; ++k) {
-    qhip_expr e = lex[k];
-    const char* str = e.lit_str;
-    e.lit_str = nullptr;
-    dup_hint = fnv1a64(std::string((const char*)&e, sizeof e), dup_hint);
-    if (str && e.lit_len > 0 && e.kind == QHIP_EXPR_LITERAL) dup_hint = fnv1a64(std::string(str, (size_t)e.lit_len), dup_hint);
-  }
+  auto fold_exprs = [](uint64_t h, const qhip_expr* ex, int n) {
+    for (int k = 0; k < n; ++k) {
+      qhip_expr e = ex[k];
+      const char* str = e.lit_str;
+      e.lit_str = nullptr;
+      h = fnv1a64(std::string((const char*)&e, sizeof e), h);
+      if (str && e.lit_len > 0 && e.kind == QHIP_EXPR_LITERAL) h = fnv1a64(std::string(str, (size_t)e.lit_len), h);
+    }
+    return h;
+  };
+  uint64_t dup_hint = fold_exprs(B * 0x9E3779B97F4A7C15ULL + (uint64_t)(lpred + 1), lex, nlex);
   for (int k = 0; k < n_on; ++k) dup_hint = dup_hint * 1099511628211ULL + (uint64_t)on_l[k];
   const bool speculate = env_int("QHIP_JOIN_FORCE_CSR", 0) == 0 && env_int("QHIP_JOIN_NO_SPECULATION", 0) == 0 && !ctx->join_dup_builds.count(dup_hint);
   const int region_mode = env_int("QHIP_JOIN_REGION", 1);   // LDS-staged region build: 0 never, 1 when it pays, 2 always (tests)
   const bool want_regions = speculate && B > 0 && (region_mode == 2 || (region_mode == 1 && B >= 2048));
+  // Deferred sizing (qhip.h: qhip_ctx_allow_deferred_sizes): this join as a whole is identified by both sides' expressions,
+  // its type and the probe rows (the build rows too unless they are themselves a capacity)
+  uint64_t size_key = (L->rows_dev ? 0 : B) * 0x9E3779B97F4A7C15ULL + P * 0xD6E8FEB86659FD93ULL + ((uint64_t)(join_type + 1) << 56) +
+                      ((uint64_t)(lpred + 1) << 20) + (uint64_t)(rpred + 1);
+  size_key = fold_exprs(fold_exprs(size_key, lex, nlex), rex, nrex);
+  for (int k = 0; k < n_on; ++k) size_key = (size_key * 1099511628211ULL + (uint64_t)on_l[k]) * 1099511628211ULL + (uint64_t)on_r[k];
+  const auto hint = ctx->join_size_hints.find(size_key);
+  const bool defer = ctx->allow_deferred_sizes > 0 && speculate && join_type == QHIP_JOIN_INNER && froot < 0 && B > 0 && P > 0 &&
+                     hint != ctx->join_size_hints.end() && env_int("QHIP_JOIN_NO_DEFER", 0) == 0;
+  // room for what the join produced last time + 1/8 + 1024 (an FK -> PK join cannot exceed its probe rows)
+  const uint64_t defer_cap = defer ? std::min<uint64_t>(P, hint->second + hint->second / 8 + 1024) : 0;
+  // device status block of the call: [build status words | probe status words | pair total]: cleared once, read back once
+  // (a join of deferred size keeps a block of its own: its output's row count lives there)
+  std::shared_ptr<DevBuf> own_block;
+  if (defer) own_block = std::make_shared<DevBuf>(128);
+  uint32_t* const dstat = defer ? own_block->as<uint32_t>() : ctx->status.as<uint32_t>();
+  QHIP_HIP_CHECK(hipMemsetAsync(dstat, 0, (2 * QS_WORDS + 1) * 4, s));
   plan_keys(les, lcols, on_l, n_on, lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL);
   plan_keys(res, rcols, on_r, n_on, rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
   for (int k = 0; k < n_on; ++k)
@@ -137,6 +157,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (n_regions > 8192 || (((size_t)8 * (1 + W)) << slot_bits) + ((size_t)8 << bword_bits) > 64 * 1024) n_regions = 0;
   }
   const bool region_build = n_regions > 0;
+  if (L->rows_dev && !region_build) {   // only qk_join_scatter reads a device-side row count: wait, shrink, start over
+    settle_rows(L);
+    return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
+  }
   const uint32_t nslots = region_build ? n_regions << slot_bits : std::max<uint32_t>(16, pow2_ceil32(B * 2));
   // hash filter: 64-bit words, 8 bits per slot (region layout: 2^bword_bits words per region)
   const uint32_t filter_words = region_build ? n_regions << bword_bits : std::max<uint32_t>(16, nslots / 8);
@@ -160,19 +184,19 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     wgs = (B + rows_per_wg - 1) / rows_per_wg;
     DevBuf entries(B * (1 + (size_t)W) * 8), first(wgs * ((size_t)n_regions + 1) * 4);
     HScatterLaunch sl;
-    sl.entries = entries.as<uint64_t>(); sl.first = first.as<uint32_t>(); sl.status = ctx->status.as<uint32_t>();
+    sl.entries = entries.as<uint64_t>(); sl.first = first.as<uint32_t>(); sl.status = dstat;
     sl.n_regions = n_regions; sl.rows_per_wg = (uint32_t)rows_per_wg;
     void* args[] = {&ka, &sl};
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, (unsigned)wgs, 1, 1, 1024, 1, 1, (n_regions + 1) * 4, s, args, nullptr));
     launch_join_region_build(W, entries.as<uint64_t>(), first.as<uint32_t>(), (uint32_t)wgs, (uint32_t)rows_per_wg, table, bloom, n_regions,
-                             slot_bits, bword_bits, ctx->status.as<uint32_t>(), s);
+                             slot_bits, bword_bits, dstat, s);
     // (entries / first go back to the pool here; whoever gets them next runs on the same stream, i.e. afterwards)
   } else {
     QHIP_HIP_CHECK(hipMemsetAsync(arena.ptr, 0, arena.bytes, s));
     row_slot.alloc((B + 1) * 4);
     eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
     launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
-                             filter_words - 1, ctx->status.as<uint32_t>(), s);
+                             filter_words - 1, dstat, s);
   }
   uint32_t max_count = 0;
   // read-backs land in the context's page-locked scratch: a D2H copy into pageable memory is a stream round trip of its
@@ -186,7 +210,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   };
   if (!speculate) {
     QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));   // key evaluation + build
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    QHIP_HIP_CHECK(sync_stream(s));
+    verify_pending_sizes(ctx);
     check_build_status();
   }
   // Unique build keys (every FK -> PK join): each slot's state word names its one build row and nothing else is needed.
@@ -220,6 +245,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // probe-row order. LeftSemi / LeftAnti without a residual filter only need the visited bits: pass 1 sets them.
   DevBuf ent_slot((P + 1) * 4), ent_row((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
   uint64_t M = 0;
+  const uint32_t* deferred_slot = nullptr;
   bool probe_timed = false;
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
@@ -253,9 +279,25 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     hipEventRecord(ctx->ev[3], s);
     probe_timed = true;
     if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, dstat + 2 * QS_WORDS, s);
+    if (defer) {
+      // no read-back: the status block + total go to a page-locked slot that the consumer's synchronisation checks
+      if (!ctx->size_slots) QHIP_HIP_CHECK(hipHostMalloc((void**)&ctx->size_slots, (size_t)kSizeSlots * 32 * 4, hipHostMallocDefault));
+      if (ctx->pending_sizes.size() >= (size_t)kSizeSlots) fail(QHIP_HIP_ERROR, "too many joins of deferred size in flight (internal error)");
+      uint32_t* slot = ctx->size_slots + (size_t)(ctx->size_slot_next++ % kSizeSlots) * 32;
+      QHIP_HIP_CHECK(hipMemcpyAsync(slot, dstat, (2 * QS_WORDS + 1) * 4, hipMemcpyDeviceToHost, s));
+      ctx->pending_sizes.push_back({slot, size_key, defer_cap, dup_hint});
+      M = defer_cap;
+      b_idx.alloc((M + 1) * 4);
+      p_idx.alloc((M + 1) * 4);
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+                       nullptr, nullptr, nullptr, (uint32_t)M, s);
+      launch_fill_tail_u32(b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), dstat + 2 * QS_WORDS, (uint32_t)M, s);
+      deferred_slot = slot;
+    } else {
     // ONE read-back: build status (needed only now under speculation), probe status and the pair total
     QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, (2 * QS_WORDS + 1) * 4, hipMemcpyDeviceToHost, s));
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    QHIP_HIP_CHECK(sync_stream(s));
+    verify_pending_sizes(ctx);   // (a build side of deferred size: did ITS join have room?)
     if (speculate) {
       check_build_status();
       if (max_count > 1) {   // duplicate build keys after all: remember, and run again with the CSR layout
@@ -266,6 +308,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     }
     check_status_words(st);
     M = st[QS_WORDS];
+    if (join_type == QHIP_JOIN_INNER && froot < 0) {
+      if (ctx->join_size_hints.size() > 4096) ctx->join_size_hints.clear();   // hints, not records
+      ctx->join_size_hints[size_key] = M;
+    }
     if (want_pairs) {
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
@@ -276,12 +322,14 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       }
       launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
-                       mark_in_probe ? visited.as<uint32_t>() : nullptr, s);
+                       mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, s);
+    }
     }
     visited_done = mark_in_probe;
   } else if (speculate) {
     QHIP_HIP_CHECK(hipMemcpyAsync(st_build, dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    QHIP_HIP_CHECK(sync_stream(s));
+    verify_pending_sizes(ctx);
     check_build_status();   // (duplicates do not matter without probe rows)
   }
   if (!probe_timed) { hipEventRecord(ctx->ev[2], s); hipEventRecord(ctx->ev[3], s); }
@@ -309,7 +357,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     DevBuf b2(((uint64_t)m2 + 1) * 4), p2(((uint64_t)m2 + 1) * 4);
     launch_gather_fixed(b_idx.ptr, sel.as<uint32_t>(), b2.ptr, m2, 4, s);
     launch_gather_fixed(p_idx.ptr, sel.as<uint32_t>(), p2.ptr, m2, 4, s);
-    QHIP_HIP_CHECK(hipStreamSynchronize(s));
+    QHIP_HIP_CHECK(sync_stream(s));
     b_idx = std::move(b2);
     p_idx = std::move(p2);
     M = m2;
@@ -396,6 +444,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   add_side(L, b_all, left_nullable);
   if (!semi_anti) add_side(R, p_all, right_nullable);
   out->num_rows = (int64_t)total_rows;
+  if (deferred_slot) {   // total_rows is the capacity; the count is the pair total in this join's own status block
+    out->rows_blk = own_block;
+    out->rows_dev = dstat + 2 * QS_WORDS;
+    out->rows_host = deferred_slot + 2 * QS_WORDS;
+  }
 
   // ---- output batches: one per non-empty probe batch (hash_join.rs:363-372), then the tail batch
   out->batch_offsets.clear();
@@ -412,10 +465,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pend->tail = has_tail;
     pend->total_rows = (int64_t)total_rows;
     if (pad_right) launch_lookup_u32(final_off, drows, (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
-    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, drows, (uint32_t)nb1, pend->pos->as<uint32_t>(), s);   // probe rows ascend
+    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, out->rows_dev, drows, (uint32_t)nb1, pend->pos->as<uint32_t>(), s);   // probe rows ascend
     out->batch_offsets.clear();
     out->pending_offsets = pend;
-    if (env_int("QHIP_EAGER_OFFSETS", 0) != 0) (void)out->offsets();
+    if (env_int("QHIP_EAGER_OFFSETS", 0) != 0 && !deferred_slot) (void)out->offsets();
   } else if (has_tail) {
     out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
   }
@@ -455,7 +508,12 @@ extern "C" int qhip_hash_join_execute(qhip_ctx* ctx, const qhip_table* left, con
   if (!ctx || !left || !right || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
   return guarded(ctx, [&] {
-    *out = hash_join(ctx, left, right, join_type, left_exprs, n_left_exprs, right_exprs, n_right_exprs, on_left, on_right, n_on, filter_exprs,
-                     n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols, left_scan_filter_root, right_scan_filter_root);
+    try {
+      *out = hash_join(ctx, left, right, join_type, left_exprs, n_left_exprs, right_exprs, n_right_exprs, on_left, on_right, n_on, filter_exprs,
+                       n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols, left_scan_filter_root, right_scan_filter_root);
+    } catch (...) {
+      ctx->pending_sizes.clear();   // (joins of deferred size below: whatever they left is void with this call's input)
+      throw;
+    }
   });
 }

@@ -21,9 +21,10 @@ struct HKArgs {
   const uint8_t* strlit;
   int stroff[kMaxLits + 1];
   int64_t nrows;
+  const uint32_t* nrows_dev;
 };
 static_assert(sizeof(HKCol) == 24, "KCol layout");
-static_assert(sizeof(HKArgs) == 24 * 24 + 8 * 24 + 8 * 24 + 8 + 104 + 8, "KArgs layout");
+static_assert(sizeof(HKArgs) == 24 * 24 + 8 * 24 + 8 * 24 + 8 + 104 + 8 + 8, "KArgs layout");
 
 struct HAggLaunch {
   uint64_t* gtable;

@@ -147,7 +147,7 @@ qhip_table* nested_loop_join(Ctx* ctx, const qhip_table* L, const qhip_table* R,
     launch_fill_u32(l_all->as<uint32_t>() + M + TL, TR, kNullIdx, s);
     QHIP_HIP_CHECK(hipMemcpyAsync(r_all->as<uint32_t>() + M + TL, sel_r.ptr, TR * 4, hipMemcpyDeviceToDevice, s));
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(s));   // sel_l / sel_r are about to be released
+  QHIP_HIP_CHECK(sync_stream(s));   // sel_l / sel_r are about to be released
   add_columns(l_all, r_all, total, TR > 0, TL > 0);
   out->num_rows = (int64_t)total;
   out->batch_offsets.push_back((int64_t)total);   // unmatched_batch, possibly empty
@@ -193,6 +193,8 @@ extern "C" int qhip_nested_loop_join_execute(qhip_ctx* ctx, const qhip_table* le
   if (!ctx || !left || !right || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
   return guarded(ctx, [&] {
+    settle_rows(left);
+    settle_rows(right);
     *out = nested_loop_join(ctx, left, right, join_type, filter_exprs, n_filter_exprs, filter_root, filter_sides, filter_cols, n_filter_cols);
   });
 }
@@ -200,5 +202,5 @@ extern "C" int qhip_nested_loop_join_execute(qhip_ctx* ctx, const qhip_table* le
 extern "C" int qhip_cross_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_table* right, qhip_table** out) {
   if (!ctx || !left || !right || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = cross_join(ctx, left, right); });
+  return guarded(ctx, [&] { settle_rows(left); settle_rows(right); *out = cross_join(ctx, left, right); });
 }

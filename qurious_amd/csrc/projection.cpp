@@ -129,5 +129,5 @@ extern "C" int qhip_projection_execute(qhip_ctx* ctx, const qhip_table* in, cons
                                        int32_t n_out, const char* const* out_names, qhip_table** out) {
   if (!ctx || !in || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = project_table(ctx, in, exprs, n_exprs, roots, n_out, out_names); });
+  return guarded(ctx, [&] { settle_rows(in); *out = project_table(ctx, in, exprs, n_exprs, roots, n_out, out_names); });
 }

@@ -34,7 +34,7 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
   QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
   uint32_t status[QS_WORDS];
   QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));
   check_status_words(status);
 }
 
@@ -235,7 +235,7 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, 
     launch_gather_bits(col.validity ? col.validity->as<uint8_t>() : nullptr, idx, m, words->as<uint64_t>(), counter.as<uint32_t>(), ctx->stream);
     uint32_t set = 0;
     QHIP_HIP_CHECK(hipMemcpyAsync(&set, counter.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
-    QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    QHIP_HIP_CHECK(sync_stream(ctx->stream));
     out.null_count = (int64_t)m - (int64_t)set;
     if (out.null_count > 0) out.validity = words;
   }
@@ -296,13 +296,52 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
   if (deferred_status) return;
   uint32_t status[QS_WORDS];
   QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));
   check_status_words(status);
 }
 
 }  // namespace qhip
 
 // The boundaries are read on the table's stream into the page-locked scratch (one round trip), once.
+void qhip::settle_rows(const qhip_table* tc) {
+  if (!tc || !tc->rows_dev) return;
+  qhip_table* t = const_cast<qhip_table*>(tc);
+  Ctx* ctx = t->ctx;
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  QHIP_HIP_CHECK(qhip::sync_stream(ctx->stream));
+  try {
+    verify_pending_sizes(ctx);   // QHIP_RETRY when the join had too little room: the table is then void
+  } catch (...) {
+    ctx->pending_sizes.clear();
+    throw;
+  }
+  const int64_t m = std::min<int64_t>((int64_t)*t->rows_host, t->num_rows);
+  t->num_rows = m;
+  for (DevColumn& c : t->cols) {
+    c.length = m;
+    if (c.type.id == QHIP_NULL) c.null_count = m;
+    if (c.deferred) {
+      c.deferred->m = (uint64_t)m;
+      if (c.deferred->done) {   // gathered over the capacity by an earlier reader: the filler rows' NULLs do not count
+        DevColumn& r = c.deferred->result;
+        r.length = m;
+        if (r.validity && m > 0) {
+          DevBuf counter(4);
+          QHIP_HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 4, ctx->stream));
+          launch_count_bits(r.validity->as<uint64_t>(), (uint64_t)m, counter.as<uint32_t>(), ctx->stream);
+          uint32_t set = 0;
+          copy_sync(ctx->stream, &set, counter.ptr, 4, hipMemcpyDeviceToHost);
+          r.null_count = m - (int64_t)set;
+        } else if (m == 0) r.null_count = 0;
+      }
+    }
+  }
+  if (t->pending_offsets) t->pending_offsets->total_rows = m;
+  t->rows_dev = nullptr;
+  t->rows_host = nullptr;
+  t->rows_blk.reset();
+}
+
 const std::vector<int64_t>& qhip_table::offsets() const {
   if (!pending_offsets) return batch_offsets;
   const qhip::PendingOffsets& p = *pending_offsets;
@@ -315,7 +354,7 @@ const std::vector<int64_t>& qhip_table::offsets() const {
     pos = pos_v.data();
   }
   QHIP_HIP_CHECK(hipMemcpyAsync(pos, p.pos->ptr, p.n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  QHIP_HIP_CHECK(qhip::sync_stream(ctx->stream));
   batch_offsets.clear();
   if (p.skip_empty) {
     batch_offsets.push_back(0);

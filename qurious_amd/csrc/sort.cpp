@@ -193,11 +193,11 @@ extern "C" int qhip_sort_execute(qhip_ctx* ctx, const qhip_table* in, const qhip
                                  const int32_t* descending, const int32_t* nulls_first, int32_t n_keys, int64_t limit, qhip_table** out) {
   if (!ctx || !in || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = sort_table(ctx, in, exprs, n_exprs, key_roots, descending, nulls_first, n_keys, limit); });
+  return guarded(ctx, [&] { settle_rows(in); *out = sort_table(ctx, in, exprs, n_exprs, key_roots, descending, nulls_first, n_keys, limit); });
 }
 
 extern "C" int qhip_limit_execute(qhip_ctx* ctx, const qhip_table* in, int64_t skip, int64_t fetch, qhip_table** out) {
   if (!ctx || !in || !out) return QHIP_INVALID_ARGUMENT;
   *out = nullptr;
-  return guarded(ctx, [&] { *out = limit_table(ctx, in, skip, fetch); });
+  return guarded(ctx, [&] { settle_rows(in); *out = limit_table(ctx, in, skip, fetch); });
 }

@@ -76,7 +76,7 @@ struct Coalescer {
         QHIP_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
         QHIP_HIP_CHECK(hipEventRecord(ctx->up_ev[k], ctx->stream));
       }
-    QHIP_HIP_CHECK(hipEventSynchronize(ctx->up_ev[cur]));   // a previous user's copy out of this slot has finished
+    QHIP_HIP_CHECK(sync_event(ctx->up_ev[cur]));   // a previous user's copy out of this slot has finished
   }
   void send() {
     if (!fill) return;
@@ -85,7 +85,7 @@ struct Coalescer {
     dst += fill;
     fill = 0;
     cur ^= 1;
-    QHIP_HIP_CHECK(hipEventSynchronize(ctx->up_ev[cur]));   // the other slot's copy (two sends ago) has finished
+    QHIP_HIP_CHECK(sync_event(ctx->up_ev[cur]));   // the other slot's copy (two sends ago) has finished
   }
   void append(const void* src, size_t n) {
     const uint8_t* p = (const uint8_t*)src;
@@ -228,7 +228,7 @@ static DevColumn upload_column(Ctx* ctx, const char* format, int64_t c, const Ar
     col.null_count = N;
   }
   h2d_flush(ctx);                                      // every chunk staged and on the stream
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // the staging vectors die here
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the staging vectors die here
   return col;
 }
 
@@ -434,7 +434,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
     } else if (col.type.id == QHIP_UTF8) {
       int32_t* off = (int32_t*)xmalloc((size_t)(n + 1) * 4);
       d2h(off, (const int32_t*)col.values->ptr + r0, (size_t)(n + 1) * 4, ctx->stream);
-      QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // need the offsets to size the data slice
+      QHIP_HIP_CHECK(sync_stream(ctx->stream));   // need the offsets to size the data slice
       land_staged();
       const int32_t base = off[0];
       const int64_t nbytes = (int64_t)off[n] - base;
@@ -449,7 +449,7 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
     ca->buffers = p->buffer_ptrs.data();
     top->children.push_back(ca);
   }
-  QHIP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  QHIP_HIP_CHECK(sync_stream(ctx->stream));
   land_staged();
   for (auto& f : bitfix) { copy_bits(f.raw, f.bit_off, f.dst, 0, f.nbits); free(f.raw); }
   for (auto& f : offfix) { const int32_t base = f.off[0]; for (int64_t i = 0; i < f.n; ++i) f.off[i] -= base; }
@@ -497,6 +497,7 @@ int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
                         struct ArrowSchema* out_schema) {
   if (!ctx || !t) return QHIP_INVALID_ARGUMENT;
   return guarded(ctx, [&] {
+    settle_rows(t);
     if (out_array) table_batch_to_arrow(ctx, t, batch_index, out_array);
     if (out_schema) table_schema_to_arrow(t, out_schema);
   });
@@ -505,6 +506,7 @@ int qhip_table_to_arrow(qhip_ctx* ctx, const qhip_table* t, int64_t batch_index,
 int qhip_table_batch_offsets(const qhip_table* t, int64_t* out, int64_t n_out) {
   if (!t || !out) return QHIP_INVALID_ARGUMENT;
   try {
+    settle_rows(t);
     const std::vector<int64_t>& off = t->offsets();
     if (n_out != (int64_t)off.size()) return QHIP_INVALID_ARGUMENT;
     for (size_t k = 0; k < off.size(); ++k) out[k] = off[k];
@@ -514,9 +516,12 @@ int qhip_table_batch_offsets(const qhip_table* t, int64_t* out, int64_t n_out) {
 
 int64_t qhip_table_num_batches(const qhip_table* t) {
   if (!t) return -1;
-  try { return t->num_batches(); } catch (const qhip::Error&) { return -1; }   // (pending boundaries are read from the device here)
+  try { settle_rows(t); return t->num_batches(); } catch (const qhip::Error&) { return -1; }   // (pending boundaries are read from the device here)
 }
-int64_t qhip_table_num_rows(const qhip_table* t) { return t ? t->num_rows : -1; }
+int64_t qhip_table_num_rows(const qhip_table* t) {
+  if (!t) return -1;
+  try { settle_rows(t); return t->num_rows; } catch (const qhip::Error&) { return -1; }   // (a join output of deferred size is waited for here)
+}
 int64_t qhip_table_num_columns(const qhip_table* t) { return t ? (int64_t)t->cols.size() : -1; }
 int64_t qhip_table_column_bytes(const qhip_table* t, int64_t col) {
   if (!t || col < 0 || col >= (int64_t)t->cols.size()) return -1;

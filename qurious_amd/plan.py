@@ -117,6 +117,31 @@ class Scan(PhysicalPlan):
         return super().execute()
 
 
+def _feeding(ctx, node: "PhysicalPlan") -> DeviceTable:
+    """Execute `node` as the input of an operator that reads a device-side row count (HashAggregate's input, a hash
+    join's build side): a hash join at the top of `node` may then skip the wait for its output size
+    (qhip.h: qhip_ctx_allow_deferred_sizes). The consumer runs right after, inside `_retrying`."""
+    ctx.allow_deferred_sizes(+1)
+    try:
+        return node.execute_device()
+    finally:
+        ctx.allow_deferred_sizes(-1)
+
+
+def _retrying(ctx, run):
+    """run() = execute the input(s), then the operator. QHIP_RETRY from the operator: a join of deferred size below had
+    too little room; it has forgotten its hint, so the second run waits for the size."""
+    for attempt in range(3):
+        try:
+            return run()
+        except _ffi.RetryInput:
+            if attempt == 2:
+                raise
+        except Exception:
+            ctx.allow_deferred_sizes(0)   # reset: nothing of deferred size is left in flight after an error
+            raise
+
+
 # Instrumented executions (bench.py's per-kernel roofline records): while a list is installed here every device operator
 # appends (operator label, qhip_exec_stats of the call). Reading the stats waits for the operator's events, so this is for
 # separate, untimed passes only.
@@ -208,9 +233,12 @@ class HashAggregate(PhysicalPlan):
             return node.datasource.device_table(), node.filter
         if isinstance(node, Filter) and isinstance(node.input, Scan) and node.input.filter is None and node.input.projections is None:
             return node.input.datasource.device_table(), node.predicate
-        return node.execute_device(), None
+        return _feeding(get_context(), node), None
 
     def execute_device(self) -> DeviceTable:
+        return _retrying(get_context(), self._execute_once)
+
+    def _execute_once(self) -> DeviceTable:
         table, pred = self._source()
         # plan nodes are immutable after construction (like the reference's): the lowered description is built once
         cached = getattr(self, "_lowered", None)
@@ -474,8 +502,17 @@ class HashJoinExec(PhysicalPlan):
         return node.execute_device(), None
 
     def execute_device(self) -> DeviceTable:
+        return _retrying(get_context(), self._execute_once)
+
+    def _execute_once(self) -> DeviceTable:
         fuse = self.join_type == JoinType.Inner
-        lt, lpred = self._side(self.left, fuse)
+        # the build side may arrive with a device-side row count when nothing executes between it and this join, i.e.
+        # when the probe side is a table access (a Scan, fused or plain) — the reference's order, left first, is kept
+        right_is_table = isinstance(self.right, Scan) and self.right.projections is None and (self.right.filter is None or fuse)
+        if right_is_table and not isinstance(self.left, Scan):
+            lt, lpred = _feeding(get_context(), self.left), None
+        else:
+            lt, lpred = self._side(self.left, fuse)
         rt, rpred = self._side(self.right, fuse)
         return self._join_tables(lt, rt, lpred, rpred)
 

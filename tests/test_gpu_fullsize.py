@@ -106,6 +106,13 @@ def test_q3_at_sf10_group_set_and_checksums_equal_numpy(ctx):
     # idempotence + the device-resident top-10 agrees with a host-side ordering of the full result
     again = pa.Table.from_batches(plan.execute()).combine_chunks()
     assert int(_dec_lo(again.column(3).chunk(0)).sum()) == want_total and again.num_rows == want_groups
+    # a repeated Q3 waits for the device ONCE (the aggregate's read-back): both joins leave their sizes on the device
+    # (tests/test_gpu_deferred_sizes.py), the 113 k groups are assembled there too
+    before = ctx.sync_count()
+    t = plan.execute_device()
+    assert ctx.sync_count() - before == 1
+    third = pa.Table.from_batches(t.to_batches()).combine_chunks()
+    assert int(_dec_lo(third.column(3).chunk(0)).sum()) == want_total and third.num_rows == want_groups
     top = rows_of(queries.q3_top10(*tabs).execute())
     order = np.lexsort((out.column(1).cast(pa.int32()).to_numpy(), -g_rev))[:10]
     assert [r[0] for r in top] == [int(g_key[i]) for i in order]
