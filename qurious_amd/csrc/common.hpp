@@ -144,6 +144,11 @@ struct PendingOffsets {
   bool skip_empty = false;         // hash join (hash_join.rs:363-372): only non-empty probe batches produce a batch
   bool tail = false;               // ... and a final batch (unmatched / semi rows), possibly empty
   int64_t total_rows = 0;
+  // ... or not even searched for yet (an Inner / Left join's pairs ascend by probe row: batch b starts at the first of the
+  // search_m pairs whose probe row is >= bounds[b]): the search runs when somebody asks (a parent's build side or an
+  // aggregate never does — one launch less per join)
+  std::shared_ptr<DevBuf> search_in, bounds;
+  uint64_t search_m = 0;
 };
 }  // namespace qhip
 struct qhip_table {
@@ -166,8 +171,8 @@ struct qhip_table {
   // count is *rows_dev on the device (*rows_host once the stream has been synchronised) and rows [count, num_rows) repeat
   // row 0 of both sides (valid to gather, never counted). HashAggregate and a hash join's build side read such a table as
   // it is (their kernels stop at *rows_dev); every other reader calls settle_rows() first.
-  mutable std::shared_ptr<qhip::DevBuf> rows_blk;   // the join's own status block [build | probe | pair total]
-  mutable const uint32_t* rows_dev = nullptr;       // -> the pair total inside rows_blk
+  mutable std::shared_ptr<qhip::DevBuf> rows_blk;   // owns the device-side count
+  mutable const uint32_t* rows_dev = nullptr;       // -> the pair total the join's pass 2 left there
   mutable const uint32_t* rows_host = nullptr;      // -> its page-locked copy
 };
 namespace qhip {
@@ -191,6 +196,11 @@ struct Ctx {
   mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 — read when the stats are asked for
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
+  // 128-byte blocks of zeros for status words / counters of ONE operator call (zeroed_block): handed out in turn from a ring
+  // that is cleared in bulk every 512 blocks — a memset launch per call costs ~5 us of stream time, more than many of the
+  // kernels it precedes. Single stream: whoever held a block 512 hand-outs ago has long finished.
+  DevBuf zero_ring;
+  size_t zero_next = 0;
   std::unordered_set<uint64_t> join_dup_builds;   // build sides (key policy x row count) seen with duplicate keys: no speculation
   // Deferred sizing. A hash join remembers how many pairs it produced (keyed by its expressions, type and probe rows, NOT
   // by the data). The next time the same join runs under a consumer that can read a device-side row count
@@ -243,6 +253,7 @@ constexpr int kSizeSlots = 64;
 // hint) when a join produced more pairs than it had room for or met duplicate build keys — what was computed from its
 // output is then garbage and the consumer's input runs again; key / filter errors surface as they would have in the join.
 void verify_pending_sizes(Ctx* ctx);
+uint32_t* zeroed_block(Ctx* ctx);   // 32 zeroed u32 words, valid for the current operator call (ctx.cpp)
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;

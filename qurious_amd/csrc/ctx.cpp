@@ -27,6 +27,16 @@ void note_sync() {
   }
 }
 
+uint32_t* zeroed_block(Ctx* ctx) {
+  constexpr size_t kBlock = 128, kBlocks = 512;
+  if (!ctx->zero_ring.ptr || ctx->zero_next >= kBlocks) {
+    if (!ctx->zero_ring.ptr) ctx->zero_ring.alloc(kBlock * kBlocks);
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->zero_ring.ptr, 0, kBlock * kBlocks, ctx->stream));
+    ctx->zero_next = 0;
+  }
+  return (uint32_t*)(ctx->zero_ring.as<uint8_t>() + kBlock * ctx->zero_next++);
+}
+
 void verify_pending_sizes(Ctx* ctx) {
   if (ctx->pending_sizes.empty()) return;
   std::vector<Ctx::PendingSize> pend;
@@ -296,6 +306,7 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   ctx->modules.clear();
   ctx->plan_cache.clear();
   ctx->status.release();
+  ctx->zero_ring.release();
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int k = 0; k < 2; ++k) {
     if (ctx->up_slot[k]) (void)hipHostFree(ctx->up_slot[k]);

@@ -80,10 +80,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       rcols[(size_t)re.column].utf8_max_len = m;
     }
   }
-  ExprSet les, res;
-  les.build(lex, nlex, lcols);
-  res.build(rex, nrex, rcols);
-  KeysPlan lkp, rkp;
   DevBuf lkeys, lvalid;
   hipEventRecord(ctx->ev[0], s);
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
@@ -121,20 +117,61 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
                      hint != ctx->join_size_hints.end() && env_int("QHIP_JOIN_NO_DEFER", 0) == 0;
   // room for what the join produced last time + 1/8 + 1024 (an FK -> PK join cannot exceed its probe rows)
   const uint64_t defer_cap = defer ? std::min<uint64_t>(P, hint->second + hint->second / 8 + 1024) : 0;
-  // device status block of the call: [build status words | probe status words | pair total]: cleared once, read back once
-  // (a join of deferred size keeps a block of its own: its output's row count lives there)
-  std::shared_ptr<DevBuf> own_block;
-  if (defer) own_block = std::make_shared<DevBuf>(128);
-  uint32_t* const dstat = defer ? own_block->as<uint32_t>() : ctx->status.as<uint32_t>();
-  QHIP_HIP_CHECK(hipMemsetAsync(dstat, 0, (2 * QS_WORDS + 1) * 4, s));
-  plan_keys(les, lcols, on_l, n_on, lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL);
-  plan_keys(res, rcols, on_r, n_on, rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
-  for (int k = 0; k < n_on; ++k)
-    if (lkp.keys[(size_t)k].type != rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
-      fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(lkp.keys[(size_t)k].type) +
-                                      " == " + dtype_name(rkp.keys[(size_t)k].type));
+  // device status block of the call: [build status words | probe status words | pair total], read back once
+  // (zeroed_block: handed out clean from the context's ring — no memset launch per join)
+  uint32_t* const dstat = zeroed_block(ctx);
+  // the lowered key plans of both sides (typing + generated source + loaded kernels) are cached per context, keyed by the
+  // column signatures and the expression PODs: a repeated join costs no typing, code generation or module lookup
+  std::string pkey = "join|";
+  {
+    auto put = [&](const void* p, size_t n) { pkey.append((const char*)p, n); };
+    for (const std::vector<InputCol>* cols : {&lcols, &rcols}) {
+      for (auto& ic : *cols) {
+        const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0};
+        put(v, sizeof v);
+      }
+      put("|", 1);
+    }
+    auto put_exprs = [&](const qhip_expr* ex, int n) {
+      for (int k = 0; k < n; ++k) {
+        qhip_expr e = ex[k];
+        const char* str = e.lit_str; const int64_t len = e.lit_len;
+        e.lit_str = nullptr;
+        put(&e, sizeof e);
+        if (str && len > 0 && e.kind == QHIP_EXPR_LITERAL) put(str, (size_t)len);
+      }
+      put("|", 1);
+    };
+    put_exprs(lex, nlex);
+    put_exprs(rex, nrex);
+    put(on_l, sizeof(int32_t) * (size_t)n_on);
+    put(on_r, sizeof(int32_t) * (size_t)n_on);
+    const int v[3] = {lpred, rpred, want_regions ? 1 : 0};
+    put(v, sizeof v);
+  }
+  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod; };
+  std::shared_ptr<JoinPlan> jp;
+  {
+    auto cached = ctx->plan_cache.find(pkey);
+    if (cached != ctx->plan_cache.end()) jp = std::static_pointer_cast<JoinPlan>(cached->second);
+    else {
+      jp = std::make_shared<JoinPlan>();
+      ExprSet les, res;
+      les.build(lex, nlex, lcols);
+      res.build(rex, nrex, rcols);
+      plan_keys(les, lcols, on_l, n_on, jp->lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL);
+      plan_keys(res, rcols, on_r, n_on, jp->rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
+      for (int k = 0; k < n_on; ++k)
+        if (jp->lkp.keys[(size_t)k].type != jp->rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
+          fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(jp->lkp.keys[(size_t)k].type) +
+                                          " == " + dtype_name(jp->rkp.keys[(size_t)k].type));
+      if (jp->rkp.W != jp->lkp.W) fail(QHIP_HIP_ERROR, "join key layouts of the two sides differ (internal error)");
+      if (ctx->plan_cache.size() > 4096) ctx->plan_cache.clear();
+      ctx->plan_cache[pkey] = jp;
+    }
+  }
+  const KeysPlan &lkp = jp->lkp, &rkp = jp->rkp;
   const int W = lkp.W;
-  if (rkp.W != W) fail(QHIP_HIP_ERROR, "join key layouts of the two sides differ (internal error)");
 
   // ---- build. Two layouts of the distinct-key table (slot = [state | key words], state - 2 = the build row):
   //  * region layout, LDS-staged (the default while unique build keys are assumed): the table is cut into regions of 2^sb
@@ -173,7 +210,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   uint64_t* bloom = (uint64_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
   DevBuf start, row_slot, sorted_rows;
   if (region_build) {
-    std::shared_ptr<Module> mod = get_module(ctx, lkp.source, lkp.kernel_name);
+    if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);
+    const std::shared_ptr<Module>& mod = jp->lmod;
     HKArgs ka;
     DevBuf strlit;
     fill_kargs(ctx, L, lkp.bind, ka, strlit);
@@ -194,7 +232,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   } else {
     QHIP_HIP_CHECK(hipMemsetAsync(arena.ptr, 0, arena.bytes, s));
     row_slot.alloc((B + 1) * 4);
-    eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp, lkeys, lvalid, lpred, true);
+    ExprSet les;
+    les.build(lex, nlex, lcols);
+    KeysPlan lkp_eval;   // (eval_key_words plans by itself: the same layout as lkp)
+    eval_key_words(ctx, L, les, lcols, on_l, n_on, lkp_eval, lkeys, lvalid, lpred, true, dstat);
     launch_join_build_insert(W, lkeys.as<uint64_t>(), lvalid.as<uint64_t>(), B, table, nslots, row_slot.as<uint32_t>(), count, bloom,
                              filter_words - 1, dstat, s);
   }
@@ -246,11 +287,13 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   DevBuf ent_slot((P + 1) * 4), ent_row((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
   uint64_t M = 0;
   const uint32_t* deferred_slot = nullptr;
+  std::shared_ptr<DevBuf> rows_blk;
   bool probe_timed = false;
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
   if (P > 0) {
-    std::shared_ptr<Module> mod = get_module(ctx, rkp.source, rkp.kernel_name);
+    if (!jp->rmod) jp->rmod = get_module(ctx, rkp.source, rkp.kernel_name);
+    const std::shared_ptr<Module>& mod = jp->rmod;
     HKArgs ka;
     DevBuf strlit;
     fill_kargs(ctx, R, rkp.bind, ka, strlit);
@@ -284,14 +327,14 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       if (!ctx->size_slots) QHIP_HIP_CHECK(hipHostMalloc((void**)&ctx->size_slots, (size_t)kSizeSlots * 32 * 4, hipHostMallocDefault));
       if (ctx->pending_sizes.size() >= (size_t)kSizeSlots) fail(QHIP_HIP_ERROR, "too many joins of deferred size in flight (internal error)");
       uint32_t* slot = ctx->size_slots + (size_t)(ctx->size_slot_next++ % kSizeSlots) * 32;
-      QHIP_HIP_CHECK(hipMemcpyAsync(slot, dstat, (2 * QS_WORDS + 1) * 4, hipMemcpyDeviceToHost, s));
       ctx->pending_sizes.push_back({slot, size_key, defer_cap, dup_hint});
       M = defer_cap;
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
+      rows_blk = std::make_shared<DevBuf>(64);   // the output table's device-side row count
+      // pass 2 also pads the index vectors up to the capacity, publishes the status block to `slot` and the total to rows_blk
       launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
-                       nullptr, nullptr, nullptr, (uint32_t)M, s);
-      launch_fill_tail_u32(b_idx.as<uint32_t>(), p_idx.as<uint32_t>(), dstat + 2 * QS_WORDS, (uint32_t)M, s);
+                       nullptr, nullptr, nullptr, (uint32_t)M, dstat, slot, rows_blk->as<uint32_t>(), s);
       deferred_slot = slot;
     } else {
     // ONE read-back: build status (needed only now under speculation), probe status and the pair total
@@ -322,7 +365,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       }
       launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
-                       mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, s);
+                       mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, nullptr, nullptr, nullptr, s);
     }
     }
     visited_done = mark_in_probe;
@@ -444,9 +487,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   add_side(L, b_all, left_nullable);
   if (!semi_anti) add_side(R, p_all, right_nullable);
   out->num_rows = (int64_t)total_rows;
-  if (deferred_slot) {   // total_rows is the capacity; the count is the pair total in this join's own status block
-    out->rows_blk = own_block;
-    out->rows_dev = dstat + 2 * QS_WORDS;
+  if (deferred_slot) {   // total_rows is the capacity; the count is what pass 2 left in rows_blk
+    out->rows_blk = rows_blk;
+    out->rows_dev = rows_blk->as<uint32_t>();
     out->rows_host = deferred_slot + 2 * QS_WORDS;
   }
 
@@ -459,13 +502,18 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     // somebody asks: a download, a Filter / Limit / probe side above; a parent's build side or an aggregate never does)
     const uint64_t* drows = R->device_offsets();
     auto pend = std::make_shared<PendingOffsets>();
-    pend->pos = std::make_shared<DevBuf>(nb1 * 4);
     pend->n = nb1;
     pend->skip_empty = true;
     pend->tail = has_tail;
     pend->total_rows = (int64_t)total_rows;
-    if (pad_right) launch_lookup_u32(final_off, drows, (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
-    else launch_lower_bound_u32(p_all->as<uint32_t>(), M, out->rows_dev, drows, (uint32_t)nb1, pend->pos->as<uint32_t>(), s);   // probe rows ascend
+    if (pad_right) {
+      pend->pos = std::make_shared<DevBuf>(nb1 * 4);
+      launch_lookup_u32(final_off, drows, (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
+    } else {   // the pairs' probe rows ascend: a binary search per batch boundary, run when somebody asks (PendingOffsets)
+      pend->search_in = p_all;
+      pend->search_m = M;
+      pend->bounds = R->offsets_dev;
+    }
     out->batch_offsets.clear();
     out->pending_offsets = pend;
     if (env_int("QHIP_EAGER_OFFSETS", 0) != 0 && !deferred_slot) (void)out->offsets();

@@ -468,8 +468,22 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table,
 // pair count and first pair position of every MATCHING probe row (cnt_out is zero-filled by the caller).
 __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* tile_nent, const u32* tile_off,
                                                        const u32* count, const u32* start, const u32* rows, u64 np, u32* b_idx, u32* p_idx,
-                                                       u32* pair_off, u32* cnt_out, u32* visited, u32 cap) {
+                                                       u32* pair_off, u32* cnt_out, u32* visited, u32 cap, const u32* stat_block,
+                                                       u32* publish, u32* rows_out) {
   constexpr int TILE = 64 * QH_PROBE_R;
+  // a join of deferred size (cap = the room its output has; stat_block = [build status | probe status | pair total]): rows
+  // [total, cap) of the index vectors repeat row 0 of both sides (valid to gather, never counted), the total goes to the
+  // output table's device-side row count and the status block to page-locked host memory, where the consumer's
+  // synchronisation finds it — all in this launch instead of a fill, a copy and a device-to-device copy behind it
+  if (stat_block) {
+    const u32 total = stat_block[2 * QS_WORDS];
+    for (u64 k = (u64)total + (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < cap; k += (u64)gridDim.x * QH_BLOCK) { b_idx[k] = 0; p_idx[k] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x <= 2 * QS_WORDS) {
+      publish[threadIdx.x] = stat_block[threadIdx.x];
+      if (threadIdx.x == 2 * QS_WORDS) *rows_out = total;
+      __threadfence_system();
+    }
+  }
   const int lane = qh_lane();
   const u64 ntiles = (np + TILE - 1) / TILE;
   for (u64 tile = (u64)blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6); tile < ntiles; tile += (u64)gridDim.x * (QH_BLOCK / 64)) {
@@ -530,10 +544,6 @@ __global__ __launch_bounds__(QH_BLOCK) void k_lower_bound_u32(const u32* a, u64 
   u64 lo = 0, hi = m;
   while (lo < hi) { const u64 mid = (lo + hi) >> 1; if ((u64)a[mid] < v) lo = mid + 1; else hi = mid; }
   pos[k] = (u32)lo;
-}
-// deferred sizing: rows [*total, cap) of a join's index vectors repeat row 0 of both sides (valid to gather, never counted)
-__global__ __launch_bounds__(QH_BLOCK) void k_fill_tail_u32(u32* a, u32* b, const u32* total, u32 cap) {
-  for (u64 k = (u64)*total + (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < cap; k += (u64)gridDim.x * QH_BLOCK) { a[k] = 0; b[k] = 0; }
 }
 // ================================================================ sort (physical/plan/sort.rs:48-82)
 // lexsort_to_indices as a sequence of stable LSD radix passes over order-preserving key images, least significant key
@@ -907,16 +917,14 @@ void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u32*)m_dev, (const u64*)bound, nb, (u32*)pos);
 }
-void launch_fill_tail_u32(uint32_t* a, uint32_t* b, const uint32_t* total, uint32_t cap, hipStream_t s) {
-  if (cap) hipLaunchKernelGGL(k_fill_tail_u32, dim3(std::min<uint64_t>(grid_for(cap, QH_BLOCK), 256)), dim3(QH_BLOCK), 0, s, (u32*)a, (u32*)b, (const u32*)total, (u32)cap);
-}
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* tile_nent, const uint32_t* tile_off, const uint32_t* count,
                       const uint32_t* start, const uint32_t* rows, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, uint32_t* pair_off,
-                      uint32_t* cnt_out, uint32_t* visited, uint32_t cap, hipStream_t s) {
+                      uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish, uint32_t* rows_out,
+                      hipStream_t s) {
   if (!np) return;
   hipLaunchKernelGGL(k_join_emit, dim3(grid_for(np, QH_BLOCK * QH_PROBE_R)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
                      (const u32*)tile_nent, (const u32*)tile_off, (const u32*)count, (const u32*)start, (const u32*)rows, (u64)np, (u32*)b_idx,
-                     (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap);
+                     (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap, (const u32*)stat_block, (u32*)publish, (u32*)rows_out);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;

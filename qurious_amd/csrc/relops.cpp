@@ -273,8 +273,9 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, 
 }
 
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
-                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root, bool deferred_status) {
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root, bool deferred_status, uint32_t* status_dev) {
   plan_keys(es, icols, roots, n, kp, predicate_root);
+  if (!status_dev) status_dev = ctx->status.as<uint32_t>();
   const int64_t N = t->num_rows;
   const uint64_t nwords = (uint64_t)(N + 63) / 64;
   keys.alloc((size_t)kp.W * (size_t)N * 8);
@@ -284,10 +285,10 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
   HKArgs ka;
   DevBuf strlit;
   fill_kargs(ctx, t, kp.bind, ka, strlit);
-  if (!deferred_status) QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+  if (!deferred_status) QHIP_HIP_CHECK(hipMemsetAsync(status_dev, 0, QS_WORDS * 4, ctx->stream));
   void* kptr = keys.ptr;
   void* vptr = keyvalid.ptr;
-  void* sptr = ctx->status.ptr;
+  void* sptr = status_dev;
   void* args[] = {&ka, &kptr, &vptr, &sptr};
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
   QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
@@ -295,7 +296,7 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
   // recycled after return: any later writer runs on the same stream, i.e. after this kernel.
   if (deferred_status) return;
   uint32_t status[QS_WORDS];
-  QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+  QHIP_HIP_CHECK(hipMemcpyAsync(status, status_dev, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
   QHIP_HIP_CHECK(sync_stream(ctx->stream));
   check_status_words(status);
 }
@@ -336,7 +337,7 @@ void qhip::settle_rows(const qhip_table* tc) {
       }
     }
   }
-  if (t->pending_offsets) t->pending_offsets->total_rows = m;
+  if (t->pending_offsets) { t->pending_offsets->total_rows = m; t->pending_offsets->search_m = (uint64_t)m; }
   t->rows_dev = nullptr;
   t->rows_host = nullptr;
   t->rows_blk.reset();
@@ -352,6 +353,11 @@ const std::vector<int64_t>& qhip_table::offsets() const {
   if (128 + p.n * 4 + 1024 > ctx->pinned_bytes) {
     pos_v.resize(p.n);
     pos = pos_v.data();
+  }
+  if (p.search_in) {
+    qhip::settle_rows(this);   // (a join of deferred size: the number of pairs must be exact before it is searched)
+    pending_offsets->pos = std::make_shared<qhip::DevBuf>(p.n * 4);
+    qhip::launch_lower_bound_u32(p.search_in->as<uint32_t>(), p.search_m, nullptr, p.bounds->as<uint64_t>(), (uint32_t)p.n, p.pos->as<uint32_t>(), ctx->stream);
   }
   QHIP_HIP_CHECK(hipMemcpyAsync(pos, p.pos->ptr, p.n * 4, hipMemcpyDeviceToHost, ctx->stream));
   QHIP_HIP_CHECK(qhip::sync_stream(ctx->stream));

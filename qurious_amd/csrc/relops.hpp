@@ -46,6 +46,7 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
 void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 // key words [W][N] + validity bitmap of the key expressions `roots`
 void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, const int32_t* roots, int n,
-                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false);
+                    KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false,
+                    uint32_t* status_dev = nullptr);   // (status words: the context's block unless the caller keeps its own)
 
 }  // namespace qhip
