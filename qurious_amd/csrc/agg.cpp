@@ -112,9 +112,12 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
   }
   for (size_t l = 0; l < b.lit_lo.size(); ++l) { a.lit_lo[l] = b.lit_lo[l]; a.lit_hi[l] = b.lit_hi[l]; }
   for (size_t l = 0; l < b.stroff.size() && l < (size_t)kMaxLits + 1; ++l) a.stroff[l] = b.stroff[l];
-  strlit_dev.alloc(b.strlits.size());
-  if (!b.strlits.empty())
-    QHIP_HIP_CHECK(hipMemcpyAsync(strlit_dev.ptr, b.strlits.data(), b.strlits.size(), hipMemcpyHostToDevice, ctx->stream));
+  // (a caller that keeps strlit_dev with its cached plan uploads the literals once: same bindings, same bytes)
+  if (!strlit_dev.ptr || strlit_dev.bytes != b.strlits.size()) {
+    strlit_dev.alloc(b.strlits.size());
+    if (!b.strlits.empty())
+      QHIP_HIP_CHECK(hipMemcpyAsync(strlit_dev.ptr, b.strlits.data(), b.strlits.size(), hipMemcpyHostToDevice, ctx->stream));
+  }
   a.strlit = (const uint8_t*)strlit_dev.ptr;
   a.nrows = t->num_rows;
   a.nrows_dev = t->rows_dev;   // (a join output whose size the host has not waited for: aggregate / join build only)
@@ -285,7 +288,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   uint32_t status[QS_WORDS];
   int retries = 0;
   float main_ms = 0;
-  uint32_t G = 0, guess = 0;
+  uint32_t G = 0, guess = 0, pre_copied = 0;   // (pre_copied: dense slots that came back with the status words)
   std::vector<uint64_t> slots;
   // dense slots fetched together with the status words (one sync), through the context's page-locked scratch
   // (256 of them, or what the plan produced last time plus a quarter while that stays a host-side result)
@@ -302,7 +305,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   struct DevFinal {
     std::unique_ptr<qhip_table> out;
     std::vector<FinCol> fc;
-    DevBuf fc_dev, nulls_dev;
+    DevBuf fc_dev;
     std::vector<std::shared_ptr<DevBuf>> valid_bufs;
     bool has_utf8 = false;
   };
@@ -365,14 +368,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       F.out->cols.push_back(std::move(col));
     }
     F.fc_dev.alloc(F.fc.size() * sizeof(FinCol));
-    F.nulls_dev.alloc((size_t)ncols * 4);
     QHIP_HIP_CHECK(hipMemcpyAsync(F.fc_dev.ptr, F.fc.data(), F.fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
-    QHIP_HIP_CHECK(hipMemsetAsync(F.nulls_dev.ptr, 0, (size_t)ncols * 4, ctx->stream));
-    QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+    // [status words | null count per column], zeroed, from the context's ring; read back together
+    if (ncols > 240) fail(QHIP_UNSUPPORTED, "more than 240 output columns in an aggregate assembled on the device");
+    uint32_t* fin_dev = zeroed_block(ctx, (QS_WORDS + ncols + 31) / 32);
     launch_agg_finalize(dense, cap_rows, g_dev, plan.slot_words, plan.null_mask_word ? 1 : 0, (const FinCol*)F.fc_dev.ptr, ncols,
-                        F.nulls_dev.as<uint32_t>(), ctx->status.as<uint32_t>(), ctx->stream);
-    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned, ctx->status.ptr, QS_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
-    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned + QS_WORDS, F.nulls_dev.ptr, (size_t)ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
+                        fin_dev + QS_WORDS, fin_dev, ctx->stream);
+    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned, fin_dev, (size_t)(QS_WORDS + ncols) * 4, hipMemcpyDeviceToHost, ctx->stream));
   };
   // (call after the stream has been synchronised at least up to the read-backs above)
   auto finish_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t groups, bool synced) -> qhip_table* {
@@ -418,7 +420,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // zeroed, so the kernel launch is the first thing on the stream. (total_slots <= guess there: one compaction always
     // suffices and the table is not needed again after it.)
     const bool use_arena = plan.W > 0 && replicas > 1 && total_slots <= 8192 && table_bytes <= (1u << 20) && env_int("QHIP_AGG_NO_ARENA", 0) == 0;
-    uint32_t* status_dev = ctx->status.as<uint32_t>();
+    // [status words (64 bytes) | compaction counter]: in the arena, else a zeroed block of the context's ring; read back together
+    uint32_t* status_dev = nullptr;
     std::shared_ptr<DevBuf> arena;
     const size_t zero_bytes = 128 + table_bytes;   // status (64) + counter (64) + table
     if (use_arena) {
@@ -437,7 +440,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     } else {
       gtable.alloc(table_bytes);
       QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, table_bytes, ctx->stream));
-      QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+      status_dev = zeroed_block(ctx);
       table_dev = gtable.as<uint64_t>();
     }
     HAggLaunch L;
@@ -522,8 +525,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     } else if (N > 0)
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
-    QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t* const counter_dev = status_dev + 16;   // (page-locked mirror: status_pinned = pinned + 0, pre_host[0] = pinned + 64)
+    pre_copied = 0;
     if (plan.W == 0) {
+      QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
       QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, table_dev, (size_t)slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
     } else {
       // speculative compaction right behind the kernel: [counter | dense slots]; the common case (few groups, no
@@ -532,26 +537,28 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         // counter at +64 (zeroed with the arena), dense slots behind the table; the 8 bytes in front of the slots are a
         // copy target only in the read-back below, so read counter and slots separately
         dense_dev = (uint64_t*)(arena->as<uint8_t>() + zero_bytes) ;
-        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, (uint32_t*)(arena->as<uint8_t>() + 64), guess, ctx->stream);
-        const uint32_t pre = std::min(PRE, guess);
-        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, arena->as<uint8_t>() + 64, 8, hipMemcpyDeviceToHost, ctx->stream));
-        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream);
+        pre_copied = std::min(PRE, guess);
+        QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
+        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
       } else {
         dense.alloc((size_t)guess * slot_bytes + 8);
-        QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
         dense_dev = dense.as<uint64_t>();
-        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
-        const uint32_t pre = std::min(PRE, guess);
-        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host, dense.ptr, 8 + (size_t)pre * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream);
+        QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
         // a plan that produced many groups last time will most likely do so again: assemble its output columns on the
-        // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all
+        // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all,
+        // and no slot crosses PCIe
         bool utf8_key = false;
         for (auto& kd : plan.keys) utf8_key = utf8_key || kd.type.id == QHIP_UTF8;
         spec_enqueued = false;
         if (replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0) {
           spec = DevFinal();
-          enqueue_device_finalize(spec, dense_dev + 1, guess, dense.as<uint32_t>());
+          enqueue_device_finalize(spec, dense_dev + 1, guess, counter_dev);
           spec_enqueued = true;
+        } else {
+          pre_copied = std::min(PRE, guess);
+          QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
         }
       }
     }
@@ -595,10 +602,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       // more groups than the speculative buffer holds: compact again with the exact size
       guess = G;
       dense.alloc((size_t)guess * slot_bytes + 8);
-      QHIP_HIP_CHECK(hipMemsetAsync(dense.ptr, 0, 8, ctx->stream));
       dense_dev = dense.as<uint64_t>();
-      launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, dense.as<uint32_t>(), guess, ctx->stream);
+      launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, zeroed_block(ctx), guess, ctx->stream);
       QHIP_HIP_CHECK(sync_stream(ctx->stream));
+      pre_copied = 0;
     }
     if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
       // the speculative device-side assembly is the result
@@ -622,7 +629,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
     if (replicas == 1 && G >= dev_threshold) {
       dense_keep = std::move(dense);
-    } else if (G <= std::min(PRE, guess)) {
+    } else if (G <= pre_copied) {
       slots.assign(pre_host + 1, pre_host + 1 + (size_t)G * plan.slot_words);
     } else {
       slots.resize((size_t)G * plan.slot_words);

@@ -253,7 +253,7 @@ constexpr int kSizeSlots = 64;
 // hint) when a join produced more pairs than it had room for or met duplicate build keys — what was computed from its
 // output is then garbage and the consumer's input runs again; key / filter errors surface as they would have in the join.
 void verify_pending_sizes(Ctx* ctx);
-uint32_t* zeroed_block(Ctx* ctx);   // 32 zeroed u32 words, valid for the current operator call (ctx.cpp)
+uint32_t* zeroed_block(Ctx* ctx, int n = 1);   // n x 32 contiguous zeroed u32 words, valid for the current operator call (ctx.cpp)
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;

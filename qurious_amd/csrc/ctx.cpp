@@ -27,14 +27,26 @@ void note_sync() {
   }
 }
 
-uint32_t* zeroed_block(Ctx* ctx) {
-  constexpr size_t kBlock = 128, kBlocks = 512;
-  if (!ctx->zero_ring.ptr || ctx->zero_next >= kBlocks) {
-    if (!ctx->zero_ring.ptr) ctx->zero_ring.alloc(kBlock * kBlocks);
-    QHIP_HIP_CHECK(hipMemsetAsync(ctx->zero_ring.ptr, 0, kBlock * kBlocks, ctx->stream));
+uint32_t* zeroed_block(Ctx* ctx, int n) {
+  // two halves of 256 blocks: the half being handed out from was cleared when it was entered; moving on to the other half
+  // clears THAT one only, so blocks a call already holds (it may ask for several, one after another) stay intact — a
+  // single call would have to take more than 256 blocks to catch up with itself
+  constexpr size_t kBlock = 128, kHalf = 256;
+  if (n < 1 || (size_t)n > kHalf / 4) fail(QHIP_HIP_ERROR, "zeroed_block: bad block count (internal error)");
+  if (!ctx->zero_ring.ptr) {
+    ctx->zero_ring.alloc(kBlock * kHalf * 2);
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->zero_ring.ptr, 0, kBlock * kHalf, ctx->stream));
     ctx->zero_next = 0;
   }
-  return (uint32_t*)(ctx->zero_ring.as<uint8_t>() + kBlock * ctx->zero_next++);
+  size_t half = ctx->zero_next / kHalf, off = ctx->zero_next % kHalf;
+  if (ctx->zero_next == 2 * kHalf || off + (size_t)n > kHalf || (off == 0 && ctx->zero_next != 0)) {
+    half = ctx->zero_next == 2 * kHalf ? 0 : (off == 0 ? half : half + 1) % 2;
+    QHIP_HIP_CHECK(hipMemsetAsync(ctx->zero_ring.as<uint8_t>() + half * kHalf * kBlock, 0, kBlock * kHalf, ctx->stream));
+    off = 0;
+  }
+  uint32_t* p = (uint32_t*)(ctx->zero_ring.as<uint8_t>() + (half * kHalf + off) * kBlock);
+  ctx->zero_next = half * kHalf + off + (size_t)n;
+  return p;
 }
 
 void verify_pending_sizes(Ctx* ctx) {

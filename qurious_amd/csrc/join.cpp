@@ -149,7 +149,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const int v[3] = {lpred, rpred, want_regions ? 1 : 0};
     put(v, sizeof v);
   }
-  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod; };
+  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
   std::shared_ptr<JoinPlan> jp;
   {
     auto cached = ctx->plan_cache.find(pkey);
@@ -213,8 +213,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);
     const std::shared_ptr<Module>& mod = jp->lmod;
     HKArgs ka;
-    DevBuf strlit;
-    fill_kargs(ctx, L, lkp.bind, ka, strlit);
+    fill_kargs(ctx, L, lkp.bind, ka, jp->lstr);
     // a step-1 workgroup (1024 threads) owns a row range of two or three rows per thread when the rows allow (2
     // workgroups per CU); its entries stay inside the range, so nothing is shared between workgroups
     uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>((B + 2047) / 2048, (uint64_t)ctx->num_cus * 2));
@@ -295,8 +294,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (!jp->rmod) jp->rmod = get_module(ctx, rkp.source, rkp.kernel_name);
     const std::shared_ptr<Module>& mod = jp->rmod;
     HKArgs ka;
-    DevBuf strlit;
-    fill_kargs(ctx, R, rkp.bind, ka, strlit);
+    fill_kargs(ctx, R, rkp.bind, ka, jp->rstr);
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
     DevBuf tile_tot((ntiles + 1) * 4), tile_nent((ntiles + 1) * 4);
     HProbeLaunch pl;

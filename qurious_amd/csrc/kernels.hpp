@@ -55,6 +55,11 @@ void launch_sort_utf8_chunk(const int32_t* offsets, const uint8_t* data, const u
                             uint64_t flip, uint64_t* out, hipStream_t s);
 void stable_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
                            hipStream_t s);
+// several fixed-width gathers (out[k] = in[idx[k]], NULL index -> zero) in one launch
+struct GatherDesc { const void* in; const uint32_t* idx; void* out; uint64_t m; uint32_t width; uint32_t pad_; };
+constexpr int kGatherBatch = 8;
+struct GatherBatch { GatherDesc d[kGatherBatch]; };
+void launch_gather_multi(const GatherBatch& b, int n, hipStream_t s);
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s);
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s);
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* tile_nent, const uint32_t* tile_off, const uint32_t* count,

@@ -178,6 +178,29 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_fixed(const T* in, const u3
     out[k] = v;
   }
 }
+// ... several columns in ONE launch (blockIdx.y = the column): what an aggregate / join reads from a join output are a few
+// short fixed-width columns, each a ~5 us launch of its own otherwise
+template <class T>
+__device__ __forceinline__ void qh_gather_loop(const void* in_, const u32* idx, void* out_, u64 m) {
+  const T* in = (const T*)in_;
+  T* out = (T*)out_;
+  for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
+    const u32 i = idx[k];
+    T v;
+    if (i == QH_NULL_IDX) memset(&v, 0, sizeof(T)); else v = in[i];
+    out[k] = v;
+  }
+}
+__global__ __launch_bounds__(QH_BLOCK) void k_gather_multi(GatherBatch b) {
+  const GatherDesc d = b.d[blockIdx.y];
+  switch (d.width) {
+    case 1: qh_gather_loop<u8>(d.in, d.idx, d.out, d.m); break;
+    case 2: qh_gather_loop<u16>(d.in, d.idx, d.out, d.m); break;
+    case 4: qh_gather_loop<u32>(d.in, d.idx, d.out, d.m); break;
+    case 8: qh_gather_loop<u64>(d.in, d.idx, d.out, d.m); break;
+    default: qh_gather_loop<u128>(d.in, d.idx, d.out, d.m); break;
+  }
+}
 // Mask-driven compaction of a fixed-width column (Filter with a predicate that keeps a good part of the rows): wavefront
 // word j of the keep mask covers rows 64 j .. 64 j + 63; a kept row's value goes to wave_offset[j] + its rank inside the
 // word. The input is read in row order (fully coalesced, the dropped rows' bytes ride along), the output is written in
@@ -804,6 +827,12 @@ void launch_gather_fixed(const void* in, const uint32_t* idx, void* out, uint64_
     case 8: hipLaunchKernelGGL(k_gather_fixed<u64>, g, b, 0, s, (const u64*)in, (const u32*)idx, (u64*)out, (u64)m); break;
     default: hipLaunchKernelGGL(k_gather_fixed<u128>, g, b, 0, s, (const u128*)in, (const u32*)idx, (u128*)out, (u64)m); break;
   }
+}
+void launch_gather_multi(const GatherBatch& b, int n, hipStream_t s) {
+  uint64_t m = 0;
+  for (int k = 0; k < n; ++k) m = std::max<uint64_t>(m, b.d[k].m);
+  if (!m || n <= 0) return;
+  hipLaunchKernelGGL(k_gather_multi, dim3(grid_for(m), (unsigned)n), dim3(QH_BLOCK), 0, s, b);
 }
 void launch_compact_fixed(const void* in, const uint64_t* mask, const uint32_t* wave_offset, void* out, uint64_t nrows, int width, hipStream_t s) {
   if (!nrows) return;

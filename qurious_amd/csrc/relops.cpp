@@ -215,6 +215,45 @@ void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::share
 }
 
 void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs) {
+  // the plain cases first, together: deferred gathers of fixed-width columns without NULLs (no validity to gather, nothing
+  // to count) go into ONE launch per 8 columns
+  {
+    std::vector<DeferredGather*> batch;
+    std::vector<bool> seen(t->cols.size(), false);
+    for (int k = 0; k < n_exprs; ++k) {
+      if (exprs[k].kind != QHIP_EXPR_COLUMN || exprs[k].column < 0 || exprs[k].column >= (int)t->cols.size() || seen[(size_t)exprs[k].column]) continue;
+      seen[(size_t)exprs[k].column] = true;
+      const DevColumn& c = t->cols[(size_t)exprs[k].column];
+      if (!c.deferred || c.deferred->done || c.pending_upload) continue;
+      DeferredGather& d = *c.deferred;
+      if (d.idx_may_be_null || d.src.deferred || d.src.pending_upload || d.src.null_count > 0 || dtype_width(d.src.type) <= 0 || !d.src.values || d.m == 0) continue;
+      batch.push_back(&d);
+    }
+    for (size_t first = 0; batch.size() >= 2 && first < batch.size(); first += (size_t)kGatherBatch) {
+      GatherBatch gb;
+      memset(&gb, 0, sizeof gb);
+      const int n = (int)std::min<size_t>((size_t)kGatherBatch, batch.size() - first);
+      for (int j = 0; j < n; ++j) {
+        DeferredGather& d = *batch[first + (size_t)j];
+        DevColumn out;
+        out.type = d.src.type;
+        out.length = (int64_t)d.m;
+        out.utf8_max_len = d.src.utf8_max_len;
+        out.value_maxabs = d.src.value_maxabs;
+        const int w = dtype_width(d.src.type);
+        out.values = std::make_shared<DevBuf>((size_t)d.m * (size_t)w);
+        gb.d[j] = GatherDesc{d.src.values->ptr, d.idx->as<uint32_t>(), out.values->ptr, d.m, (uint32_t)w, 0};
+        d.result = std::move(out);
+      }
+      launch_gather_multi(gb, n, ctx->stream);
+      for (int j = 0; j < n; ++j) {   // (the launch holds raw pointers: the sources may go only now — stream-ordered pool)
+        DeferredGather& d = *batch[first + (size_t)j];
+        d.done = true;
+        d.src = DevColumn();
+        d.idx.reset();
+      }
+    }
+  }
   for (int k = 0; k < n_exprs; ++k)
     if (exprs[k].kind == QHIP_EXPR_COLUMN && exprs[k].column >= 0 && exprs[k].column < (int)t->cols.size())
       (void)resolved(ctx, t->cols[(size_t)exprs[k].column]);
