@@ -800,16 +800,17 @@ struct ProbeLaunch {
   const u32* count;      // build rows per slot (unused when start == nullptr)
   const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
-  u32* ent_slot;         // out, per tile of 64 * QH_PROBE_R consecutive probe rows (one wavefront's share): the matching rows,
-  u32* ent_row;          //      compacted in row order at [tile * TILE, tile * TILE + tile_nent[tile]): slot of the key (unique
-                         //      build keys: the build row itself) and probe row. Rows without a match write nothing.
-  u32* tile_nent;        // out, per tile: number of matching probe rows
-  u32* tile_total;       // out, per tile: number of (build, probe) pairs
+  u32* ent_slot;         // out, per CHUNK (the tiles_per_wave consecutive tiles of 64 * QH_PROBE_R probe rows one wavefront owns): the
+  u32* ent_row;          //      matching rows, compacted in row order from the chunk's first row position on: slot of the key
+                         //      (unique build keys: the build row itself) and probe row. Rows without a match write nothing.
+  u32* tile_nent;        // out, per chunk: number of matching probe rows
+  u32* tile_total;       // out, per chunk: number of (build, probe) pairs
   u32* visited;          // build-row bitmap to mark here (LeftSemi / LeftAnti without a residual filter) or nullptr
   u32* status;
   u32 nslots, bloom_mask;  // legacy layout: slots of the one table (power of two), 64-bit words of the filter - 1
   u32 n_regions;           // region layout (0 = legacy): regions of 2^slot_bits slots, each with a filter slice of
   u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; dbg: timing experiments only (QHIP_PROBE_DBG, results are wrong)
+  u32 tiles_per_wave, pad_;          // wavefront w of the grid owns tiles [w * tiles_per_wave, (w + 1) * tiles_per_wave)
 };
 
 // The build's hash filter is a blocked Bloom filter: FOUR bits per key inside ONE 64-bit word (two in each half), sized at
@@ -860,14 +861,14 @@ struct QhProbeTile {
   i64 tile;                                              // wave-uniform
   bool live;                                             // wave-uniform: a real tile of this wavefront (not a drain trip's)
 };
-struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, stride, mine; };
+struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, mine; u32 nent, total; };   // (nent / total: the chunk so far, wave-uniform)
 
 // stage 1: issue the column loads of the wavefront's j-th tile (j beyond its last tile: tile 0 once more, not live)
 template <class P>
 __device__ __forceinline__ void qh_probe_stage1(const KArgs& a, QhProbeTile<P>& x, const QhProbeCtx& c, i64 j) {
   constexpr int R = QH_PROBE_R, TILE = 64 * R;
   x.live = j < c.mine;
-  x.tile = x.live ? c.first + j * c.stride : 0;   // (a drain trip reads tile 0: the same L2-resident lines for every wavefront)
+  x.tile = x.live ? c.first + j : 0;   // (a drain trip reads tile 0: the same L2-resident lines for every wavefront)
   const i64 tb = x.tile * TILE;
   // row r * 64 + lane: the lanes of one load / lookup instruction hold 64 CONSECUTIVE rows. Fact tables are usually stored
   // in foreign-key order (lineitem by order key), so the filter and table lookups of an instruction fall into few cache
@@ -914,7 +915,7 @@ __device__ __forceinline__ void qh_probe_stage3(const ProbeLaunch& L, QhProbeTil
 }
 // stage 4: compare the home slot, walk on after a collision (rare: the filter), write the tile's entries and counts
 template <class P>
-__device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c) {
+__device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTile<P>& x, QhProbeCtx& c) {
   constexpr int R = QH_PROBE_R, TILE = 64 * R, W = P::W;
   const int lane = c.lane;
   u32 sid[R];
@@ -932,7 +933,7 @@ __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTil
     }
   }
   if (!x.live) return;   // wave-uniform: a drain trip writes nothing
-  u32 total = 0, nent = 0;
+  u32 total = 0, nent = c.nent;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool found = sid[r] != 0xFFFFFFFFu;
@@ -941,12 +942,14 @@ __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTil
     total += found ? cnt : 0u;
     const u64 m = qh_ballot(found);
     if (found) {
-      const size_t pos = (size_t)x.tile * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+      // the chunk's entries are appended tile after tile: nent is the chunk's running count (<= the rows seen so far)
+      const size_t pos = (size_t)c.first * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
       L.ent_slot[pos] = sid[r];
       L.ent_row[pos] = (u32)(x.tile * TILE + r * 64 + lane);
     }
     nent += (u32)__builtin_popcountll(m);
   }
+  c.nent = nent;
   if (L.visited) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -955,8 +958,7 @@ __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTil
         for (u32 q = 0; q < cnt; ++q) { const u32 b = L.start ? L.rows[s0 + q] : sid[r]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
       }
   }
-  total = (u32)qh_wave_sum_u64(total);
-  if (lane == 0) { L.tile_total[x.tile] = total; L.tile_nent[x.tile] = nent; }
+  c.total += (u32)qh_wave_sum_u64(total);   // (published once per chunk, at the end of the kernel)
 }
 
 template <class P>
@@ -968,11 +970,17 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
   c.regions = L.n_regions != 0;
   c.smask = c.regions ? (1u << L.slot_bits) - 1u : L.nslots - 1u;
   c.lane = qh_lane();
-  // the wavefront's tiles: first, first + stride, ... (wave-uniform numbers, kept in SGPRs: the pipeline's control flow is scalar)
-  c.stride = (i64)gridDim.x * NW;
-  c.first = (i64)blockIdx.x * NW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (c.first >= ntiles) return;
-  c.mine = (ntiles - c.first + c.stride - 1) / c.stride;
+  // the wavefront's chunk: tiles first .. first + mine - 1 (wave-uniform numbers, kept in SGPRs: the pipeline's control flow is
+  // scalar). A chunk's matches form ONE run of entries and one (count, pair total) — pass 2 and the scan in front of it work
+  // per chunk, not per tile (Q3's lineitem probe: 19.5 k chunks instead of 234 k tiles with 1.4 matches each)
+  const i64 wave = (i64)blockIdx.x * NW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  c.first = wave * (i64)L.tiles_per_wave;
+  c.nent = 0; c.total = 0;
+  if (c.first >= ntiles) {
+    if (c.lane == 0) { L.tile_total[wave] = 0; L.tile_nent[wave] = 0; }
+    return;
+  }
+  c.mine = ntiles - c.first < (i64)L.tiles_per_wave ? ntiles - c.first : (i64)L.tiles_per_wave;
   u32 err = 0;
   QhProbeTile<P> A, B, C;
   // fill the pipeline. EVERY stage call below and in the loop is unconditional and works on a real tile (the trips behind
@@ -997,6 +1005,7 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
     QH_PROBE_TRIP(C, A, B, j + 2)
   }
 #undef QH_PROBE_TRIP
+  if (c.lane == 0) { L.tile_total[wave] = c.total; L.tile_nent[wave] = c.nent; }
   qh_report(L.status, err);
 }
 

@@ -296,7 +296,17 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     HKArgs ka;
     fill_kargs(ctx, R, rkp.bind, ka, jp->rstr);
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
-    DevBuf tile_tot((ntiles + 1) * 4), tile_nent((ntiles + 1) * 4);
+    // a wavefront owns a CHUNK of consecutive tiles (~12 once every CU has work: it pays three trips to fill and drain its
+    // pipeline); the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of
+    // exactly the assumed residency that is one short runs its remainder as a second round) — the hardware deals them out as
+    // earlier ones finish, so the tail is a fraction of one workgroup's share. A chunk's matches are one run of entries with
+    // one count: the scan and pass 2 work per chunk.
+    const uint64_t tpw_max = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
+    const uint64_t waves_wanted = std::max<uint64_t>(std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cus * 16), (ntiles + tpw_max - 1) / tpw_max);
+    const uint64_t tiles_per_wave = (ntiles + waves_wanted - 1) / waves_wanted;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, ((ntiles + tiles_per_wave - 1) / tiles_per_wave + 3) / 4);
+    const uint64_t nchunks = (uint64_t)grid * 4;
+    DevBuf tile_tot((nchunks + 1) * 4), tile_nent((nchunks + 1) * 4);
     HProbeLaunch pl;
     pl.table = table; pl.bloom = bloom; pl.count = count; pl.start = start_ptr; pl.rows = rows_ptr;
     pl.ent_slot = ent_slot.as<uint32_t>();
@@ -308,18 +318,13 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.nslots = nslots; pl.bloom_mask = filter_words - 1;
     pl.n_regions = n_regions; pl.slot_bits = slot_bits; pl.bword_bits = bword_bits;
     pl.dbg = (uint32_t)env_int("QHIP_PROBE_DBG", 0);
+    pl.tiles_per_wave = (uint32_t)tiles_per_wave;
     void* args[] = {&ka, &pl};
-    // ~12 tiles per wavefront once every CU has work: each wavefront pays three trips to fill and drain its pipeline,
-    // and the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of exactly
-    // the assumed residency that is one short runs its remainder as a second round) — the hardware deals them out as
-    // earlier ones finish, so the tail is a fraction of one workgroup's share
-    const uint64_t tpw = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::max<uint64_t>(std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 4), (ntiles + 4 * tpw - 1) / (4 * tpw)));
     hipEventRecord(ctx->ev[2], s);
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     hipEventRecord(ctx->ev[3], s);
     probe_timed = true;
-    if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), ntiles, dstat + 2 * QS_WORDS, s);
+    if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), nchunks, dstat + 2 * QS_WORDS, s);
     if (defer) {
       // no read-back: the status block + total go to a page-locked slot that the consumer's synchronisation checks
       if (!ctx->size_slots) QHIP_HIP_CHECK(hipHostMalloc((void**)&ctx->size_slots, (size_t)kSizeSlots * 32 * 4, hipHostMallocDefault));
@@ -331,7 +336,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       p_idx.alloc((M + 1) * 4);
       rows_blk = std::make_shared<DevBuf>(64);   // the output table's device-side row count
       // pass 2 also pads the index vectors up to the capacity, publishes the status block to `slot` and the total to rows_blk
-      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        nullptr, nullptr, nullptr, (uint32_t)M, dstat, slot, rows_blk->as<uint32_t>(), s);
       deferred_slot = slot;
     } else {
@@ -361,7 +366,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
         pair_off.alloc((P + 1) * 4);
         QHIP_HIP_CHECK(hipMemsetAsync(cnt.ptr, 0, cnt.bytes, s));   // pass 2 only visits matching probe rows
       }
-      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, P, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
                        mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, nullptr, nullptr, nullptr, s);
     }

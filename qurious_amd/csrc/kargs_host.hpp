@@ -73,8 +73,9 @@ struct HProbeLaunch {
   uint32_t* status;
   uint32_t nslots, bloom_mask;
   uint32_t n_regions = 0, slot_bits = 0, bword_bits = 0, dbg = 0;   // region layout of the LDS-staged build (0 = legacy)
+  uint32_t tiles_per_wave = 1, pad_ = 0;
 };
-static_assert(sizeof(HProbeLaunch) == 11 * 8 + 8 + 16, "ProbeLaunch layout");
+static_assert(sizeof(HProbeLaunch) == 11 * 8 + 8 + 16 + 8, "ProbeLaunch layout");
 
 struct HScatterLaunch {
   uint64_t* entries;

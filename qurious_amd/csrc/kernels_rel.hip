@@ -109,10 +109,55 @@ __global__ __launch_bounds__(QH_BLOCK) void k_scan_sums_inplace(u32* sums, u32 n
   if (threadIdx.x == 0) { sums[nchunks] = carry_s; if (total) *total = carry_s; }
 }
 
+// up to 64 k values in ONE launch of one workgroup (thread t owns ceil(n / 1024) consecutive values): the three launches of
+// the chunked scan below cost ~15 us of stream time whatever n is
+__global__ __launch_bounds__(1024) void k_scan_small(const u32* in, u32* out, u32 n, u32* total) {
+  __shared__ u32 wsum[16];
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  constexpr int MAXV = 16;                                  // 16 x 4 values per thread: n <= 65536
+  const u32 tid = threadIdx.x;
+  const u32 nv = ((n + 1023u) / 1024u + 3u) / 4u;           // 16-byte vectors per thread (wave-uniform)
+  const u32 first = tid * nv * 4u;
+  v4u v[MAXV];
+  // all loads first (independent, 16 bytes each), then the sums: a dependent chain of 4-byte loads costs ~1 us per step
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const u32 i = first + (u32)k * 4u;
+    v[k] = (v4u)(0u);
+    if ((u32)k < nv) {
+      if (i + 3u < n) v[k] = *(const v4u*)(in + i);
+      else { v[k].x = i < n ? in[i] : 0u; v[k].y = i + 1u < n ? in[i + 1] : 0u; v[k].z = i + 2u < n ? in[i + 2] : 0u; }
+    }
+  }
+  u32 sum = 0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+  const u32 incl = wave_incl_scan_u32(sum);
+  if ((tid & 63u) == 63u) wsum[tid >> 6] = incl;
+  __syncthreads();
+  u32 run = incl - sum;
+  for (u32 w = 0; w < (tid >> 6); ++w) run += wsum[w];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const u32 i = first + (u32)k * 4u;
+    if ((u32)k < nv && i < n) {
+      v4u o;
+      o.x = run; o.y = run + v[k].x; o.z = o.y + v[k].y; o.w = o.z + v[k].z;
+      if (i + 3u < n) *(v4u*)(out + i) = o;
+      else { out[i] = o.x; if (i + 1u < n) out[i + 1] = o.y; if (i + 2u < n) out[i + 2] = o.z; }
+    }
+    run += v[k].x + v[k].y + v[k].z + v[k].w;
+  }
+  if (tid == 1023u && total) *total = run;
+}
 // out[i] = sum(in[0..i)); out may alias in. *total (device) receives the grand total when non-null.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, hipStream_t s) {
   if (n == 0) {
     if (total_dev) hipMemsetAsync(total_dev, 0, 4, s);
+    return;
+  }
+  if (n <= 65536 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0) {   // (16-byte loads / stores)
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, (const u32*)in, (u32*)out, (u32)n, (u32*)total_dev);
     return;
   }
   const uint64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -489,11 +534,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table,
 // same tile as in pass 1; tile_off is the exclusive scan of pass 1's per-tile pair counts. Unique build keys
 // (start == nullptr): the entry already holds the one build row. cnt_out / pair_off (Right / Full joins) receive the
 // pair count and first pair position of every MATCHING probe row (cnt_out is zero-filled by the caller).
-__global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* tile_nent, const u32* tile_off,
-                                                       const u32* count, const u32* start, const u32* rows, u64 np, u32* b_idx, u32* p_idx,
-                                                       u32* pair_off, u32* cnt_out, u32* visited, u32 cap, const u32* stat_block,
+__global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* chunk_nent, const u32* chunk_off,
+                                                       const u32* count, const u32* start, const u32* rows, u64 nchunks, u64 chunk_rows, u32* b_idx,
+                                                       u32* p_idx, u32* pair_off, u32* cnt_out, u32* visited, u32 cap, const u32* stat_block,
                                                        u32* publish, u32* rows_out) {
-  constexpr int TILE = 64 * QH_PROBE_R;
   // a join of deferred size (cap = the room its output has; stat_block = [build status | probe status | pair total]): rows
   // [total, cap) of the index vectors repeat row 0 of both sides (valid to gather, never counted), the total goes to the
   // output table's device-side row count and the status block to page-locked host memory, where the consumer's
@@ -508,14 +552,15 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, con
     }
   }
   const int lane = qh_lane();
-  const u64 ntiles = (np + TILE - 1) / TILE;
-  for (u64 tile = (u64)blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6); tile < ntiles; tile += (u64)gridDim.x * (QH_BLOCK / 64)) {
-    const u32 n = tile_nent[tile];
-    u32 base = tile_off[tile];
+  // a wavefront per chunk (the consecutive tiles one probe wavefront owned): its entries are one run
+  for (u64 ch = (u64)blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6); ch < nchunks; ch += (u64)gridDim.x * (QH_BLOCK / 64)) {
+    const u32 n = chunk_nent[ch];
+    u32 base = chunk_off[ch];
+    const u64 e0 = ch * chunk_rows;
     for (u32 j0 = 0; j0 < n; j0 += 64) {
       const u32 j = j0 + lane;
       const bool live = j < n;
-      const u32 sid = live ? ent_slot[tile * TILE + j] : 0u, p = live ? ent_row[tile * TILE + j] : 0u;
+      const u32 sid = live ? ent_slot[e0 + j] : 0u, p = live ? ent_row[e0 + j] : 0u;
       u32 c = start ? count[sid] : 1u;
       c = live ? c : 0u;
       const u32 incl = wave_incl_scan_u32(c);
@@ -946,14 +991,15 @@ void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u32*)m_dev, (const u64*)bound, nb, (u32*)pos);
 }
-void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* tile_nent, const uint32_t* tile_off, const uint32_t* count,
-                      const uint32_t* start, const uint32_t* rows, uint64_t np, uint32_t* b_idx, uint32_t* p_idx, uint32_t* pair_off,
-                      uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish, uint32_t* rows_out,
-                      hipStream_t s) {
-  if (!np) return;
-  hipLaunchKernelGGL(k_join_emit, dim3(grid_for(np, QH_BLOCK * QH_PROBE_R)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
-                     (const u32*)tile_nent, (const u32*)tile_off, (const u32*)count, (const u32*)start, (const u32*)rows, (u64)np, (u32*)b_idx,
-                     (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap, (const u32*)stat_block, (u32*)publish, (u32*)rows_out);
+void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
+                      const uint32_t* start, const uint32_t* rows, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
+                      uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish,
+                      uint32_t* rows_out, hipStream_t s) {
+  if (!nchunks) return;
+  hipLaunchKernelGGL(k_join_emit, dim3(grid_for(nchunks * 64, QH_BLOCK)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
+                     (const u32*)chunk_nent, (const u32*)chunk_off, (const u32*)count, (const u32*)start, (const u32*)rows, (u64)nchunks,
+                     (u64)chunk_rows, (u32*)b_idx, (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap, (const u32*)stat_block,
+                     (u32*)publish, (u32*)rows_out);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;
