@@ -114,13 +114,18 @@ def operator_stats(step, passes=5):
     """`passes` instrumented (untimed) executions of `step`: per operator call, in execution order, the mean of its
     qhip_exec_stats timings (HIP events on the library's stream) and its last other fields."""
     runs = []
-    for _ in range(passes):
-        qplan.STATS_SINK = []
-        try:
-            step()
-        finally:
-            sink, qplan.STATS_SINK = qplan.STATS_SINK, None
-        runs.append(sink)
+    ctx = q.get_context()
+    ctx.set_timing(True)    # (HIP events around the operators' phases: off in the timed region, they cost stream time)
+    try:
+        for _ in range(passes):
+            qplan.STATS_SINK = []
+            try:
+                step()
+            finally:
+                sink, qplan.STATS_SINK = qplan.STATS_SINK, None
+            runs.append(sink)
+    finally:
+        ctx.set_timing(False)
     out = []
     for k, (label, st) in enumerate(runs[-1]):
         same = [r[k][1] for r in runs if len(r) == len(runs[-1])]
@@ -413,8 +418,12 @@ class FilterBench:
             elapsed = clock.run(lambda: plan.execute_device(), max(3, args.steps // 2), 2)
             steps = max(3, args.steps // 2)
             qplan.STATS_SINK = None
-            res = plan.execute_device()
-            st = self.ctx.last_stats()
+            self.ctx.set_timing(True)    # (one instrumented, untimed execution: HIP events around the operator)
+            try:
+                res = plan.execute_device()
+                st = self.ctx.last_stats()
+            finally:
+                self.ctx.set_timing(False)
             kept = res.num_rows
             # bytes the operator moves: the predicate column once, then per kept row every column's value read and written + the
             # 4-byte selection index read once per column

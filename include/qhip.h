@@ -201,6 +201,10 @@ int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out);
 /* Host waits on the device (stream / event synchronisations) this process has made through the library so far: the
  * "host round trips" a plan costs = the difference around its execution. */
 uint64_t qhip_ctx_sync_count(const qhip_ctx* ctx);
+/* Timings in qhip_exec_stats (main_kernel_ms, total_device_ms, build_ms) come from HIP events recorded around an operator's
+ * phases. Every event record is a packet of its own on the stream (~5 us of stream time each; a two-join query recorded
+ * ten), so they are OFF by default (the fields then read 0): switch them on for instrumented runs (or QHIP_TIMING=1). */
+int qhip_ctx_set_timing(qhip_ctx* ctx, int32_t on);
 /* Deferred sizing. A hash join normally waits for its pair total to size its output (one host round trip per join). It
  * also remembers, per join (expressions, join type, probe rows — not the data), how many pairs it produced. While
  * deferred sizes are allowed, an Inner join with such a hint does NOT wait: its output is allocated for the remembered

@@ -133,6 +133,7 @@ def load_library() -> C.CDLL:
             "qhip_ctx_last_stats": (C.c_int, [vp, P(qhip_exec_stats)]),
             "qhip_ctx_synchronize": (C.c_int, [vp]),
             "qhip_ctx_sync_count": (C.c_uint64, [vp]),
+            "qhip_ctx_set_timing": (C.c_int, [vp, i32]),
             "qhip_ctx_allow_deferred_sizes": (C.c_int, [vp, i32]),
             "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
@@ -201,6 +202,10 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.qhip_ctx_synchronize(self.handle))
+
+    def set_timing(self, on: bool):
+        """qhip_exec_stats timings (HIP events around an operator's phases) on / off; off by default, they cost stream time."""
+        self.check(self.lib.qhip_ctx_set_timing(self.handle, 1 if on else 0))
 
     def sync_count(self) -> int:
         """Host waits on the device made through the library so far (the difference around a plan = its round trips)."""

@@ -59,6 +59,18 @@ def catalog_sources():
             os.environ.pop("QHIP_AGG_R", None)
         else:
             os.environ["QHIP_AGG_R"] = saved
+    # a repeated Q3 runs its joins with DEFERRED sizes (qhip.h: qhip_ctx_allow_deferred_sizes): join 2's build kernel and the
+    # aggregate then read their input's row count on the device — separate instantiations of the same bodies
+    os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
+    os.environ["QHIP_AGG_R"] = "1"
+    try:
+        out.append(("q3 join-1 output build entries, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        out.append(("q3 aggregate, 1 row/thread, device-side row count", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+    finally:
+        os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
+        os.environ.pop("QHIP_AGG_R", None)
+        if saved is not None:
+            os.environ["QHIP_AGG_R"] = saved
     top = queries.q3_top10(*tabs)
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)

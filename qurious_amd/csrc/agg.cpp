@@ -192,6 +192,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const int r_env = env_int("QHIP_AGG_R", 0) ? env_int("QHIP_AGG_R", 0) : in->num_rows <= small_rows ? 1 : in->num_rows <= 2 * small_rows ? 2 : 0;
   const int kc_env = env_int("QHIP_AGG_KC", -1);
   put(&r_env, sizeof r_env); put(&kc_env, sizeof kc_env);
+  const int dev_rows = in->rows_dev ? 1 : 0;   // (a join output of deferred size: the kernel variant that reads the row count on the device)
+  put(&dev_rows, sizeof dev_rows);
   std::shared_ptr<AggPlan> plan_ptr;
   auto cached = ctx->plan_cache.find(key);
   if (cached != ctx->plan_cache.end()) plan_ptr = std::static_pointer_cast<AggPlan>(cached->second);
@@ -199,7 +201,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ExprSet es;
     es.build(exprs, n_exprs, icols);
     plan_ptr = std::make_shared<AggPlan>();
-    plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, r_env, *plan_ptr);
+    plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, r_env, *plan_ptr, dev_rows != 0);
     if (ctx->plan_cache.size() > 4096) ctx->plan_cache.clear();
     ctx->plan_cache[key] = plan_ptr;
   }
@@ -222,9 +224,11 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   };
   if (n_groups > 0 && zero_batches_in) return no_batches_out();
 
-  std::shared_ptr<Module> mod = get_module(ctx, plan.source, plan.kernel_name);
+  if (!plan.module) plan.module = get_module(ctx, plan.source, plan.kernel_name);
+  std::shared_ptr<Module> mod = std::static_pointer_cast<Module>(plan.module);
   HKArgs ka;
-  DevBuf strlit;
+  if (!plan.strlit) plan.strlit = std::make_shared<DevBuf>();
+  DevBuf& strlit = *std::static_pointer_cast<DevBuf>(plan.strlit);
   fill_kargs(ctx, in, plan.bind, ka, strlit);
   mark("module + kargs");
 
@@ -451,7 +455,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     L.replicas = replicas;
     L.collect_stats = env_int("QHIP_AGG_STATS", 0) ? 1u : 0u;
     void* args[] = {&ka, &L};
-    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+    time_mark(ctx, 0);
     // Many groups on a big input: partition the rows by key hash first, so that every bin's groups fit an LDS table and the
     // HBM table is touched once per GROUP instead of once per row (device/qhip_device.hpp, "partitioned aggregation").
     // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
@@ -524,7 +528,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
 
     } else if (N > 0)
       QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
-    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
+    time_mark(ctx, 1);
     uint32_t* const counter_dev = status_dev + 16;   // (page-locked mirror: status_pinned = pinned + 0, pre_host[0] = pinned + 64)
     pre_copied = 0;
     if (plan.W == 0) {
@@ -578,7 +582,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
     // a join of deferred size that turned out to have produced nothing has no output batches (hash_join.rs:363-372)
     if (in->rows_dev && in->rows_host && *in->rows_host == 0 && n_groups > 0) return no_batches_out();
-    QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
+    if (ctx->timing) QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;
     if (replicas == 1 && cap >= cap_max) fail(QHIP_HIP_ERROR, "group table overflow at maximum capacity (internal error)");

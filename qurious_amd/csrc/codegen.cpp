@@ -561,7 +561,8 @@ static std::string ord64(const DType& t, const std::string& v) {
 }
 
 void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, const int32_t* group_roots, int n_groups,
-                    const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& P) {
+                    const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& P, bool dev_rows) {
+  const char* dr = dev_rows ? ", true" : "";   // the instantiation that reads the row count from the device (a join output of deferred size)
   P = AggPlan();
   P.R = rows_per_thread;
   if (predicate_root >= 0 && es.at(predicate_root).type.id != QHIP_BOOL)
@@ -859,11 +860,11 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "    slot_update<MemHbm>(gs, q);\n  }\n";
   s << "};\n";
   P.kernel_name = "qk_filter_agg";
-  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P>(a, L); }\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P" << dr << ">(a, L); }\n";
   if (P.W > 0) {
     // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)
-    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_hist(KArgs a, PartLaunch L) { qh_agg_part_body<P, false>(a, L); }\n";
-    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_scatter(KArgs a, PartLaunch L) { qh_agg_part_body<P, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_hist(KArgs a, PartLaunch L) { qh_agg_part_body<P, false" << dr << ">(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_scatter(KArgs a, PartLaunch L) { qh_agg_part_body<P, true" << dr << ">(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_reduce(ReduceLaunch R, AggLaunch L) { qh_agg_reduce_body<P>(R, L); }\n";
   }
   P.source = s.str();
@@ -888,7 +889,7 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
 }
 
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root,
-               int kernel) {
+               int kernel, bool dev_rows) {
   out = KeysPlan();
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
@@ -925,7 +926,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   if (kernel == KEYS_KERNEL_PROBE)
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P>(a, L); }\n";
   else if (kernel == KEYS_KERNEL_SCATTER)
-    s << "extern \"C\" __global__ __launch_bounds__(QH_SCATTER_BLOCK) void qk_join_scatter(KArgs a, ScatterLaunch L) { qh_join_scatter_body<P>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_SCATTER_BLOCK) void qk_join_scatter(KArgs a, ScatterLaunch L) { qh_join_scatter_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   else
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
          "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";

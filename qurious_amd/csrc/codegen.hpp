@@ -96,11 +96,15 @@ struct AggPlan {
   mutable std::shared_ptr<void> arena;
   mutable size_t arena_bytes = 0;
   mutable bool arena_clean = false;
+  mutable std::shared_ptr<void> module;   // the loaded main kernel (jit.hpp Module), looked up once per cached plan
+  mutable std::shared_ptr<void> strlit;   // DevBuf: the plan's string literals, uploaded once
 };
 
 // group_roots / aggs refer to nodes of `es`; predicate_root < 0 = no filter
 void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, const int32_t* group_roots,
-                    int n_groups, const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& out);
+                    int n_groups, const qhip_agg* aggs, int n_aggs, int rows_per_thread, AggPlan& out, bool dev_rows = false);
+// (dev_rows: the input's row count lives on the device — KArgs::nrows_dev, a join output of deferred size; a separate
+// instantiation of the kernel bodies, so that kernels over ordinary tables keep their row count a plain kernel argument)
 
 struct MaskPlan { KernelBindings bind; std::string source; std::string kernel_name; };
 void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, MaskPlan& out);
@@ -114,7 +118,7 @@ struct KeysPlan {
 // qh_join_probe_body) or qk_join_scatter (build rows -> region entries of the LDS-staged join build, qh_join_scatter_body)
 enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2 };
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
-               int kernel = KEYS_KERNEL_EVAL);
+               int kernel = KEYS_KERNEL_EVAL, bool dev_rows = false);   // (dev_rows: KEYS_KERNEL_SCATTER only)
 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };

@@ -193,6 +193,9 @@ struct Ctx {
   std::string device_name;
   int num_cus = 256;
   qhip_exec_stats stats;
+  // HIP events around an operator's phases (qhip_exec_stats timings). OFF by default: every event record is a packet of its
+  // own on the stream (~5 us of stream time; Q3 recorded 10 per query) — qhip_ctx_set_timing / QHIP_TIMING=1 switch them on
+  bool timing = false;
   mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 — read when the stats are asked for
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
@@ -253,6 +256,7 @@ constexpr int kSizeSlots = 64;
 // hint) when a join produced more pairs than it had room for or met duplicate build keys — what was computed from its
 // output is then garbage and the consumer's input runs again; key / filter errors surface as they would have in the join.
 void verify_pending_sizes(Ctx* ctx);
+inline void time_mark(Ctx* ctx, int k) { if (ctx->timing) (void)hipEventRecord(ctx->ev[k], ctx->stream); }   // ev[k], only when timings are wanted
 uint32_t* zeroed_block(Ctx* ctx, int n = 1);   // n x 32 contiguous zeroed u32 words, valid for the current operator call (ctx.cpp)
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);

@@ -303,6 +303,7 @@ int qhip_ctx_create(int device_index, qhip_ctx** out) {
     g_live_contexts[c->device & 31].fetch_add(1);
     for (auto& ev : c->ev) QHIP_HIP_CHECK(hipEventCreate(&ev));
     c->status.alloc(4 * QS_WORDS * sizeof(uint32_t));   // (a hash join uses three blocks: build status, probe status, pair total)
+    c->timing = env_int("QHIP_TIMING", 0) != 0;
     c->pinned_bytes = 256 * 1024;
     QHIP_HIP_CHECK(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
     memset(&c->stats, 0, sizeof(c->stats));
@@ -343,6 +344,12 @@ int qhip_ctx_synchronize(qhip_ctx* ctx) {
 }
 
 uint64_t qhip_ctx_sync_count(const qhip_ctx*) { return qhip::sync_counter(); }
+
+int qhip_ctx_set_timing(qhip_ctx* ctx, int32_t on) {
+  if (!ctx) return QHIP_INVALID_ARGUMENT;
+  ctx->timing = on != 0;
+  return QHIP_OK;
+}
 
 int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta) {
   if (!ctx) return QHIP_INVALID_ARGUMENT;

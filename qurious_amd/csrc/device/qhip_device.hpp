@@ -425,7 +425,10 @@ __device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& 
   return used;
 }
 
-template <class P>
+// DEVROWS: the input is a join output whose row count lives on the device (KArgs::nrows_dev) — a separate instantiation, so
+// that the kernels over ordinary tables keep a.nrows a plain kernel argument (two more live scalars cost the TPC-H Q1 kernel,
+// which spills SGPRs, 8 % of its time)
+template <class P, bool DEVROWS = false>
 __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
   constexpr int R = P::R;
@@ -455,8 +458,9 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   u64 seen_pass = 0, seen_hits = 0;
 
   const i64 tile_rows = (i64)QH_BLOCK * R;
-  const i64 nrows = qh_rows(a);
-  const i64 ntiles = (nrows + tile_rows - 1) / tile_rows;
+  const i64 nrows_dr = DEVROWS ? qh_rows(a) : 0;
+#define QH_NROWS (DEVROWS ? nrows_dr : a.nrows)
+  const i64 ntiles = (QH_NROWS + tile_rows - 1) / tile_rows;
   for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
     // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (the load is
     // issued with the tile's loads and consumed at the end of the iteration, wave-uniform)
@@ -469,13 +473,14 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       // phase 1: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
       // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
       const u32 o = (u32)r * QH_BLOCK + (u32)tid;
-      const bool inb = tb + (i64)o < nrows;
-      P::load(a, tb, inb ? o : (u32)(nrows - 1 - tb), raw[r]);
+      const bool inb = tb + (i64)o < QH_NROWS;
+      P::load(a, tb, inb ? o : (u32)(QH_NROWS - 1 - tb), raw[r]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // phase 2: predicate, key words and aggregate arguments of each row (may branch)
-      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < nrows;
+      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < QH_NROWS;
+#undef QH_NROWS
       u32 e = 0;
       P::eval(a, raw[r], row[r], e);
       row[r].pass = row[r].pass && inb;
@@ -632,7 +637,7 @@ struct PartLaunch {
 
 __device__ __forceinline__ u32 qh_part_bin(u64 h, u32 n_bins) { return (u32)(h >> 40) & (n_bins - 1); }   // the HBM table uses the LOW bits
 
-template <class P, bool SCATTER>
+template <class P, bool SCATTER, bool DEVROWS = false>
 __device__ __forceinline__ void qh_agg_part_body(const KArgs& a, const PartLaunch& L) {
   constexpr int W = P::W;
   u32* cnt = (u32*)qh_dyn_lds;              // [n_bins] counts (pass 1) / next free record of the bin's run (pass 2)
@@ -640,7 +645,7 @@ __device__ __forceinline__ void qh_agg_part_body(const KArgs& a, const PartLaunc
   for (u32 b = tid; b < L.n_bins; b += QH_BLOCK) cnt[b] = SCATTER ? L.hist[(size_t)b * gridDim.x + blockIdx.x] : 0u;
   __syncthreads();
   const i64 first = (i64)blockIdx.x * L.rows_per_wg;
-  const i64 nrows = qh_rows(a);
+  const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
   const i64 last = first + L.rows_per_wg < nrows ? first + L.rows_per_wg : nrows;
   u32 err = 0;
   // PR rows per thread and iteration, in phases like the fused kernel: all loads of the tile first (their latencies
@@ -1030,7 +1035,7 @@ struct ScatterLaunch {
 
 #define QH_SCATTER_BLOCK 1024   // 16 wavefronts per workgroup: a workgroup's row range is two or three rows per thread, so each
                                 // of its phases is ONE round of loads (the phases are latency chains, not bandwidth)
-template <class P>
+template <class P, bool DEVROWS = false>
 __device__ __forceinline__ void qh_join_scatter_body(const KArgs& a, const ScatterLaunch& L) {
   constexpr int R = 4, W = P::W, TB = QH_SCATTER_BLOCK;
   u32* cnt = (u32*)qh_dyn_lds;         // [n_regions + 1] rows of this workgroup per region, then the next free place of the region's run
@@ -1039,7 +1044,7 @@ __device__ __forceinline__ void qh_join_scatter_body(const KArgs& a, const Scatt
   for (u32 r = tid; r <= nr; r += TB) cnt[r] = 0;
   __syncthreads();
   const i64 first = (i64)blockIdx.x * L.rows_per_wg;
-  const i64 nrows = qh_rows(a);
+  const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
   const i64 last = first + L.rows_per_wg < nrows ? first + L.rows_per_wg : nrows;
   u32 err = 0;
   for (int pass = 0; pass < 2; ++pass) {

@@ -42,7 +42,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
   ExprSet es;
   es.build(exprs, n_exprs, icols);
   DevBuf mask, wave, sel;
-  hipEventRecord(ctx->ev[0], ctx->stream);
+  time_mark(ctx, 0);
   run_pred_mask(ctx, in, es, icols, root, mask, wave);
   // rows kept (the one read-back that sizes the output), then every column compacted:
   //  * a predicate that keeps a good part of the rows (>= 1/8): MASK-DRIVEN — each column is read in row order and its kept
@@ -71,7 +71,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
     out->cols.push_back(gather_column(ctx, in->cols[(size_t)c], sel.as<uint32_t>(), m, false));
   }
-  hipEventRecord(ctx->ev[1], ctx->stream);
+  time_mark(ctx, 1);
   // output batch boundaries = kept rows before each input batch start
   const size_t nb1 = in->offsets().size();
   out->num_rows = m;
@@ -89,7 +89,7 @@ static qhip_table* filter_execute(Ctx* ctx, const qhip_table* in, const qhip_exp
     out->pending_offsets = pend;
     if (env_int("QHIP_EAGER_OFFSETS", 0) != 0) (void)out->offsets();
   }
-  ctx->stats_timing_pending = 1;   // ev0..ev1, read by qhip_ctx_last_stats
+  ctx->stats_timing_pending = ctx->timing ? 1 : 0;   // ev0..ev1, read by qhip_ctx_last_stats
   ctx->stats.rows_in = in->num_rows;
   ctx->stats.rows_out = m;
   snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_pred_mask+gather");

@@ -81,7 +81,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     }
   }
   DevBuf lkeys, lvalid;
-  hipEventRecord(ctx->ev[0], s);
+  time_mark(ctx, 0);
   if ((lpred >= 0 || rpred >= 0) && join_type != QHIP_JOIN_INNER)
     fail(QHIP_INVALID_ARGUMENT, "fused scan filters are only defined for Inner joins (rows rejected by a filter must not surface as unmatched rows)");
   if (lpred >= nlex || rpred >= nrex) fail(QHIP_INVALID_ARGUMENT, "scan filter index out of range");
@@ -146,7 +146,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     put_exprs(rex, nrex);
     put(on_l, sizeof(int32_t) * (size_t)n_on);
     put(on_r, sizeof(int32_t) * (size_t)n_on);
-    const int v[3] = {lpred, rpred, want_regions ? 1 : 0};
+    const int v[4] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0};
     put(v, sizeof v);
   }
   struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
@@ -159,7 +159,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       ExprSet les, res;
       les.build(lex, nlex, lcols);
       res.build(rex, nrex, rcols);
-      plan_keys(les, lcols, on_l, n_on, jp->lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL);
+      plan_keys(les, lcols, on_l, n_on, jp->lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL, want_regions && L->rows_dev);
       plan_keys(res, rcols, on_r, n_on, jp->rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
       for (int k = 0; k < n_on; ++k)
         if (jp->lkp.keys[(size_t)k].type != jp->rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
@@ -320,9 +320,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.dbg = (uint32_t)env_int("QHIP_PROBE_DBG", 0);
     pl.tiles_per_wave = (uint32_t)tiles_per_wave;
     void* args[] = {&ka, &pl};
-    hipEventRecord(ctx->ev[2], s);
+    time_mark(ctx, 2);
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
-    hipEventRecord(ctx->ev[3], s);
+    time_mark(ctx, 3);
     probe_timed = true;
     if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), nchunks, dstat + 2 * QS_WORDS, s);
     if (defer) {
@@ -378,7 +378,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     verify_pending_sizes(ctx);
     check_build_status();   // (duplicates do not matter without probe rows)
   }
-  if (!probe_timed) { hipEventRecord(ctx->ev[2], s); hipEventRecord(ctx->ev[3], s); }
+  if (!probe_timed) { time_mark(ctx, 2); time_mark(ctx, 3); }
 
   // ---- residual JoinFilter (join/mod.rs:125-154): evaluate over an intermediate batch of the filter's columns, keep true rows
   bool filtered = false;
@@ -523,8 +523,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   } else if (has_tail) {
     out->batch_offsets.push_back((int64_t)total_rows);   // always present, possibly empty (hash_join.rs:374-381)
   }
-  hipEventRecord(ctx->ev[1], s);
-  ctx->stats_timing_pending = 2;   // total = ev0..ev1, probe = ev2..ev3, read by qhip_ctx_last_stats
+  time_mark(ctx, 1);
+  ctx->stats_timing_pending = ctx->timing ? 2 : 0;   // total = ev0..ev1, probe = ev2..ev3, read by qhip_ctx_last_stats
   ctx->stats.rows_in = (int64_t)P;
   ctx->stats.rows_out = (int64_t)total_rows;
   ctx->stats.groups = (int64_t)M;

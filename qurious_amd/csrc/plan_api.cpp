@@ -43,7 +43,7 @@ int qhip_plan_aggregate_source(const qhip_dtype* col_types, const int32_t* col_h
     ExprSet es; es.build(exprs, n_exprs, in);
     AggPlan p;
     const char* r = getenv("QHIP_AGG_R");
-    plan_aggregate(es, in, predicate_root, group_roots, n_groups, aggs, n_aggs, r && *r ? atoi(r) : 0, p);
+    plan_aggregate(es, in, predicate_root, group_roots, n_groups, aggs, n_aggs, r && *r ? atoi(r) : 0, p, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0);
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }
@@ -89,7 +89,7 @@ int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has
     auto in = make_input(col_types, col_has_nulls, n_cols);
     ExprSet es; es.build(exprs, n_exprs, in);
     KeysPlan p;
-    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_SCATTER);
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_SCATTER, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0);
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }

@@ -63,7 +63,7 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
     if (is_col[(size_t)k]) out->cols[(size_t)k] = in->cols[(size_t)es.at(roots[k]).column];
     else { croots.push_back(roots[k]); cslot.push_back(k); }
   }
-  hipEventRecord(ctx->ev[0], s);
+  time_mark(ctx, 0);
   if (!croots.empty()) {
     ProjectionPlan plan;
     plan_projection(es, icols, croots.data(), (int)croots.size(), plan);
@@ -115,8 +115,8 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
       for (size_t c = 0; c < plan.outs.size(); ++c) out->cols[(size_t)cslot[c]].validity.reset();
     }
   }
-  hipEventRecord(ctx->ev[1], s);
-  ctx->stats_timing_pending = 1;
+  time_mark(ctx, 1);
+  ctx->stats_timing_pending = ctx->timing ? 1 : 0;
   ctx->stats.rows_in = N;
   ctx->stats.rows_out = N;
   snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_project");

@@ -36,7 +36,7 @@ qhip_table* sort_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, i
   if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
   hipStream_t s = ctx->stream;
   const uint64_t N = (uint64_t)in->num_rows;
-  hipEventRecord(ctx->ev[0], s);
+  time_mark(ctx, 0);
 
   resolve_referenced(ctx, in, exprs, n_exprs);
   std::vector<InputCol> icols = input_cols_of(in);
@@ -129,8 +129,8 @@ qhip_table* sort_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, i
   defer_gather(ctx, in->cols, idx, m, false, out->cols);
   out->num_rows = (int64_t)m;
   out->batch_offsets = {0, (int64_t)m};   // sort.rs:81: always exactly one batch
-  hipEventRecord(ctx->ev[1], s);
-  ctx->stats_timing_pending = 1;
+  time_mark(ctx, 1);
+  ctx->stats_timing_pending = ctx->timing ? 1 : 0;
   ctx->stats.rows_in = (int64_t)N;
   ctx->stats.rows_out = (int64_t)m;
   snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_sort_keys+radix passes");

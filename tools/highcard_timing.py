@@ -9,6 +9,7 @@ from qurious_amd import synth
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000
 groups = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 ctx = q.get_context()
+ctx.set_timing(True)
 schema = pa.schema([pa.field("k", pa.int64(), False), pa.field("v", pa.int64(), False)])
 rng = np.random.default_rng(3)
 for name, keys in (("uniform", rng.integers(0, groups, n)), ("zipf 1.1", synth.zipf_ranks(0, n, groups, 1.1, 7).astype(np.int64))):

@@ -1,6 +1,7 @@
 """Host-side cost of a plan: wall time of every C-ABI operator call of TPC-H Q3 (the joins of deferred size return as soon
-as their work is enqueued, so their call time IS the host's enqueue cost; the aggregate's call contains the plan's one wait).
-usage: python tools/host_overhead.py [sf]"""
+as their work is enqueued, so their call time IS the host's enqueue cost; the aggregate's call contains the plan's one wait),
+or of Q1's aggregate list over `rows` lineitem rows (a tiny table shows the fixed cost of a call).
+usage: python tools/host_overhead.py [sf] | python tools/host_overhead.py q1 [rows]"""
 import os
 import sys
 import time
@@ -9,12 +10,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qurious_amd as q  # noqa: E402
 from qurious_amd import plan as P, queries, synth  # noqa: E402
 
-sf = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 ctx = q.get_context()
-c, o, l = synth.q3_tables(sf)
-tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
-        q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
-plan = queries.q3(*tabs)
+if len(sys.argv) > 1 and sys.argv[1] == "q1":
+    rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 59_986_052
+    sf = f"Q1 over {rows} rows"
+    plan = queries.q1_full(q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, synth.lineitem(rows, 1 << 20)))
+else:
+    sf = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    c, o, l = synth.q3_tables(sf)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    sf = f"Q3 SF{sf}"
+    plan = queries.q3(*tabs)
 for _ in range(5):
     plan.execute_device()
 lib = ctx.lib
@@ -49,9 +56,9 @@ total = (time.perf_counter() - t0) / n * 1e6
 per = {}
 for name, us in calls:
     per.setdefault(name, []).append(us)
-print(f"Q3 SF{sf}: {total:.0f} us per query, {waits} host wait(s)")
+print(f"{sf}: {total:.0f} us per query, {waits} host wait(s)")
 k = 0
-for name, us in calls[-3:]:
+for name, us in calls[-len(per):] if len(per) == 1 else calls[-3:]:
     print(f"  call {k} {name}: {us:.0f} us (last query)")
     k += 1
 for name, v in per.items():

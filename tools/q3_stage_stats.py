@@ -7,6 +7,7 @@ from qurious_amd import queries, synth
 skew = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 sf = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 ctx = q.get_context()
+ctx.set_timing(True)
 c, o, l = synth.q3_tables_skewed(sf, skew) if skew > 0 else synth.q3_tables(sf)
 tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o), q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
 plan = queries.q3(*tabs)
