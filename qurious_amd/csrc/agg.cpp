@@ -23,6 +23,8 @@
 #include "relops.hpp"
 
 namespace qhip {
+static uint64_t g_learn_tick = 0;   // orders what twin aggregate plans learnt (AggPlan::learnt_at)
+
 
 // ---------------------------------------------------------------- HostColumn
 void HostColumn::init_fixed(const DType& t, int64_t n) {
@@ -193,7 +195,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const int kc_env = env_int("QHIP_AGG_KC", -1);
   put(&r_env, sizeof r_env); put(&kc_env, sizeof kc_env);
   const int dev_rows = in->rows_dev ? 1 : 0;   // (a join output of deferred size: the kernel variant that reads the row count on the device)
+  std::string sibling_key = key;
   put(&dev_rows, sizeof dev_rows);
+  { const int other = 1 - dev_rows; sibling_key.append((const char*)&other, sizeof other); }
   std::shared_ptr<AggPlan> plan_ptr;
   auto cached = ctx->plan_cache.find(key);
   if (cached != ctx->plan_cache.end()) plan_ptr = std::static_pointer_cast<AggPlan>(cached->second);
@@ -202,10 +206,20 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     es.build(exprs, n_exprs, icols);
     plan_ptr = std::make_shared<AggPlan>();
     plan_aggregate(es, icols, pred_root, group_roots, n_groups, aggs, n_aggs, r_env, *plan_ptr, dev_rows != 0);
+
     if (ctx->plan_cache.size() > 4096) ctx->plan_cache.clear();
     ctx->plan_cache[key] = plan_ptr;
   }
   const AggPlan& plan = *plan_ptr;
+  {
+    // the same aggregate over an input whose row count is / is not on the device is a twin plan (another kernel variant):
+    // what either learnt about the data (groups, occupied slots) serves both
+    auto sib = ctx->plan_cache.find(sibling_key);
+    if (sib != ctx->plan_cache.end()) {
+      const AggPlan& o = *std::static_pointer_cast<AggPlan>(sib->second);
+      if (o.learnt_at > plan.learnt_at) { plan.last_groups = o.last_groups; plan.last_dense = o.last_dense; plan.learnt_at = o.learnt_at; }
+    }
+  }
   mark("planned");
 
   // output schema: keys then aggregates (hash.rs:166-169)
@@ -477,7 +491,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (partitioned) {
       ran_partitioned = true;
       hipStream_t s = ctx->stream;
-      const uint32_t per_bin = std::max<uint32_t>(16, l_nslots * 3 / 8);   // groups a bin should hold: LDS table 3/8 full
+      // (QHIP_AGG_PART_LDS_BYTES: bigger LDS tables in the reduce pass = fewer bins = longer runs per tile in pass 2 — measured:
+      // pass 2 gains less than the reduce pass loses with one or two workgroups per CU: 50 M rows -> 1 M groups 1.86 -> 2.23 ms
+      // at 64 KB, 2.98 ms at 128 KB; off by default)
+      uint32_t l_nslots_p = l_nslots;
+      if (!getenv("QHIP_AGG_LDS_BYTES"))
+        while ((uint64_t)l_nslots_p * 2 * slot_bytes <= (uint64_t)env_int("QHIP_AGG_PART_LDS_BYTES", 0)) l_nslots_p *= 2;
+      const uint32_t per_bin = std::max<uint32_t>(16, l_nslots_p * (l_nslots_p > l_nslots ? 5 : 3) / 8);   // groups a bin should hold
       uint32_t n_bins = 16;
       while (n_bins < 4096 && (uint64_t)n_bins * per_bin < std::max<uint32_t>(plan.last_groups, 1)) n_bins *= 2;
       if (env_int("QHIP_AGG_PART_BINS", 0) >= 16) n_bins = (uint32_t)pow2_ceil((uint64_t)std::min(4096, env_int("QHIP_AGG_PART_BINS", 0)));
@@ -499,7 +519,15 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       void* pargs[] = {&ka, &pl};
       QHIP_HIP_CHECK(hipModuleLaunchKernel(m_hist->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
       exclusive_scan_u32(hist.as<uint32_t>(), hist.as<uint32_t>(), n_hist, hist.as<uint32_t>() + n_hist, s);
-      QHIP_HIP_CHECK(hipModuleLaunchKernel(m_scat->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
+      // pass 2: LDS-staged (records of a tile ordered by bin, written out as runs) when a tile of records fits LDS
+      const bool staged = plan.part_pr > 0 && env_int("QHIP_AGG_PART_STAGE", 1) != 0;
+      if (staged) {
+        std::shared_ptr<Module> m_stage = get_module(ctx, plan.source, "qk_agg_part_stage");
+        const size_t tile = (size_t)1024 * (size_t)plan.part_pr;
+        const size_t stage_lds = (size_t)n_bins * 12 + 8 + tile * ((size_t)(plan.slot_words - 1) * 8 + 2) + 16;
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_stage->fn, (unsigned)g1, 1, 1, 1024, 1, 1, (unsigned)stage_lds, s, pargs, nullptr));
+      } else
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_scat->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
       // first record of every bin (= of its first workgroup's run) + the record total: one strided read-back
       uint32_t* first = (uint32_t*)((uint8_t*)ctx->pinned + 128);
       QHIP_HIP_CHECK(hipMemcpy2DAsync(first, 4, hist.ptr, (size_t)g1 * 4, 4, n_bins, hipMemcpyDeviceToHost, s));
@@ -520,9 +548,11 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         rl.records = records.as<uint64_t>();
         rl.item_first = items_dev.as<uint32_t>();
         rl.n_items = n_items;
-        void* rargs[] = {&rl, &L};
+        HAggLaunch Lp = L;
+        Lp.l_nslots = l_nslots_p;
+        void* rargs[] = {&rl, &Lp};
         const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 4);
-        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, s, rargs, nullptr));
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
         QHIP_HIP_CHECK(sync_stream(s));   // hist / records / items go back to the pool here; item_first is pageable
       }
 
@@ -613,7 +643,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
     if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
       // the speculative device-side assembly is the result
-      plan.last_groups = G;
+      plan.last_groups = G; plan.learnt_at = ++g_learn_tick;
       qhip_table* result = finish_device_finalize(spec, dense_dev + 1, G, true);
       ctx->stats.main_kernel_ms = main_ms;
       ctx->stats.total_device_ms = main_ms;
@@ -689,7 +719,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
   }
 
-  plan.last_groups = G;
+  plan.last_groups = G; plan.learnt_at = ++g_learn_tick;
   auto set_stats = [&]() {
     ctx->stats.main_kernel_ms = main_ms;
     ctx->stats.total_device_ms = main_ms;

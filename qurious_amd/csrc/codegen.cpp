@@ -691,6 +691,11 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "struct P {\n";
   const int KC = P.KC;
   s << "  static constexpr int W = " << P.W << ";\n  static constexpr int R = " << P.R << ";\n  static constexpr int SLOT_WORDS = " << P.slot_words << ";\n";
+  // rows per thread of the partitioned path's staged scatter (qh_agg_part_stage_body): what a 1 024-thread workgroup can stage
+  // in LDS beside 4 096 bins' counters (160 KB per CU), at most 4; 0 = records too wide, per-lane stores
+  P.part_pr = std::min(4, (int)((163840 - 4096 * 12 - 1024) / (1024 * ((P.slot_words - 1) * 8 + 2))));
+  if (const char* e = getenv("QHIP_AGG_PART_PR")) P.part_pr = std::min(P.part_pr, std::max(1, atoi(e)));   // (experiments)
+  s << "  static constexpr int PART_PR = " << P.part_pr << ";\n";
   s << "  static constexpr int KC = " << KC << ";\n";
   s << "  struct Row {\n    bool pass;\n    u64 key[" << KW << "];\n";
   for (size_t a = 0; a < P.args.size(); ++a) {
@@ -865,6 +870,8 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_hist(KArgs a, PartLaunch L) { qh_agg_part_body<P, false" << dr << ">(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_scatter(KArgs a, PartLaunch L) { qh_agg_part_body<P, true" << dr << ">(a, L); }\n";
+    if (P.part_pr > 0)
+      s << "extern \"C\" __global__ __launch_bounds__(QH_STAGE_BLOCK) void qk_agg_part_stage(KArgs a, PartLaunch L) { qh_agg_part_stage_body<P" << dr << ">(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_reduce(ReduceLaunch R, AggLaunch L) { qh_agg_reduce_body<P>(R, L); }\n";
   }
   P.source = s.str();

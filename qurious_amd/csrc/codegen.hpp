@@ -82,6 +82,7 @@ struct AggPlan {
   int R = 4;
   int KC = 0;                  // wave-resident hot keys
   int slot_words = 0;          // 1 + W + cell words
+  int part_pr = 0;             // partitioned path: rows per thread of the LDS-staged scatter (0: records too wide for it)
   std::vector<KeyDesc> keys;
   std::vector<ArgDesc> args;
   std::vector<CellDesc> cells;
@@ -91,6 +92,7 @@ struct AggPlan {
   std::string kernel_name;
   mutable uint32_t last_groups = 0;   // groups the plan produced the last time it ran (sizes the first table attempt)
   mutable uint32_t last_dense = 0;    // ... and the occupied slots over all table replicas (sizes the one read-back)
+  mutable uint64_t learnt_at = 0;     // when the two were last set (a per-process tick): twin plans take over the fresher pair
   // the small replicated first-attempt table of a plan that keeps producing few groups is kept between calls, zeroed at
   // the END of a call (off the critical path): [status words | dense counter | table | dense slots]
   mutable std::shared_ptr<void> arena;

@@ -216,7 +216,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     fill_kargs(ctx, L, lkp.bind, ka, jp->lstr);
     // a step-1 workgroup (1024 threads) owns a row range of two or three rows per thread when the rows allow (2
     // workgroups per CU); its entries stay inside the range, so nothing is shared between workgroups
-    uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>((B + 2047) / 2048, (uint64_t)ctx->num_cus * 2));
+    uint64_t wgs = std::max<uint64_t>(1, std::min<uint64_t>((B + 2047) / 2048, (uint64_t)std::max(1, env_int("QHIP_JOIN_SCATTER_WGS", ctx->num_cus * 2))));
     const uint64_t rows_per_wg = (((B + wgs - 1) / wgs) + 63) / 64 * 64;
     wgs = (B + rows_per_wg - 1) / rows_per_wg;
     DevBuf entries(B * (1 + (size_t)W) * 8), first(wgs * ((size_t)n_regions + 1) * 4);

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_build_insert(const u64* keys,
 }
 // LDS-staged build, step 2 (step 1: qh_join_scatter_body in device/qhip_device.hpp): ONE workgroup per region. Thread w
 // collects the region's entries [row + 2 | key words] that step-1 workgroup w (w + 512, ...) left in its own range of
-// `entries` (their positions: first[w][region], first[w][region + 1]) and inserts them into an open-addressing image of
+// `entries` (their positions: first[region][w], first[region + 1][w]) and inserts them into an open-addressing image of
 // the region in LDS (DS compare-and-swap on the state word, probe sequence wrapping inside the region); the region's
 // slice of the hash filter is assembled beside it, and both are stored as whole lines — the table is never memset and
 // never sees an HBM atomic. A second row with an equal key (the unique-key speculation failed) or a region with more
@@ -473,20 +473,22 @@ __global__ __launch_bounds__(QH_REGION_BLOCK) void k_join_region_build(const u64
   // this thread's share: the region's entries of step-1 workgroups tid, tid + RB, ... (the loads of the first one are
   // issued before the LDS image is cleared)
   u32 lo = 0, hi = 0;
-  if (tid < n_wgs) { const u32* f = first + (size_t)tid * (n_regions + 1) + reg; lo = f[0]; hi = f[1]; }
+  const u32* const f0 = first + (size_t)reg * n_wgs;   // first[region][workgroup]: two contiguous rows
+  const u32* const f1 = f0 + n_wgs;
+  if (tid < n_wgs) { lo = f0[tid]; hi = f1[tid]; }
   if (tid == 0) total = 0;
   for (u32 k = tid; k < S * (1 + W); k += RB) lt[k] = 0;
   for (u32 k = tid; k < BW; k += RB) lb[k] = 0;
   __syncthreads();
   u32 mine = hi - lo;
-  for (u32 w = tid + RB; w < n_wgs; w += RB) { const u32* f = first + (size_t)w * (n_regions + 1) + reg; mine += f[1] - f[0]; }
+  for (u32 w = tid + RB; w < n_wgs; w += RB) mine += f1[w] - f0[w];
   if (mine) atomicAdd(&total, mine);
   __syncthreads();
   const bool overfull = total > S - (S >> 3);   // workgroup-uniform
   bool careful = overfull;
   if (!overfull) {
     for (u32 w = tid; w < n_wgs; w += RB) {
-      if (w != tid) { const u32* f = first + (size_t)w * (n_regions + 1) + reg; lo = f[0]; hi = f[1]; }
+      if (w != tid) { lo = f0[w]; hi = f1[w]; }
       const u64* src = entries + ((size_t)w * rows_per_wg + lo) * (1 + W);
       const u32 n = hi - lo;
       // four entries at a time: their loads are issued together (a thread has two entries on average, rarely more than four)
