@@ -923,6 +923,8 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   if (raw) {
+    out.probe_r = std::max(1, std::min(8, env_int("QHIP_PROBE_R", 4)));
+    s << "  static constexpr int PROBE_R = " << out.probe_r << ";\n";
     s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
     s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
     s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const Raw& w, u64* k, u32& err) {\n" << code;
@@ -930,9 +932,13 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
   }
   s << "    return " << all << ";\n  }\n};\n";
-  if (kernel == KEYS_KERNEL_PROBE)
-    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P>(a, L); }\n";
-  else if (kernel == KEYS_KERNEL_SCATTER)
+  if (kernel == KEYS_KERNEL_PROBE) {
+    const int waves = env_int("QHIP_PROBE_WAVES", out.probe_r >= 4 ? 5 : out.probe_r == 3 ? 6 : 8);
+    // two entry points: the region layout of the LDS-staged build (the rule) and the one-table legacy layout. Five waves per
+    // SIMD (<= 96 VGPRs): the three tiles in flight need ~90; at 98 the kernel fell to four waves and ran 10-20 % slower
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe_onetable(KArgs a, ProbeLaunch L) { qh_join_probe_body<P, false>(a, L); }\n";
+  } else if (kernel == KEYS_KERNEL_SCATTER)
     s << "extern \"C\" __global__ __launch_bounds__(QH_SCATTER_BLOCK) void qk_join_scatter(KArgs a, ScatterLaunch L) { qh_join_scatter_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   else
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "

@@ -115,6 +115,7 @@ struct KeysPlan {
   int W = 0; bool null_mask_word = false;   // join keys never carry a null mask (NULL keys never match); partition keys do not need one either
   std::vector<KeyDesc> keys;
   KernelBindings bind; std::string source; std::string kernel_name;
+  int probe_r = 4;   // KEYS_KERNEL_PROBE: probe rows per thread and tile (P::PROBE_R)
 };
 // which kernel wraps the generated key policy: qk_eval_keys (key words -> arrays), qk_join_probe (fused filter + key + lookup,
 // qh_join_probe_body) or qk_join_scatter (build rows -> region entries of the LDS-staged join build, qh_join_scatter_body)

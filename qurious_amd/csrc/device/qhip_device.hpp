@@ -909,7 +909,7 @@ struct ProbeLaunch {
   const u32* count;      // build rows per slot (unused when start == nullptr)
   const u32* start;      // first position of a slot's rows in `rows`; nullptr: unique build keys (the slot's state word - 2 is the row)
   const u32* rows;       // build rows grouped by slot, ascending inside a slot
-  u32* ent_slot;         // out, per CHUNK (the tiles_per_wave consecutive tiles of 64 * QH_PROBE_R probe rows one wavefront owns): the
+  u32* ent_slot;         // out, per CHUNK (the tiles_per_wave consecutive tiles of 64 * PROBE_R probe rows one wavefront owns): the
   u32* ent_row;          //      matching rows, compacted in row order from the chunk's first row position on: slot of the key
                          //      (unique build keys: the build row itself) and probe row. Rows without a match write nothing.
   u32* tile_nent;        // out, per chunk: number of matching probe rows
@@ -918,7 +918,7 @@ struct ProbeLaunch {
   u32* status;
   u32 nslots, bloom_mask;  // legacy layout: slots of the one table (power of two), 64-bit words of the filter - 1
   u32 n_regions;           // region layout (0 = legacy): regions of 2^slot_bits slots, each with a filter slice of
-  u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; dbg: timing experiments only (QHIP_PROBE_DBG, results are wrong)
+  u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; (dbg: unused)
   u32 tiles_per_wave, pad_;          // wavefront w of the grid owns tiles [w * tiles_per_wave, (w + 1) * tiles_per_wave)
 };
 
@@ -939,7 +939,7 @@ __device__ __forceinline__ u32 qh_filter_word(u64 h, u32 word_mask) { return (u3
 __device__ __forceinline__ u32 qh_rfilter_word(u64 h, u32 sb, u32 wb) { return ((u32)h >> sb) & ((1u << wb) - 1u); }
 __device__ __forceinline__ u64 qh_rfilter_mask(u64 h, u32 sb, u32 wb) { return qh_filter_mask((u32)(h >> (sb + wb))); }
 
-#define QH_PROBE_R 4   // probe rows per thread and tile
+// probe rows per thread and tile: P::PROBE_R (4; the key policy carries it so that the shape can be varied per plan)
 // Probe pass 1 (hash_join.rs:218-275 for every probe batch at once): evaluate the fused scan filter and the key words
 // straight from the probe table's columns, look the key up, keep (slot, probe row) of the matching rows only — compacted
 // per 256-row tile with ballot/popcount ranks — and the pair count per tile. Pass 2 (k_join_emit) turns the entries into
@@ -961,12 +961,12 @@ __device__ __forceinline__ u64 qh_rfilter_mask(u64 h, u32 sb, u32 wb) { return q
 // s_waitcnt vmcnt(0): the pipeline drains every trip.)
 template <class P>
 struct QhProbeTile {
-  typename P::Raw raw[QH_PROBE_R];                       // stage 1 -> 2
-  u64 k[QH_PROBE_R][P::W];                               // stage 2 -> 4
-  u64 fw[QH_PROBE_R], fm[QH_PROBE_R];                    // stage 2 -> 3: filter word, the key's mask
-  u32 at[QH_PROBE_R];                                    // stage 2 -> 4: the key's home slot (base + slot inside the region)
-  u64 st[QH_PROBE_R], kw[QH_PROBE_R][P::W];              // stage 3 -> 4
-  bool ok[QH_PROBE_R];
+  typename P::Raw raw[P::PROBE_R];                       // stage 1 -> 2
+  u64 k[P::PROBE_R][P::W];                               // stage 2 -> 4
+  u64 fw[P::PROBE_R], fm[P::PROBE_R];                    // stage 2 -> 3: filter word, the key's mask
+  u32 at[P::PROBE_R];                                    // stage 2 -> 4: the key's home slot (base + slot inside the region)
+  u64 st[P::PROBE_R], kw[P::PROBE_R][P::W];              // stage 3 -> 4
+  bool ok[P::PROBE_R];
   i64 tile;                                              // wave-uniform
   bool live;                                             // wave-uniform: a real tile of this wavefront (not a drain trip's)
 };
@@ -975,7 +975,7 @@ struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, mine; u32 nent
 // stage 1: issue the column loads of the wavefront's j-th tile (j beyond its last tile: tile 0 once more, not live)
 template <class P>
 __device__ __forceinline__ void qh_probe_stage1(const KArgs& a, QhProbeTile<P>& x, const QhProbeCtx& c, i64 j) {
-  constexpr int R = QH_PROBE_R, TILE = 64 * R;
+  constexpr int R = P::PROBE_R, TILE = 64 * R;
   x.live = j < c.mine;
   x.tile = x.live ? c.first + j : 0;   // (a drain trip reads tile 0: the same L2-resident lines for every wavefront)
   const i64 tb = x.tile * TILE;
@@ -991,9 +991,11 @@ __device__ __forceinline__ void qh_probe_stage1(const KArgs& a, QhProbeTile<P>& 
   }
 }
 // stage 2: filter + key words from the columns, hash, issue the filter-word loads
-template <class P>
+// (REGIONS — the table layout — is a template parameter: as a run-time flag both layouts' slot / filter arithmetic was
+// evaluated for every row and one of them thrown away)
+template <class P, bool REGIONS>
 __device__ __forceinline__ void qh_probe_stage2(const KArgs& a, const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c, u32& err) {
-  constexpr int R = QH_PROBE_R, TILE = 64 * R, W = P::W;
+  constexpr int R = P::PROBE_R, TILE = 64 * R, W = P::W;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool inb = x.tile * TILE + r * 64 + c.lane < a.nrows;
@@ -1001,31 +1003,38 @@ __device__ __forceinline__ void qh_probe_stage2(const KArgs& a, const ProbeLaunc
     x.ok[r] = P::keys(a, x.raw[r], x.k[r], e) && inb;
     err |= (inb && x.live) ? e : 0u;
     const u64 h = qh_key_hash<W>(x.k[r]);
-    const u32 reg = c.regions ? qh_region(h, L.n_regions) : 0u;
-    x.at[r] = (c.regions ? reg << L.slot_bits : 0u) + ((u32)h & c.smask);
-    x.fm[r] = c.regions ? qh_rfilter_mask(h, L.slot_bits, L.bword_bits) : qh_filter_mask((u32)h);
-    const u32 word = c.regions ? (reg << L.bword_bits) + qh_rfilter_word(h, L.slot_bits, L.bword_bits) : qh_filter_word(h, L.bloom_mask);
+    const u32 reg = REGIONS ? qh_region(h, L.n_regions) : 0u;
+    x.at[r] = (REGIONS ? reg << L.slot_bits : 0u) + ((u32)h & c.smask);
+    x.fm[r] = REGIONS ? qh_rfilter_mask(h, L.slot_bits, L.bword_bits) : qh_filter_mask((u32)h);
+    const u32 word = REGIONS ? (reg << L.bword_bits) + qh_rfilter_word(h, L.slot_bits, L.bword_bits) : qh_filter_word(h, L.bloom_mask);
     // (32-bit byte offset from the scalar base: the filter holds < 2^29 words)
-    x.fw[r] = *(const u64*)((const char*)L.bloom + (size_t)(((x.ok[r] && !(L.dbg & 4u)) ? word : 0u) << 3));
+    x.fw[r] = *(const u64*)((const char*)L.bloom + (size_t)((x.ok[r] ? word : 0u) << 3));
   }
 }
 // stage 3: filter test, issue the home-slot loads of the rows that pass
 template <class P>
 __device__ __forceinline__ void qh_probe_stage3(const ProbeLaunch& L, QhProbeTile<P>& x, const QhProbeCtx& c) {
-  constexpr int R = QH_PROBE_R, W = P::W;
+  constexpr int R = P::PROBE_R, W = P::W;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    x.ok[r] = x.ok[r] && (x.fw[r] & x.fm[r]) == x.fm[r] && !(L.dbg & 2u);
+    x.ok[r] = x.ok[r] && (x.fw[r] & x.fm[r]) == x.fm[r];
     const u64* slot = L.table + (size_t)(x.ok[r] ? x.at[r] : 0u) * (1 + W);
-    x.st[r] = slot[0];
+    if (W == 1) {   // [state | key]: one 16-byte load
+      typedef u64 qh_v2u64 __attribute__((ext_vector_type(2)));
+      const qh_v2u64 sk = *(const qh_v2u64*)slot;
+      x.st[r] = sk.x;
+      x.kw[r][0] = sk.y;
+    } else {
+      x.st[r] = slot[0];
 #pragma unroll
-    for (int w = 0; w < W; ++w) x.kw[r][w] = slot[1 + w];
+      for (int w = 0; w < W; ++w) x.kw[r][w] = slot[1 + w];
+    }
   }
 }
 // stage 4: compare the home slot, walk on after a collision (rare: the filter), write the tile's entries and counts
 template <class P>
 __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTile<P>& x, QhProbeCtx& c) {
-  constexpr int R = QH_PROBE_R, TILE = 64 * R, W = P::W;
+  constexpr int R = P::PROBE_R, TILE = 64 * R, W = P::W;
   const int lane = c.lane;
   u32 sid[R];
 #pragma unroll
@@ -1036,7 +1045,7 @@ __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTil
 #pragma unroll
       for (int w = 0; w < W; ++w) eq &= x.kw[r][w] == x.k[r][w];
       const u32 home = x.at[r] & c.smask, base = x.at[r] & ~c.smask;
-      sid[r] = eq ? x.at[r] : (L.dbg & 1u) ? 0xFFFFFFFFu : qh_join_find<W>(L.table, base, c.smask, x.k[r], home + 1);   // collision: walk on from the next slot
+      sid[r] = eq ? x.at[r] : qh_join_find<W>(L.table, base, c.smask, x.k[r], home + 1);   // collision: walk on from the next slot
       // unique build keys: the slot's state word carries its one build row, which is all pass 2 needs
       if (!L.start && sid[r] != 0xFFFFFFFFu) sid[r] = (u32)((eq ? x.st[r] : L.table[(size_t)sid[r] * (1 + W)]) - 2);
     }
@@ -1070,14 +1079,14 @@ __device__ __forceinline__ void qh_probe_stage4(const ProbeLaunch& L, QhProbeTil
   c.total += (u32)qh_wave_sum_u64(total);   // (published once per chunk, at the end of the kernel)
 }
 
-template <class P>
+template <class P, bool REGIONS>
 __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLaunch& L) {
-  constexpr int R = QH_PROBE_R, TILE = 64 * R, NW = QH_BLOCK / 64;
+  constexpr int R = P::PROBE_R, TILE = 64 * R, NW = QH_BLOCK / 64;
   const i64 ntiles = (a.nrows + TILE - 1) / TILE;
   QhProbeCtx c;
   // where a key lives: legacy = one table (base 0, mask nslots - 1); region layout = its region's slot range
-  c.regions = L.n_regions != 0;
-  c.smask = c.regions ? (1u << L.slot_bits) - 1u : L.nslots - 1u;
+  c.regions = REGIONS;
+  c.smask = REGIONS ? (1u << L.slot_bits) - 1u : L.nslots - 1u;
   c.lane = qh_lane();
   // the wavefront's chunk: tiles first .. first + mine - 1 (wave-uniform numbers, kept in SGPRs: the pipeline's control flow is
   // scalar). A chunk's matches form ONE run of entries and one (count, pair total) — pass 2 and the scan in front of it work
@@ -1097,16 +1106,16 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
   // then the same on every path, which is what lets the compiler wait with s_waitcnt vmcnt(N > 0) for exactly the loads
   // issued a trip earlier. (With `if (tile valid)` around the stages it must assume the shortest path and drains.)
   qh_probe_stage1<P>(a, A, c, 0);
-  qh_probe_stage2<P>(a, L, A, c, err);
+  qh_probe_stage2<P, REGIONS>(a, L, A, c, err);
   qh_probe_stage1<P>(a, B, c, 1);
   qh_probe_stage3<P>(L, A, c);
-  qh_probe_stage2<P>(a, L, B, c, err);
+  qh_probe_stage2<P, REGIONS>(a, L, B, c, err);
   qh_probe_stage1<P>(a, C, c, 2);
   // one trip: finish X4's tile, filter-test X3's, hash X2's, then give X4 (free now) the wavefront's next tile
 #define QH_PROBE_TRIP(X4, X3, X2, J)          \
   qh_probe_stage4<P>(L, X4, c);               \
   qh_probe_stage3<P>(L, X3, c);               \
-  qh_probe_stage2<P>(a, L, X2, c, err);       \
+  qh_probe_stage2<P, REGIONS>(a, L, X2, c, err);       \
   qh_probe_stage1<P>(a, X4, c, (J));
   for (i64 j = 3; j < c.mine + 3; j += 3) {   // wave-uniform; stage 4 has run for tiles 0 .. j - 1 after the trip group
     QH_PROBE_TRIP(A, B, C, j)

@@ -149,7 +149,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const int v[4] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0};
     put(v, sizeof v);
   }
-  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
+  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod, rmod_onetable; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
   std::shared_ptr<JoinPlan> jp;
   {
     auto cached = ctx->plan_cache.find(pkey);
@@ -291,10 +291,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
   if (P > 0) {
-    if (!jp->rmod) jp->rmod = get_module(ctx, rkp.source, rkp.kernel_name);
-    const std::shared_ptr<Module>& mod = jp->rmod;
+    std::shared_ptr<Module>& rmod = region_build ? jp->rmod : jp->rmod_onetable;   // (the table layout is a template parameter of the kernel)
+    if (!rmod) rmod = get_module(ctx, rkp.source, region_build ? rkp.kernel_name : "qk_join_probe_onetable");
+    const std::shared_ptr<Module>& mod = rmod;
     HKArgs ka;
     fill_kargs(ctx, R, rkp.bind, ka, jp->rstr);
+    const uint64_t kProbeTileRows = (uint64_t)64 * (uint64_t)rkp.probe_r;   // one wavefront's tile: 64 * P::PROBE_R consecutive probe rows
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
     // a wavefront owns a CHUNK of consecutive tiles (~12 once every CU has work: it pays three trips to fill and drain its
     // pipeline); the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of
@@ -317,7 +319,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.status = dstat + QS_WORDS;
     pl.nslots = nslots; pl.bloom_mask = filter_words - 1;
     pl.n_regions = n_regions; pl.slot_bits = slot_bits; pl.bword_bits = bword_bits;
-    pl.dbg = (uint32_t)env_int("QHIP_PROBE_DBG", 0);
     pl.tiles_per_wave = (uint32_t)tiles_per_wave;
     void* args[] = {&ka, &pl};
     time_mark(ctx, 2);

@@ -85,6 +85,5 @@ struct HScatterLaunch {
   uint32_t rows_per_wg;
 };
 static_assert(sizeof(HScatterLaunch) == 32, "ScatterLaunch layout");
-constexpr int kProbeTileRows = 64 * 4;   // one wavefront's share: 64 * QH_PROBE_R consecutive probe rows
 
 }  // namespace qhip

@@ -20,4 +20,4 @@ for it in range(6):
     b = j2b.execute_device(); ctx.synchronize(); s2 = ctx.last_stats()
     cur = (s1["total_device_ms"], s1["main_kernel_ms"], s2["total_device_ms"], s2["main_kernel_ms"], s1["build_ms"], s2["build_ms"])
     best = cur if best is None else tuple(min(x, y) for x, y in zip(best, cur))
-print(f"dbg={os.environ.get('QHIP_PROBE_DBG', '0')} wgs={os.environ.get('QHIP_JOIN_SCATTER_WGS', '-')} J1 total {best[0]*1e3:.0f} us build {best[4]*1e3:.0f} probe {best[1]*1e3:.0f} us | J2 total {best[2]*1e3:.0f} us build {best[5]*1e3:.0f} probe {best[3]*1e3:.0f} us | rows {a.num_rows} {b.num_rows}", flush=True)
+print(f"wgs={os.environ.get('QHIP_JOIN_SCATTER_WGS', '-')} J1 total {best[0]*1e3:.0f} us build {best[4]*1e3:.0f} probe {best[1]*1e3:.0f} us | J2 total {best[2]*1e3:.0f} us build {best[5]*1e3:.0f} probe {best[3]*1e3:.0f} us | rows {a.num_rows} {b.num_rows}", flush=True)
