@@ -153,6 +153,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (trace) fprintf(stderr, "[qhip agg] %-28s %8.1f us\n", what,
                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   };
+  trace_point("aggregate: entry");
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   if (n_groups < 0 || n_aggs < 0 || (n_groups > 0 && !group_roots) || (n_aggs > 0 && !aggs) || (n_exprs > 0 && !exprs))
     fail(QHIP_INVALID_ARGUMENT, "qhip_hash_aggregate_execute: bad arguments");
@@ -609,6 +610,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     }
     memcpy(status, status_pinned, sizeof(status));
     mark("synchronised");
+    trace_point("aggregate: back from its wait");
     verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
     // a join of deferred size that turned out to have produced nothing has no output batches (hash_join.rs:363-372)
     if (in->rows_dev && in->rows_host && *in->rows_host == 0 && n_groups > 0) return no_batches_out();
@@ -876,6 +878,7 @@ extern "C" int qhip_hash_aggregate_execute(qhip_ctx* ctx, const qhip_table* inpu
         verify_pending_sizes(ctx);
       }
       *out = r.release();
+      trace_point("aggregate: return");
     } catch (...) {
       ctx->pending_sizes.clear();
       throw;

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <execinfo.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,12 @@
 namespace qhip {
 
 uint64_t& sync_counter() { static uint64_t n = 0; return n; }
+void trace_point(const char* what) {
+  static const bool on = env_int("QHIP_TRACE", 0) >= 2;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[qhip t] %10.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 void note_sync() {
   ++sync_counter();
   static const bool trace = env_int("QHIP_SYNC_TRACE", 0) != 0;

@@ -48,6 +48,7 @@ uint32_t read_u32(hipStream_t s, const void* dev) {
 qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int join_type, const qhip_expr* lex, int nlex, const qhip_expr* rex,
                       int nrex, const int32_t* on_l, const int32_t* on_r, int n_on, const qhip_expr* fex, int nfex, int froot,
                       const int32_t* fsides, const int32_t* fcols, int nfcols, int lpred, int rpred) {
+  trace_point("join: entry");
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats_timing_pending = 0;
@@ -224,7 +225,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     sl.entries = entries.as<uint64_t>(); sl.first = first.as<uint32_t>(); sl.status = dstat;
     sl.n_regions = n_regions; sl.rows_per_wg = (uint32_t)rows_per_wg;
     void* args[] = {&ka, &sl};
+    trace_point("join: first launch");
     QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, (unsigned)wgs, 1, 1, 1024, 1, 1, (n_regions + 1) * 4, s, args, nullptr));
+    trace_point("join: first launch done");
     launch_join_region_build(W, entries.as<uint64_t>(), first.as<uint32_t>(), (uint32_t)wgs, (uint32_t)rows_per_wg, table, bloom, n_regions,
                              slot_bits, bword_bits, dstat, s);
     // (entries / first go back to the pool here; whoever gets them next runs on the same stream, i.e. afterwards)
