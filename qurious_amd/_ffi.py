@@ -212,7 +212,26 @@ class Context:
         return int(self.lib.qhip_ctx_sync_count(self.handle))
 
     def allow_deferred_sizes(self, delta: int):
+        self._allow_depth = 0 if delta == 0 else max(0, getattr(self, "_allow_depth", 0) + int(delta))
         self.lib.qhip_ctx_allow_deferred_sizes(self.handle, int(delta))
+
+    def no_deferred_sizes(self):
+        """Context manager: no hash join below may leave its size on the device. The multi-rank operators run under it: a
+        join of deferred size can answer QHIP_RETRY on ONE rank only, whose re-execution of the input would repeat
+        collectives the other ranks do not take part in."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            depth = getattr(self, "_allow_depth", 0)
+            if depth:
+                self.lib.qhip_ctx_allow_deferred_sizes(self.handle, -depth)
+            try:
+                yield
+            finally:
+                if depth:
+                    self.lib.qhip_ctx_allow_deferred_sizes(self.handle, depth)
+        return _cm()
 
     def measure_stream_read(self, nbytes: int = 1 << 32, iters: int = 5) -> float:
         """Achieved GB/s of a plain streaming-read kernel over `nbytes` of HBM (the practical bandwidth ceiling)."""

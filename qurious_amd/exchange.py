@@ -27,7 +27,7 @@ import ctypes as C
 from typing import List, Optional, Sequence
 
 from . import _ffi
-from ._ffi import DeviceTable
+from ._ffi import DeviceTable, get_context
 from .datatypes import JoinType, to_qhip_dtype
 from .expr import ExprArray, PhysicalExpr, int32_array
 from .plan import HashJoinExec, PhysicalPlan
@@ -407,6 +407,10 @@ class DistributedHashJoinExec(HashJoinExec):
         world = _exchange_world(_dist())
         if not world:
             return HashJoinExec.execute_device(self)
+        with get_context().no_deferred_sizes():   # (a QHIP_RETRY on one rank would repeat collectives alone)
+            return self._execute_exchanged(world)
+
+    def _execute_exchanged(self, world) -> DeviceTable:
         ls, rs = self.left.schema(), self.right.schema()
         lneed, rneed = self._needed_per_side()
         # columns nothing above this join reads are dropped BEFORE the partitioning: never gathered, never sent
@@ -467,11 +471,12 @@ class BroadcastHashJoinExec(HashJoinExec):
             return HashJoinExec.execute_device(self)
         if self.join_type not in (JoinType.Inner, JoinType.Right):
             return DistributedHashJoinExec.execute_device(self)
-        ls = self.left.schema()
-        lneed, _ = self._needed_per_side()
-        build = all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
-        probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
-        return self._join_tables(build, probe, None, rpred)
+        with get_context().no_deferred_sizes():   # (a QHIP_RETRY on one rank would repeat collectives alone)
+            ls = self.left.schema()
+            lneed, _ = self._needed_per_side()
+            build = all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
+            probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
+            return self._join_tables(build, probe, None, rpred)
 
     _repartitioned = DistributedHashJoinExec.execute_device
 
