@@ -1160,17 +1160,22 @@ __device__ __forceinline__ void qh_join_scatter_body(const KArgs& a, const Scatt
   const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
   const i64 last = first + L.rows_per_wg < nrows ? first + L.rows_per_wg : nrows;
   u32 err = 0;
+  // a range of at most R rows per thread (the rule: 2-3) is evaluated ONCE: the placing pass reuses the counting pass's key
+  // words instead of reading the rows again (two dependent chains of column loads per workgroup become one)
+  const bool single = last - first <= (i64)TB * R;   // workgroup-uniform
+  u64 k[R][W];
+  bool ok[R];
   for (int pass = 0; pass < 2; ++pass) {
     for (i64 tb = first; tb < last; tb += (i64)TB * R) {
-      u64 k[R][W];
-      bool ok[R];
+      if (!single || pass == 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const i64 i = tb + (i64)r * TB + tid;
-        const bool inb = i < last;
-        u32 e = 0;
-        ok[r] = P::keys(a, inb ? i : last - 1, k[r], e) && inb;
-        if (pass == 0) err |= inb ? e : 0u;
+        for (int r = 0; r < R; ++r) {
+          const i64 i = tb + (i64)r * TB + tid;
+          const bool inb = i < last;
+          u32 e = 0;
+          ok[r] = P::keys(a, inb ? i : last - 1, k[r], e) && inb;
+          if (pass == 0) err |= inb ? e : 0u;
+        }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
