@@ -61,12 +61,17 @@ def catalog_sources():
             os.environ["QHIP_AGG_R"] = saved
     # a repeated Q3 runs its joins with DEFERRED sizes (qhip.h: qhip_ctx_allow_deferred_sizes): join 2's build kernel and the
     # aggregate then read their input's row count on the device — separate instantiations of the same bodies
-    os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
+    # ... and read the fixed-width columns of their input (deferred gathers) through the joins' index vectors
+    os.environ["QHIP_PLAN_INDIRECT"] = "1"
     os.environ["QHIP_AGG_R"] = "1"
     try:
-        out.append(("q3 join-1 output build entries, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
-        out.append(("q3 aggregate, 1 row/thread, device-side row count", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+        out.append(("q3 join-1 output build entries, indirect columns", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        out.append(("q3 aggregate, 1 row/thread, indirect columns", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+        os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
+        out.append(("q3 join-1 output build entries, indirect columns, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        out.append(("q3 aggregate, 1 row/thread, indirect columns, device-side row count", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
     finally:
+        os.environ.pop("QHIP_PLAN_INDIRECT", None)
         os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
         os.environ.pop("QHIP_AGG_R", None)
         if saved is not None:

@@ -94,12 +94,15 @@ qhip_table* table_from_host(Ctx* ctx, const std::vector<std::string>& names, con
 }
 
 // ---------------------------------------------------------------- helpers shared with other operators
-std::vector<InputCol> input_cols_of(const qhip_table* t) {
+std::vector<InputCol> input_cols_of(const qhip_table* t, bool mark_indirect) {
   std::vector<InputCol> v;
   for (auto& c0 : t->cols) {
     // a deferred column that nobody resolved is not referenced by the plan being typed: its may-have-nulls flag is enough
     const DevColumn& c = (c0.deferred && c0.deferred->done) ? c0.deferred->result : c0;
-    InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; ic.utf8_max_len = c.utf8_max_len; v.push_back(ic);
+    InputCol ic; ic.type = c.type; ic.has_nulls = c.null_count > 0; ic.utf8_max_len = c.utf8_max_len;
+    ic.indirect = mark_indirect && indirect_eligible(c0);
+    if (ic.indirect) ic.has_nulls = false;   // (eligible = a source without NULLs and an index vector without NULL indices)
+    v.push_back(ic);
   }
   return v;
 }
@@ -107,7 +110,14 @@ std::vector<InputCol> input_cols_of(const qhip_table* t) {
 void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& a, DevBuf& strlit_dev) {
   memset(&a, 0, sizeof(a));
   for (size_t s = 0; s < b.cols.size(); ++s) {
-    const DevColumn& c = resolved(ctx, t->cols[(size_t)b.cols[s]]);
+    const DevColumn& c0 = t->cols[(size_t)b.cols[s]];
+    if (s < b.indirect.size() && b.indirect[s]) {   // read through the deferred gather's index vector (InputCol::indirect)
+      if (!indirect_eligible(c0)) fail(QHIP_HIP_ERROR, "a column planned as an indirect read has been gathered meanwhile (internal error)");
+      a.c[s].v = c0.deferred->src.values->ptr;
+      a.c[s].d = (const uint8_t*)c0.deferred->idx->ptr;
+      continue;
+    }
+    const DevColumn& c = resolved(ctx, c0);
     a.c[s].v = c.values ? c.values->ptr : nullptr;
     a.c[s].n = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
     a.c[s].d = c.data ? (const uint8_t*)c.data->ptr : nullptr;
@@ -163,8 +173,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats_timing_pending = 0;
 
-  resolve_referenced(ctx, in, exprs, n_exprs);
-  std::vector<InputCol> icols = input_cols_of(in);
+  // (late materialisation: the plain deferred gathers of a join output are read through their index vectors by the kernel)
+  resolve_referenced(ctx, in, exprs, n_exprs, true);
+  std::vector<InputCol> icols = input_cols_of(in, true);
   ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
   // |value| bounds of the Int64 / Decimal128 columns (cached per column; computed only on inputs big enough to pay for the
   // reduction): the generated code multiplies and accumulates in 32 / 64 bits where the bounds allow
@@ -174,7 +185,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   std::string key = "agg|";
   auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
   for (auto& ic : icols) {
-    const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0};
+    const int v[7] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0};
     put(&ic.value_maxabs, sizeof ic.value_maxabs);   // (a whole number of bits, see ensure_value_bounds)
     put(v, sizeof v);
   }

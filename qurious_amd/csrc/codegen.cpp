@@ -99,6 +99,7 @@ int ExprGen::col_slot(int table_col) {
   for (size_t s = 0; s < bind.cols.size(); ++s) if (bind.cols[s] == table_col) return (int)s;
   if (bind.cols.size() >= 24) fail(QHIP_UNSUPPORTED, "expression references more than 24 distinct columns");
   bind.cols.push_back(table_col);
+  bind.indirect.push_back(table_col >= 0 && table_col < (int)in_.size() && in_[(size_t)table_col].indirect ? 1 : 0);
   return (int)bind.cols.size() - 1;
 }
 
@@ -187,11 +188,14 @@ void ExprGen::emit(int k, std::string& out) {
           // bits, so that the load is `global_load v, v_offset32, s[base]` — one VALU instruction for the address instead of a
           // 64-bit shift-add per column and row (a tile is far smaller than 4 GB / 16)
           const std::string T = ctype(n.type);
-          const std::string addr = base_.empty() ? "((const " + T + "*)a.c[" + S + "].v)[" + idx_ + "]"
+          const bool ind = in_[(size_t)n.column].indirect;   // late materialisation: source[index[row]] (random access, no streaming hint)
+          const std::string addr = ind ? "((const " + T + "*)a.c[" + S + "].v)[((const u32*)a.c[" + S + "].d)[" + row_ + "]]"
+                                   : base_.empty() ? "((const " + T + "*)a.c[" + S + "].v)[" + idx_ + "]"
                                                  : "(*(const " + T + "*)((const char*)((const " + T + "*)a.c[" + S + "].v" + base_ + ") + (size_t)((u32)(" + idx_ +
                                                        ") * (u32)sizeof(" + T + "))))";
           std::string rhs = addr;
-          if (nt_ && n.type.id == QHIP_DECIMAL128) rhs = "qh_nt_load_i128(&" + addr + ")";
+          if (ind) rhs = addr;
+          else if (nt_ && n.type.id == QHIP_DECIMAL128) rhs = "qh_nt_load_i128(&" + addr + ")";
           else if (nt_) rhs = "__builtin_nontemporal_load(&" + addr + ")";
           ld << "    " << (raw_ ? "" : "const " + ctype(n.type) + " ") << W << v << " = " << rhs << ";\n";
         }

@@ -13,6 +13,7 @@ namespace qhip {
 // what a generated kernel needs bound at launch: which table column sits in KArgs.c[slot], literal values
 struct KernelBindings {
   std::vector<int> cols;          // slot -> input column index
+  std::vector<char> indirect;     // slot -> read through the deferred gather's index vector (InputCol::indirect)
   std::vector<uint64_t> lit_lo;
   std::vector<int64_t> lit_hi;
   std::string strlits;            // concatenated Utf8 literals

@@ -65,9 +65,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool pad_right = join_type == QHIP_JOIN_RIGHT || join_type == QHIP_JOIN_FULL;
 
   // ---- key words of both sides (only the columns the key / scan-filter expressions read are gathered if deferred)
-  resolve_referenced(ctx, L, lex, nlex);
+  // (build side: the key kernels read the plain deferred gathers of a join output through their index vectors — the probe
+  // kernel streams, so the probe side's columns are gathered)
+  resolve_referenced(ctx, L, lex, nlex, true);
   resolve_referenced(ctx, R, rex, nrex);
-  std::vector<InputCol> lcols = input_cols_of(L), rcols = input_cols_of(R);
+  std::vector<InputCol> lcols = input_cols_of(L, true), rcols = input_cols_of(R);
   ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
   ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
   // both sides must pack a Utf8 key into the same number of words
@@ -128,7 +130,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     auto put = [&](const void* p, size_t n) { pkey.append((const char*)p, n); };
     for (const std::vector<InputCol>* cols : {&lcols, &rcols}) {
       for (auto& ic : *cols) {
-        const int v[6] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0};
+        const int v[7] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0};
         put(v, sizeof v);
       }
       put("|", 1);

@@ -22,6 +22,10 @@ static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_
       if (*e == ',') ++e;
     }
   }
+  // QHIP_PLAN_INDIRECT=1: every fixed-width column is a deferred gather read through its index vector (what an aggregate /
+  // a join build over a join output sees at run time, InputCol::indirect)
+  if (env_int("QHIP_PLAN_INDIRECT", 0))
+    for (auto& c : v) if (dtype_width(c.type) > 0) { c.indirect = true; c.has_nulls = false; }
   return v;
 }
 static int give(const std::string& s, char* buf, size_t buflen, size_t* needed) {

@@ -103,8 +103,8 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
     if (roots[k] < 0 || roots[k] >= n_exprs) continue;
     const qhip_expr& e = exprs[roots[k]];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
+    if (t->cols[(size_t)e.column].type.id != QHIP_UTF8) continue;   // (before resolving: a fixed-width key may be read through its index vector)
     const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
-    if (col.type.id != QHIP_UTF8) continue;
     if (col.utf8_max_len < 0) {
       DevBuf m(4);
       QHIP_HIP_CHECK(hipMemsetAsync(m.ptr, 0, 4, ctx->stream));
@@ -124,8 +124,9 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   for (int k = 0; k < n_exprs; ++k) {
     const qhip_expr& e = exprs[k];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
-    const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
-    if (col.type.id != QHIP_DECIMAL128 && col.type.id != QHIP_INT64) continue;
+    if (t->cols[(size_t)e.column].type.id != QHIP_DECIMAL128 && t->cols[(size_t)e.column].type.id != QHIP_INT64) continue;
+    // (a deferred gather the kernel reads through its index vector is not gathered for the statistic: it carries its source's)
+    const DevColumn& col = icols[(size_t)e.column].indirect ? t->cols[(size_t)e.column] : resolved(ctx, t->cols[(size_t)e.column]);
     if (col.value_maxabs == 0 && col.length >= min_rows && col.values) {
       DevBuf out(16);
       QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, 16, ctx->stream));
@@ -214,7 +215,21 @@ void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::share
   }
 }
 
-void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs) {
+bool indirect_eligible(const DevColumn& c) {
+  if (!c.deferred || c.deferred->done || c.pending_upload) return false;
+  const DeferredGather& d = *c.deferred;
+  return !d.idx_may_be_null && !d.src.deferred && !d.src.pending_upload && d.src.null_count == 0 && dtype_width(d.src.type) > 0 && d.src.values &&
+         d.idx && d.m > 0 && env_int("QHIP_NO_LATE_GATHER", 0) == 0;
+}
+
+void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, bool keep_indirect) {
+  if (keep_indirect) {   // the caller's kernel reads the plain deferred gathers through their index vectors: only the others are gathered
+    for (int k = 0; k < n_exprs; ++k)
+      if (exprs[k].kind == QHIP_EXPR_COLUMN && exprs[k].column >= 0 && exprs[k].column < (int)t->cols.size() &&
+          !indirect_eligible(t->cols[(size_t)exprs[k].column]))
+        (void)resolved(ctx, t->cols[(size_t)exprs[k].column]);
+    return;
+  }
   // the plain cases first, together: deferred gathers of fixed-width columns without NULLs (no validity to gather, nothing
   // to count) go into ONE launch per 8 columns
   {

@@ -9,7 +9,9 @@
 namespace qhip {
 
 // agg.cpp
-std::vector<InputCol> input_cols_of(const qhip_table* t);
+// mark_indirect: plain deferred gathers (indirect_eligible) are typed as read THROUGH their index vector (InputCol::indirect)
+std::vector<InputCol> input_cols_of(const qhip_table* t, bool mark_indirect = false);
+bool indirect_eligible(const DevColumn& c);
 void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& a, DevBuf& strlit_dev);
 void check_status_words(const uint32_t* st);
 
@@ -36,7 +38,7 @@ void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::share
                   std::vector<DevColumn>& out);
 void resolve_all(Ctx* ctx, const qhip_table* t);
 // gather the columns the expression trees reference (everything else may stay deferred)
-void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs);
+void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, bool keep_indirect = false);
 // make sure every Utf8 column used directly as a key (roots are Column nodes) has its longest-value length cached in the
 // table and copied into icols (packed key words are sized from it)
 void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n,
