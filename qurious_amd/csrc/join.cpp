@@ -67,9 +67,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // ---- key words of both sides (only the columns the key / scan-filter expressions read are gathered if deferred)
   // (build side: the key kernels read the plain deferred gathers of a join output through their index vectors — the probe
   // kernel streams, so the probe side's columns are gathered)
-  resolve_referenced(ctx, L, lex, nlex, true);
+  const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", 1) != 0;
+  resolve_referenced(ctx, L, lex, nlex, late_build);
   resolve_referenced(ctx, R, rex, nrex);
-  std::vector<InputCol> lcols = input_cols_of(L, true), rcols = input_cols_of(R);
+  std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
   ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
   ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
   // both sides must pack a Utf8 key into the same number of words
