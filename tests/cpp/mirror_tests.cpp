@@ -224,6 +224,31 @@ int main() {
     auto kase = std::make_shared<CaseExpr>(std::vector<std::pair<ExprRef, ExprRef>>{{std::make_shared<BinaryExpr>(col("v1", 0), QHIP_OP_GT, lit_i32(2)), plus}}, lit_i32(0));
     expect_rows("projection_case", Projection({"v1", "x"}, t, {col("v1", 0), kase}).execute(), {{1, 0}, {2, 0}, {3, 5}, {4, 6}});
   }
+  {   // no reference counterpart: a repeated join under an aggregate leaves its size on the device (detail::feed /
+      // detail::retrying, qhip_ctx_allow_deferred_sizes) — same rows every time, one host wait from the second run on
+    std::vector<std::optional<int32_t>> bk, bv, pk, pv;
+    for (int i = 0; i < 3000; ++i) { bk.push_back(i); bv.push_back(i % 7); }
+    for (int i = 0; i < 9000; ++i) { pk.push_back((i * 7919) % 4500); pv.push_back(i % 5); }
+    PlanRef build = build_table_scan_i32(ctx, {{"bk", bk}, {"bv", bv}}), probe = build_table_scan_i32(ctx, {{"pk", pk}, {"pv", pv}});
+    auto join = HashJoinExec::try_new(build, probe, QHIP_JOIN_INNER, {{col("bk", 0), col("pk", 0)}});
+    HashAggregate agg({"pv", "n", "s"}, join, {col("pv", 3)},
+                      {AggregateExpr::Count(col("bk", 0)), AggregateExpr::Sum(std::make_shared<CastExpr>(col("bv", 1), dtype(QHIP_INT64)), dtype(QHIP_INT64))});
+    Rows first;
+    uint64_t waits_last = 0;
+    for (int run = 0; run < 4; ++run) {
+      const uint64_t before = qhip_ctx_sync_count(ctx->raw());
+      DeviceTableRef t = agg.execute_device();
+      waits_last = qhip_ctx_sync_count(ctx->raw()) - before;
+      Rows got = rows_of(agg.execute());
+      std::sort(got.begin(), got.end());
+      if (run == 0) first = got;
+      ++checks;
+      if (got != first || got.size() != 5) { ++failures; fprintf(stderr, "FAIL join under aggregate, run %d: %s\n", run, show(got).c_str()); }
+    }
+    ++checks;
+    if (waits_last != 1) { ++failures; fprintf(stderr, "FAIL repeated join under aggregate: %llu host waits, expected 1\n", (unsigned long long)waits_last); }
+    else printf("ok   repeated_join_under_aggregate_waits_once\n");
+  }
   printf("%d checks, %d failures\n", checks, failures);
   return failures ? 1 : 0;
 }
