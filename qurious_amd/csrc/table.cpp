@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "hostcol.hpp"
 #include "kernels.hpp"
 #include "relops.hpp"
 
@@ -390,6 +391,56 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
   std::vector<OffFix> offfix;
   std::vector<std::pair<ArrowArray*, uint8_t*>> nullfix;
   for (size_t c = 0; c < t->cols.size(); ++c) {
+    // a column an operator assembled on the host and nobody has read on the device (an aggregate's few result rows) is
+    // exported from there: uploading it only to copy it back would cost a host -> HBM copy, a wait and an HBM -> host copy
+    if (t->cols[c].pending_upload && !t->cols[c].pending_upload->done && t->cols[c].pending_upload->host_col) {
+      const HostColumn& hc = *std::static_pointer_cast<HostColumn>(t->cols[c].pending_upload->host_col);
+      ArrowArray* ca = &top->child_storage[c];
+      HostArrayPrivate* p = new HostArrayPrivate();
+      ca->private_data = p;
+      ca->release = release_array;
+      ca->length = n;
+      ca->offset = 0;
+      ca->null_count = 0;
+      if (hc.type.id == QHIP_NULL) {
+        ca->null_count = n; ca->n_buffers = 0; ca->buffers = nullptr;
+        top->children.push_back(ca);
+        continue;
+      }
+      uint8_t* validity = nullptr;
+      if (hc.null_count > 0 && !hc.validity.empty()) {
+        validity = (uint8_t*)xmalloc((size_t)((n + 7) / 8));
+        memset(validity, 0, (size_t)((n + 7) / 8));
+        if (n) copy_bits(hc.validity.data(), r0, validity, 0, n);
+        ca->null_count = n - count_set_bits(validity, 0, n);
+        if (ca->null_count == 0) { free(validity); validity = nullptr; }
+      }
+      p->buffers.push_back(validity);
+      const int w = dtype_width(hc.type);
+      if (w > 0) {
+        uint8_t* v = (uint8_t*)xmalloc((size_t)n * w);
+        if (n) memcpy(v, hc.values.data() + (size_t)r0 * w, (size_t)n * w);
+        p->buffers.push_back(v);
+      } else if (hc.type.id == QHIP_BOOL) {
+        uint8_t* v = (uint8_t*)xmalloc((size_t)((n + 7) / 8));
+        memset(v, 0, (size_t)((n + 7) / 8));
+        if (n) copy_bits(hc.values.data(), r0, v, 0, n);
+        p->buffers.push_back(v);
+      } else if (hc.type.id == QHIP_UTF8) {
+        int32_t* off = (int32_t*)xmalloc((size_t)(n + 1) * 4);
+        const int32_t base = hc.offsets.empty() ? 0 : hc.offsets[(size_t)r0];
+        for (int64_t i = 0; i <= n; ++i) off[i] = (hc.offsets.empty() ? 0 : hc.offsets[(size_t)(r0 + i)]) - base;
+        uint8_t* data = (uint8_t*)xmalloc((size_t)off[n]);
+        if (off[n]) memcpy(data, hc.data.data() + base, (size_t)off[n]);
+        p->buffers.push_back(off);
+        p->buffers.push_back(data);
+      }
+      for (void* bp : p->buffers) p->buffer_ptrs.push_back(bp);
+      ca->n_buffers = (int64_t)p->buffer_ptrs.size();
+      ca->buffers = p->buffer_ptrs.data();
+      top->children.push_back(ca);
+      continue;
+    }
     const DevColumn& col = resolved(ctx, t->cols[c]);
     ArrowArray* ca = &top->child_storage[c];
     HostArrayPrivate* p = new HostArrayPrivate();
