@@ -336,11 +336,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     std::unique_ptr<qhip_table> out;
     std::vector<FinCol> fc;
     DevBuf fc_dev;
+    const uint32_t* fin_host = nullptr;   // page-locked [status words | null counts] of this finalisation
     std::vector<std::shared_ptr<DevBuf>> valid_bufs;
     bool has_utf8 = false;
   };
   const int cell0 = 1 + plan.W;
-  auto enqueue_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t cap_rows, const uint32_t* g_dev) {
+  // fin_dev: zeroed device words [status | null count per column] the caller provides and reads back itself (the speculative
+  // launch: they sit in the call's own status block and travel in its ONE read-back, fin_host = where they land); nullptr:
+  // a block of their own, read back here
+  auto enqueue_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t cap_rows, const uint32_t* g_dev, uint32_t* fin_dev,
+                                     const uint32_t* fin_host) {
     const int ncols = n_groups + n_aggs;
     F.fc.assign((size_t)ncols, FinCol());
     F.out.reset(new qhip_table());
@@ -397,26 +402,33 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       F.valid_bufs.push_back(vb);
       F.out->cols.push_back(std::move(col));
     }
-    F.fc_dev.alloc(F.fc.size() * sizeof(FinCol));
-    QHIP_HIP_CHECK(hipMemcpyAsync(F.fc_dev.ptr, F.fc.data(), F.fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
+    // the column descriptors travel as a kernel argument (up to kFinColsByValue of them: no upload), else through a buffer
+    const FinCol* fc_dev = nullptr;
+    if (ncols > kFinColsByValue) {
+      F.fc_dev.alloc(F.fc.size() * sizeof(FinCol));
+      QHIP_HIP_CHECK(hipMemcpyAsync(F.fc_dev.ptr, F.fc.data(), F.fc.size() * sizeof(FinCol), hipMemcpyHostToDevice, ctx->stream));
+      fc_dev = (const FinCol*)F.fc_dev.ptr;
+    }
     // [status words | null count per column], zeroed, from the context's ring; read back together
     if (ncols > 240) fail(QHIP_UNSUPPORTED, "more than 240 output columns in an aggregate assembled on the device");
-    uint32_t* fin_dev = zeroed_block(ctx, (QS_WORDS + ncols + 31) / 32);
-    launch_agg_finalize(dense, cap_rows, g_dev, plan.slot_words, plan.null_mask_word ? 1 : 0, (const FinCol*)F.fc_dev.ptr, ncols,
+    const bool own = fin_dev == nullptr;
+    if (own) fin_dev = zeroed_block(ctx, (QS_WORDS + ncols + 31) / 32);
+    launch_agg_finalize(dense, cap_rows, g_dev, plan.slot_words, plan.null_mask_word ? 1 : 0, F.fc.data(), fc_dev, ncols,
                         fin_dev + QS_WORDS, fin_dev, ctx->stream);
-    QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned, fin_dev, (size_t)(QS_WORDS + ncols) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    F.fin_host = own ? fin_pinned : fin_host;
+    if (own) QHIP_HIP_CHECK(hipMemcpyAsync(fin_pinned, fin_dev, (size_t)(QS_WORDS + ncols) * 4, hipMemcpyDeviceToHost, ctx->stream));
   };
   // (call after the stream has been synchronised at least up to the read-backs above)
   auto finish_device_finalize = [&](DevFinal& F, const uint64_t* dense, uint32_t groups, bool synced) -> qhip_table* {
     const int ncols = n_groups + n_aggs;
     if (!synced) QHIP_HIP_CHECK(sync_stream(ctx->stream));   // (the speculative launch sat in front of the call's one wait)
-    if (fin_pinned[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
+    if (F.fin_host[QS_ARITH_OVERFLOW]) fail(QHIP_EXEC_ERROR, "AVG(Decimal128): scaled sum overflows the result type (reference yields a mistyped NULL, avg.rs:105-116)");
     F.out->num_rows = groups;
     F.out->batch_offsets = {0, (int64_t)groups};
     for (int k = 0; k < ncols; ++k) {
       DevColumn& col = F.out->cols[(size_t)k];
       col.length = groups;
-      col.null_count = fin_pinned[QS_WORDS + k];
+      col.null_count = F.fin_host[QS_WORDS + k];
       if (col.null_count > 0) col.validity = F.valid_bufs[(size_t)k];
       if (F.fc[(size_t)k].kind == F_KEY_UTF8_LEN) {
         // lengths -> offsets (exclusive scan) -> bytes
@@ -470,7 +482,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     } else {
       gtable.alloc(table_bytes);
       QHIP_HIP_CHECK(hipMemsetAsync(gtable.ptr, 0, table_bytes, ctx->stream));
-      status_dev = zeroed_block(ctx);
+      // [status words (16) | counter (2) | .. | words 32..: the speculative finalisation's status (8) + null counts]
+      status_dev = zeroed_block(ctx, (32 + QS_WORDS + (n_groups + n_aggs) + 31) / 32);
       table_dev = gtable.as<uint64_t>();
     }
     HAggLaunch L;
@@ -591,7 +604,6 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         dense.alloc((size_t)guess * slot_bytes + 8);
         dense_dev = dense.as<uint64_t>();
         launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream);
-        QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
         // a plan that produced many groups last time will most likely do so again: assemble its output columns on the
         // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all,
         // and no slot crosses PCIe
@@ -600,9 +612,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         spec_enqueued = false;
         if (replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0) {
           spec = DevFinal();
-          enqueue_device_finalize(spec, dense_dev + 1, guess, counter_dev);
+          const int ncols = n_groups + n_aggs;
+          enqueue_device_finalize(spec, dense_dev + 1, guess, counter_dev, status_dev + 32, status_pinned + 32);
           spec_enqueued = true;
+          // ONE read-back: status + counter + the finalisation's status and null counts
+          QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, (size_t)(32 + QS_WORDS + ncols) * 4, hipMemcpyDeviceToHost, ctx->stream));
         } else {
+          QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
           pre_copied = std::min(PRE, guess);
           QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -752,7 +768,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe
     DevFinal fin;
-    enqueue_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, nullptr);
+    enqueue_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, nullptr, nullptr, nullptr);
     qhip_table* result = finish_device_finalize(fin, dense_keep.as<uint64_t>() + 1, G, false);
     set_stats();
     return result;

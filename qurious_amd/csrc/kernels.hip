@@ -21,14 +21,25 @@ __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u3
   const u32 nwaves = gridDim.x * (QH_BLOCK / 64), wave = blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6);
   const u32 per_wave = ((nslots + nwaves - 1) / nwaves + 63) / 64 * 64;
   const u64 lo = (u64)wave * per_wave, hi = lo + per_wave < (u64)nslots ? lo + per_wave : (u64)nslots;
-  if (lo >= hi) return;
+  // ONE atomic per workgroup: the wavefronts' totals meet in LDS, wavefront 0 reserves the workgroup's share and every
+  // wavefront starts behind its predecessors' (a 262 k-slot table: 256 same-address atomics instead of 1 024)
+  __shared__ u32 wtot[QH_BLOCK / 64];
+  __shared__ u32 wg_base;
+  const u32 w = threadIdx.x >> 6;
   u32 mine = 0;
-  for (u64 s = lo + lane; s < hi; s += 64) mine += table[(size_t)s * slot_words] == QH_READY ? 1u : 0u;
+  if (lo < hi) for (u64 s = lo + lane; s < hi; s += 64) mine += table[(size_t)s * slot_words] == QH_READY ? 1u : 0u;
   const u32 total = (u32)qh_wave_sum_u64(mine);
-  if (!total) return;
-  u32 base = 0;
-  if (lane == 0) base = atomicAdd(counter, total);
-  base = qh_readlane32(base, 0);
+  if (lane == 0) wtot[w] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 all = 0;
+    for (int k = 0; k < QH_BLOCK / 64; ++k) all += wtot[k];
+    wg_base = all ? atomicAdd(counter, all) : 0u;
+  }
+  __syncthreads();
+  if (lo >= hi || !total) return;
+  u32 base = wg_base;
+  for (u32 k = 0; k < w; ++k) base += wtot[k];
   for (u64 s0 = lo; s0 < hi; s0 += 64) {
     const u64 s = s0 + lane;
     const u64* slot = table + (size_t)s * slot_words;

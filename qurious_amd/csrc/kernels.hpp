@@ -56,7 +56,7 @@ void launch_sort_utf8_chunk(const int32_t* offsets, const uint8_t* data, const u
 void stable_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
                            hipStream_t s);
 // several fixed-width gathers (out[k] = in[idx[k]], NULL index -> zero) in one launch
-struct GatherDesc { const void* in; const uint32_t* idx; void* out; uint64_t m; uint32_t width; uint32_t pad_; };
+struct GatherDesc { const void* in; const uint32_t* idx; void* out; uint64_t m; uint32_t width; uint32_t null_ones; };   // null_ones: a NULL index yields all-one bytes (index composition: NULL stays NULL), else zeros
 constexpr int kGatherBatch = 8;
 struct GatherBatch { GatherDesc d[kGatherBatch]; };
 void launch_gather_multi(const GatherBatch& b, int n, hipStream_t s);
@@ -93,8 +93,9 @@ struct FinCol {
   void* out_values;     // device
   uint64_t* out_valid;  // device, one ballot word per 64 groups
 };
-void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_dev,
-                         int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s);
+constexpr int kFinColsByValue = 24;   // column descriptors passed as a kernel argument (24 x 80 bytes); more go through cols_dev
+void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_host,
+                         const FinCol* cols_dev, int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s);
 void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
                                hipStream_t s);
 }  // namespace qhip

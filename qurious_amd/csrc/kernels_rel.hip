@@ -226,24 +226,24 @@ __global__ __launch_bounds__(QH_BLOCK) void k_gather_fixed(const T* in, const u3
 // ... several columns in ONE launch (blockIdx.y = the column): what an aggregate / join reads from a join output are a few
 // short fixed-width columns, each a ~5 us launch of its own otherwise
 template <class T>
-__device__ __forceinline__ void qh_gather_loop(const void* in_, const u32* idx, void* out_, u64 m) {
+__device__ __forceinline__ void qh_gather_loop(const void* in_, const u32* idx, void* out_, u64 m, u32 null_ones) {
   const T* in = (const T*)in_;
   T* out = (T*)out_;
   for (u64 k = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; k < m; k += (u64)gridDim.x * QH_BLOCK) {
     const u32 i = idx[k];
     T v;
-    if (i == QH_NULL_IDX) memset(&v, 0, sizeof(T)); else v = in[i];
+    if (i == QH_NULL_IDX) memset(&v, null_ones ? 0xFF : 0, sizeof(T)); else v = in[i];
     out[k] = v;
   }
 }
 __global__ __launch_bounds__(QH_BLOCK) void k_gather_multi(GatherBatch b) {
   const GatherDesc d = b.d[blockIdx.y];
   switch (d.width) {
-    case 1: qh_gather_loop<u8>(d.in, d.idx, d.out, d.m); break;
-    case 2: qh_gather_loop<u16>(d.in, d.idx, d.out, d.m); break;
-    case 4: qh_gather_loop<u32>(d.in, d.idx, d.out, d.m); break;
-    case 8: qh_gather_loop<u64>(d.in, d.idx, d.out, d.m); break;
-    default: qh_gather_loop<u128>(d.in, d.idx, d.out, d.m); break;
+    case 1: qh_gather_loop<u8>(d.in, d.idx, d.out, d.m, d.null_ones); break;
+    case 2: qh_gather_loop<u16>(d.in, d.idx, d.out, d.m, d.null_ones); break;
+    case 4: qh_gather_loop<u32>(d.in, d.idx, d.out, d.m, d.null_ones); break;
+    case 8: qh_gather_loop<u64>(d.in, d.idx, d.out, d.m, d.null_ones); break;
+    default: qh_gather_loop<u128>(d.in, d.idx, d.out, d.m, d.null_ones); break;
   }
 }
 // Mask-driven compaction of a fixed-width column (Filter with a predicate that keeps a good part of the rows): wavefront
@@ -758,8 +758,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64
 // Used when there are too many groups to finish on the host (Q3: ~10^5 groups at SF10).
 __device__ __forceinline__ double qh_ord_to_f64(u64 k) { return qh_ord_f64(k); }
 
+struct FinColsArg { FinCol c[kFinColsByValue]; };
 __global__ __launch_bounds__(QH_BLOCK) void k_agg_finalize(const u64* dense, u32 G_cap, const u32* g_dev, int slot_words, int null_mask_word,
-                                                          const FinCol* cols, int ncols, u32* null_counts, u32* status) {
+                                                          FinColsArg byval, const FinCol* cols_dev, int ncols, u32* null_counts, u32* status) {
+  const FinCol* cols = cols_dev ? cols_dev : byval.c;
   // g_dev: the group count is still on the device (speculative launch behind the compaction); never beyond the capacity
   const u32 G = g_dev ? (*g_dev < G_cap ? *g_dev : G_cap) : G_cap;
   const u64 nwords = ((u64)G + 63) / 64;
@@ -1024,11 +1026,14 @@ void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t npar
   DISPATCH_W(W, hipLaunchKernelGGL(k_partition_ids<KW>, dim3(grid_for(n, QH_BLOCK * 16, 1024)), dim3(QH_BLOCK), 0, s, (const u64*)keys, (u64)n, nparts, (u32*)part, (u32*)hist));
 }
 
-void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_dev,
-                         int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s) {
+void launch_agg_finalize(const uint64_t* dense, uint32_t G_cap, const uint32_t* g_dev, int slot_words, int null_mask_word, const FinCol* cols_host,
+                         const FinCol* cols_dev, int ncols, uint32_t* null_counts, uint32_t* status, hipStream_t s) {
   if (!G_cap) return;
+  FinColsArg byval;
+  memset(&byval, 0, sizeof byval);
+  if (!cols_dev) for (int k = 0; k < ncols && k < kFinColsByValue; ++k) byval.c[k] = cols_host[k];
   hipLaunchKernelGGL(k_agg_finalize, dim3(grid_for(((uint64_t)G_cap + 63) / 64 * 64)), dim3(QH_BLOCK), 0, s, (const u64*)dense, G_cap, (const u32*)g_dev,
-                     slot_words, null_mask_word, cols_dev, ncols, (u32*)null_counts, (u32*)status);
+                     slot_words, null_mask_word, byval, cols_dev, ncols, (u32*)null_counts, (u32*)status);
 }
 void launch_agg_utf8_key_bytes(const uint64_t* dense, uint32_t G, int slot_words, int src_word, const uint32_t* offsets, uint8_t* data,
                                hipStream_t s) {

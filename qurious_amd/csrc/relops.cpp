@@ -182,6 +182,24 @@ void resolve_all(Ctx* ctx, const qhip_table* t) {
 void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::shared_ptr<DevBuf>& idx, uint64_t m, bool idx_may_be_null,
                   std::vector<DevColumn>& out) {
   std::vector<std::pair<const DevBuf*, std::shared_ptr<DevBuf>>> composed;   // inner index vector -> inner[idx]
+  // the compositions (one per distinct inner index vector) go into ONE launch
+  {
+    GatherBatch gb;
+    memset(&gb, 0, sizeof gb);
+    int n = 0;
+    for (const DevColumn& c : cols) {
+      if (!(c.deferred && !c.deferred->done)) continue;
+      const DeferredGather& in = *c.deferred;
+      bool seen = false;
+      for (auto& e : composed) seen = seen || e.first == in.idx.get();
+      if (seen || n >= kGatherBatch) continue;
+      auto both = std::make_shared<DevBuf>((m + 1) * 4);
+      gb.d[n++] = GatherDesc{in.idx->ptr, idx->as<uint32_t>(), both->ptr, m, 4u, 1u};
+      composed.emplace_back(in.idx.get(), both);
+    }
+    if (n == 1) launch_gather_u32_nullable((const uint32_t*)gb.d[0].in, gb.d[0].idx, (uint32_t*)gb.d[0].out, m, ctx->stream);
+    else if (n > 1) launch_gather_multi(gb, n, ctx->stream);
+  }
   for (const DevColumn& c : cols) {
     DevColumn o;
     o.type = c.type;
@@ -257,7 +275,7 @@ void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, i
         out.value_maxabs = d.src.value_maxabs;
         const int w = dtype_width(d.src.type);
         out.values = std::make_shared<DevBuf>((size_t)d.m * (size_t)w);
-        gb.d[j] = GatherDesc{d.src.values->ptr, d.idx->as<uint32_t>(), out.values->ptr, d.m, (uint32_t)w, 0};
+        gb.d[j] = GatherDesc{d.src.values->ptr, d.idx->as<uint32_t>(), out.values->ptr, d.m, (uint32_t)w, 0u};
         d.result = std::move(out);
       }
       launch_gather_multi(gb, n, ctx->stream);
