@@ -30,12 +30,14 @@ def catalog_sources():
     # statistics (quantity 13 bits, price 24, discount / tax 4): 32 / 64-bit multiplies, 64-bit lane accumulators
     import os
     os.environ["QHIP_PLAN_VALUE_BITS"] = "3:13,4:24,5:4,6:4"
+    os.environ["QHIP_PLAN_UTF8_FIXED1"] = "1,2"   # l_returnflag / l_linestatus: one byte each, addressed by row number
     try:
         for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table))):
             scan = plan.input
             out.append((name + " filter+aggregate, bounded values", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
     finally:
         os.environ.pop("QHIP_PLAN_VALUE_BITS", None)
+        os.environ.pop("QHIP_PLAN_UTF8_FIXED1", None)
     # Q3: build-side key words (+ fused scan filter), fused probe kernels, the aggregate over the second join's output
     tabs = (MemoryTable.try_new(CUSTOMER_SCHEMA, []), MemoryTable.try_new(ORDERS_SCHEMA, []), MemoryTable.try_new(LINEITEM_Q3_SCHEMA, []))
     agg = queries.q3(*tabs)
@@ -80,6 +82,7 @@ def catalog_sources():
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)
     out.append(("filter mask", planning.filter_source(LINEITEM_SCHEMA, queries.q1_full(table).input.filter)))
+    out.append(("filter mask, <", planning.filter_source(LINEITEM_SCHEMA, E.BinaryExpr(E.Column("l_shipdate", 0), Operator.Lt, queries._date("1992-01-27")))))
     like = E.Like(False, E.Column("l_returnflag", 1), E.Literal(ScalarValue.Utf8("A%")))
     case = E.CaseExpr([(like, E.Column("l_extendedprice", 4))], E.CastExpr(E.Literal(ScalarValue.Int64(0)), pa.decimal128(15, 2)))
     ratio = E.BinaryExpr(E.Column("l_extendedprice", 4), Operator.Div, E.Column("l_quantity", 3))

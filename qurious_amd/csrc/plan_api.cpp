@@ -22,6 +22,16 @@ static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_
       if (*e == ',') ++e;
     }
   }
+  // QHIP_PLAN_UTF8_FIXED1="1,2": every value of these Utf8 columns is exactly one byte long (what an execution finds out on the
+  // device for TPC-H's flag columns, relops.cpp ensure_utf8_key_lengths): the kernel addresses their bytes by row number
+  if (const char* e = getenv("QHIP_PLAN_UTF8_FIXED1")) {
+    int col = 0, used = 0;
+    while (*e && sscanf(e, "%d%n", &col, &used) == 1) {
+      if (col >= 0 && col < n && v[(size_t)col].type.id == QHIP_UTF8) { v[(size_t)col].utf8_max_len = 1; v[(size_t)col].utf8_fixed1 = true; }
+      e += used;
+      if (*e == ',') ++e;
+    }
+  }
   // QHIP_PLAN_INDIRECT=1: every fixed-width column is a deferred gather read through its index vector (what an aggregate /
   // a join build over a join output sees at run time, InputCol::indirect)
   if (env_int("QHIP_PLAN_INDIRECT", 0))
