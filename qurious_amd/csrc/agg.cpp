@@ -520,8 +520,13 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       // pass 2 gains less than the reduce pass loses with one or two workgroups per CU: 50 M rows -> 1 M groups 1.86 -> 2.23 ms
       // at 64 KB, 2.98 ms at 128 KB; off by default)
       uint32_t l_nslots_p = l_nslots;
+      // the reduce pass as 1 024-thread workgroups with 128 KB LDS tables (one per CU, 16 wavefronts): four times the groups
+      // per bin = a quarter of the bins = 4x longer runs per tile in pass 2, and the reduce pass itself keeps its occupancy
+      // (with 256-thread workgroups bigger tables lost more than pass 2 gained). 50 M rows -> 1 M groups 1.87 -> 1.56 ms,
+      // Zipf(1.1) keys 1.69 -> 1.50 ms (QHIP_AGG_PART_WIDE=0: the 256-thread reduce pass)
+      const bool wide = env_int("QHIP_AGG_PART_WIDE", 1) != 0 && !getenv("QHIP_AGG_LDS_BYTES") && plan.part_pr > 0 && (uint64_t)slot_bytes * 64 <= 128 * 1024;
       if (!getenv("QHIP_AGG_LDS_BYTES"))
-        while ((uint64_t)l_nslots_p * 2 * slot_bytes <= (uint64_t)env_int("QHIP_AGG_PART_LDS_BYTES", 0)) l_nslots_p *= 2;
+        while ((uint64_t)l_nslots_p * 2 * slot_bytes <= (uint64_t)env_int("QHIP_AGG_PART_LDS_BYTES", wide ? 128 * 1024 : 0)) l_nslots_p *= 2;
       const uint32_t per_bin = std::max<uint32_t>(16, l_nslots_p * (l_nslots_p > l_nslots ? 5 : 3) / 8);   // groups a bin should hold
       uint32_t n_bins = 16;
       while (n_bins < 4096 && (uint64_t)n_bins * per_bin < std::max<uint32_t>(plan.last_groups, 1)) n_bins *= 2;
@@ -561,7 +566,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
       // work items: a bin, or a slice of a big one (a heavy key's bin is aggregated by several workgroups, each merging
       // its LDS table into the HBM table: the key is merged once per slice, not once per row)
-      const uint32_t max_item = (uint32_t)std::max(4096, env_int("QHIP_AGG_PARTITION_ITEM", 32768));
+      // (work items of 128 k records for the wide reduce pass: 256 k is better for uniform keys, 64 k for skewed ones)
+      const uint32_t max_item = (uint32_t)std::max(4096, env_int("QHIP_AGG_PARTITION_ITEM", wide ? 131072 : 32768));
       for (uint32_t b = 0; b < n_bins; ++b)
         for (uint32_t r = first[b]; r < first[b + 1]; r += max_item) item_first.push_back(r);
       const uint32_t n_items = (uint32_t)item_first.size();
@@ -576,8 +582,14 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         HAggLaunch Lp = L;
         Lp.l_nslots = l_nslots_p;
         void* rargs[] = {&rl, &Lp};
-        const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 4);
-        QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
+        if (wide) {
+          std::shared_ptr<Module> m_wide = get_module(ctx, plan.source, "qk_agg_reduce_wide");
+          const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 2);
+          QHIP_HIP_CHECK(hipModuleLaunchKernel(m_wide->fn, rgrid, 1, 1, 1024, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
+        } else {
+          const unsigned rgrid = (unsigned)std::min<uint64_t>(n_items, (uint64_t)ctx->num_cus * 4);
+          QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
+        }
         QHIP_HIP_CHECK(sync_stream(s));   // hist / records / items go back to the pool here; item_first is pageable
       }
 

@@ -877,6 +877,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (P.part_pr > 0)
       s << "extern \"C\" __global__ __launch_bounds__(QH_STAGE_BLOCK) void qk_agg_part_stage(KArgs a, PartLaunch L) { qh_agg_part_stage_body<P" << dr << ">(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_reduce(ReduceLaunch R, AggLaunch L) { qh_agg_reduce_body<P>(R, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_agg_reduce_wide(ReduceLaunch R, AggLaunch L) { qh_agg_reduce_body<P, 1024>(R, L); }\n";
   }
   P.source = s.str();
   P.bind = g.bind;

@@ -404,11 +404,11 @@ __device__ __forceinline__ void qh_update_group(u64* ltable, const AggLaunch& L,
 
 // Every ready slot of the workgroup's LDS table is merged into the HBM table (one find-or-insert + the cells' atomics per
 // slot); returns this thread's count of merged slots. Callers synchronise the workgroup before.
-template <class P>
+template <class P, int TB = QH_BLOCK>
 __device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& L) {
   constexpr int W = P::W;
   u32 used = 0;
-  for (u32 s = threadIdx.x; s < L.l_nslots; s += QH_BLOCK) {
+  for (u32 s = threadIdx.x; s < L.l_nslots; s += TB) {
     u64* ls = ltable + (size_t)s * P::SLOT_WORDS;
     if (ls[0] == QH_READY) {
       ++used;
@@ -808,7 +808,9 @@ struct ReduceLaunch {
   u32 n_items;
 };
 
-template <class P>
+// (TB: threads per workgroup — 256, or 1 024 with a 128 KB LDS table: one workgroup per CU still runs 16 wavefronts, and
+// FOUR times the groups per bin mean a quarter of the bins, i.e. 4x longer runs per tile in pass 2)
+template <class P, int TB = QH_BLOCK>
 __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const AggLaunch& L) {
   constexpr int W = P::W;
   u64* ltable = (u64*)qh_dyn_lds;
@@ -816,17 +818,17 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
   const u32 lwords = L.l_nslots * (u32)P::SLOT_WORDS;
   u32 err = 0;
   for (u32 item = blockIdx.x; item < R.n_items; item += gridDim.x) {
-    for (u32 k = tid; k < lwords; k += QH_BLOCK) ltable[k] = 0;
+    for (u32 k = tid; k < lwords; k += TB) ltable[k] = 0;
     __syncthreads();
     const u32 r0 = R.item_first[item], r1 = R.item_first[item + 1];
     constexpr int RR = 4;   // records per thread and iteration: their loads are issued together
-    for (u32 i0 = r0; i0 < r1; i0 += QH_BLOCK * RR) {
+    for (u32 i0 = r0; i0 < r1; i0 += TB * RR) {
       u64 key[RR][W > 0 ? W : 1];
       typename P::Part part[RR];
       bool live[RR];
 #pragma unroll
       for (int r = 0; r < RR; ++r) {
-        const u32 i = i0 + (u32)r * QH_BLOCK + tid;
+        const u32 i = i0 + (u32)r * TB + tid;
         live[r] = i < r1;
         const u64* rec = R.records + (size_t)(live[r] ? i : r1 - 1) * (P::SLOT_WORDS - 1) - 1;
 #pragma unroll
@@ -838,7 +840,7 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
         if (live[r]) qh_update_group<P>(ltable, L, key[r], part[r], err);   // LDS table; a bin with more groups than it holds spills to HBM
     }
     __syncthreads();
-    (void)qh_merge_lds_table<P>(ltable, L);
+    (void)qh_merge_lds_table<P, TB>(ltable, L);
     __syncthreads();
   }
   qh_report(L.status, err);
