@@ -65,9 +65,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool pad_right = join_type == QHIP_JOIN_RIGHT || join_type == QHIP_JOIN_FULL;
 
   // ---- key words of both sides (only the columns the key / scan-filter expressions read are gathered if deferred)
-  // (build side: the key kernels read the plain deferred gathers of a join output through their index vectors — the probe
-  // kernel streams, so the probe side's columns are gathered)
-  const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", 1) != 0;
+  // (measured on Q3's second join: reading the build key through join 1's index vector inside qk_join_scatter costs 17 us
+  // more than the separate gather it saves — 92 vs 75 us — so the build side gathers; QHIP_LATE_GATHER_BUILD=1 switches it on)
+  const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", 0) != 0;
   resolve_referenced(ctx, L, lex, nlex, late_build);
   resolve_referenced(ctx, R, rex, nrex);
   std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
