@@ -143,3 +143,28 @@ def test_planner_choices_mirror_the_reference():
     assert [f.nullable for f in s] == [True, False] and idx == [(0, q.JoinSide.Left), (0, q.JoinSide.Right)]
     s, idx = q.build_join_schema(nn, nn, q.JoinType.LeftSemi)
     assert len(s) == 1
+
+
+def test_catalog_holds_the_kernel_variants_a_repeated_q3_launches():
+    """The kernel catalog (compiled by build()) must contain what the benchmark launches after its first execution: the
+    aggregate that reads its input through the joins' index vectors (InputCol::indirect) and the kernels that take their
+    input's row count from the device (a hash join of deferred size) — separate instantiations of the same bodies."""
+    from qurious_amd import catalog
+    srcs = dict(catalog.catalog_sources())
+    agg = srcs["q3 aggregate, 1 row/thread"]
+    agg_ind = srcs["q3 aggregate, 1 row/thread, indirect columns"]
+    agg_ind_dr = srcs["q3 aggregate, 1 row/thread, indirect columns, device-side row count"]
+    scat = srcs["q3 join-1 output build entries"]
+    scat_dr = srcs["q3 join-1 output build entries, device-side row count"]
+    assert len({agg, agg_ind, agg_ind_dr}) == 3 and scat != scat_dr
+    # an indirect column: value = source[index[row]], the index vector travels in KCol::d
+    assert "((const u32*)a.c[" in agg_ind and "].d)[" in agg_ind and "((const u32*)a.c[" not in agg
+    # the row count on the device: the DEVROWS instantiation of the bodies
+    assert "qh_filter_agg_body<P, true>" in agg_ind_dr and "qh_filter_agg_body<P>" in agg_ind
+    assert "qh_join_scatter_body<P, true>" in scat_dr and "qh_join_scatter_body<P>" in scat
+    # the probe kernel: one entry point per table layout, five waves per SIMD pinned
+    probe = srcs["q3 lineitem probe"]
+    assert "qk_join_probe(" in probe and "qk_join_probe_onetable(" in probe and "amdgpu_waves_per_eu(5)" in probe
+    # Q1's catalog variant knows what an execution finds out about the data: narrow values, one-byte flag columns
+    q1 = srcs["q1_full filter+aggregate, bounded values"]
+    assert q1 != srcs["q1_full filter+aggregate"]
