@@ -168,3 +168,57 @@ def test_catalog_holds_the_kernel_variants_a_repeated_q3_launches():
     # Q1's catalog variant knows what an execution finds out about the data: narrow values, one-byte flag columns
     q1 = srcs["q1_full filter+aggregate, bounded values"]
     assert q1 != srcs["q1_full filter+aggregate"]
+
+
+def test_retry_protocol_of_the_host_mirror():
+    """plan.py's side of deferred join sizes (qhip.h: qhip_ctx_allow_deferred_sizes), without a device: a consumer executes
+    its input with deferral allowed (+1 / -1 around the child), QHIP_RETRY from the consumer's call re-executes the input,
+    any other error resets the allowance, and a RETRY that keeps coming back surfaces after three attempts."""
+    import pytest
+    from qurious_amd import _ffi
+    from qurious_amd import plan as P
+
+    class Ctx:
+        def __init__(self):
+            self.depth, self.log = 0, []
+
+        def allow_deferred_sizes(self, d):
+            self.depth = 0 if d == 0 else self.depth + d
+            self.log.append(d)
+
+    ctx, runs = Ctx(), []
+
+    class Node(P.PhysicalPlan):
+        def execute_device(self):
+            runs.append(ctx.depth)
+            return f"table{len(runs)}"
+
+    def run():
+        t = P._feeding(ctx, Node())
+        assert ctx.depth == 0          # the allowance covers the child only: the consumer's own call runs without it
+        if len(runs) == 1:
+            raise _ffi.RetryInput(_ffi.QHIP_RETRY, "a hash join that did not wait for its size has to run again")
+        return t
+
+    assert P._retrying(ctx, run) == "table2" and runs == [1, 1] and ctx.depth == 0 and ctx.log == [1, -1, 1, -1]
+
+    def bad():
+        P._feeding(ctx, Node())
+        raise _ffi.ArrowError(_ffi.QHIP_EXEC_ERROR, "Arrow error: Divide by zero error")
+
+    with pytest.raises(_ffi.ArrowError):
+        P._retrying(ctx, bad)
+    assert ctx.depth == 0 and ctx.log[-1] == 0
+
+    attempts = []
+
+    def always():
+        attempts.append(1)
+        raise _ffi.RetryInput(_ffi.QHIP_RETRY, "again")
+
+    with pytest.raises(_ffi.RetryInput):
+        P._retrying(ctx, always)
+    assert len(attempts) == 3
+    # the status code maps to the exception the mirrors catch
+    with pytest.raises(_ffi.RetryInput):
+        _ffi._raise(_ffi.QHIP_RETRY, "x")
