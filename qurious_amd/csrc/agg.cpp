@@ -608,21 +608,28 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         // counter at +64 (zeroed with the arena), dense slots behind the table; the 8 bytes in front of the slots are a
         // copy target only in the read-back below, so read counter and slots separately
         dense_dev = (uint64_t*)(arena->as<uint8_t>() + zero_bytes) ;
-        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream);
+        // the first pre_copied dense slots land in page-locked host memory straight from the compaction kernel (no
+        // device-to-host copy of the slots behind it: that copy goes through the DMA engine, ~25 us with its hand-over gaps)
         pre_copied = std::min(PRE, guess);
+        const bool direct = env_int("QHIP_AGG_PINNED_SLOTS", 1) != 0;
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream, direct ? pre_host + 1 : nullptr, pre_copied);
         QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
-        QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (!direct) QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
       } else {
         dense.alloc((size_t)guess * slot_bytes + 8);
         dense_dev = dense.as<uint64_t>();
-        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream);
         // a plan that produced many groups last time will most likely do so again: assemble its output columns on the
         // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all,
         // and no slot crosses PCIe
         bool utf8_key = false;
         for (auto& kd : plan.keys) utf8_key = utf8_key || kd.type.id == QHIP_UTF8;
         spec_enqueued = false;
-        if (replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0) {
+        const bool will_spec = replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0;
+        // (a host-side result: its first dense slots go to page-locked host memory straight from the compaction kernel)
+        const bool direct = !will_spec && env_int("QHIP_AGG_PINNED_SLOTS", 1) != 0;
+        launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream, direct ? pre_host + 1 : nullptr,
+                             std::min(PRE, guess));
+        if (will_spec) {
           spec = DevFinal();
           const int ncols = n_groups + n_aggs;
           enqueue_device_finalize(spec, dense_dev + 1, guess, counter_dev, status_dev + 32, status_pinned + 32);
@@ -632,7 +639,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         } else {
           QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
           pre_copied = std::min(PRE, guess);
-          QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+          if (!direct) QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
         }
       }
     }

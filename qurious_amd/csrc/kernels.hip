@@ -15,8 +15,11 @@ namespace qhip {
 // Every wavefront owns a contiguous range of slots: it counts the ready ones (state words only), reserves its share of
 // the output with ONE atomic, then copies. (Atomics on one address cost ~10 ns each across the 8 XCDs: one per group
 // or even one per 64 slots would dominate the kernel.)
+// out_host (optional): page-locked HOST memory that receives the first cap_host dense slots as well — a result of few groups
+// lands where the host reads it without a device-to-host copy behind the kernel (a 26 KB copy goes through the DMA engine:
+// ~25 us of stream time with its hand-over gaps, on the critical path of TPC-H Q1's step)
 __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u32 nslots, int slot_words, u64* out, u32* counter,
-                                                            u32 out_capacity) {
+                                                            u32 out_capacity, u64* out_host, u32 cap_host) {
   const int lane = qh_lane();
   const u32 nwaves = gridDim.x * (QH_BLOCK / 64), wave = blockIdx.x * (QH_BLOCK / 64) + (threadIdx.x >> 6);
   const u32 per_wave = ((nslots + nwaves - 1) / nwaves + 63) / 64 * 64;
@@ -49,6 +52,10 @@ __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u3
       const u32 idx = base + (u32)__popcll(m & ((1ULL << lane) - 1));
       if (idx < out_capacity) {
         u64* o = out + (size_t)idx * slot_words;
+        for (int k = 0; k < slot_words; ++k) o[k] = slot[k];
+      }
+      if (idx < cap_host) {
+        u64* o = out_host + (size_t)idx * slot_words;
         for (int k = 0; k < slot_words; ++k) o[k] = slot[k];
       }
     }
@@ -93,11 +100,11 @@ static inline unsigned grid_for(uint64_t n, unsigned cap = 2048) {
 }
 
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
-                          uint32_t out_capacity, hipStream_t s) {
+                          uint32_t out_capacity, hipStream_t s, uint64_t* out_host, uint32_t cap_host) {
   // few, long-lived wavefronts: 64 .. 2048 of them, each with >= 256 slots
   const unsigned blocks = (unsigned)std::max<uint64_t>(16, std::min<uint64_t>(512, ((uint64_t)nslots + 1023) / 1024));
   hipLaunchKernelGGL(k_compact_slots, dim3(blocks), dim3(QH_BLOCK), 0, s, (const u64*)table, nslots, slot_words, (u64*)out, counter,
-                     out_capacity);
+                     out_capacity, (u64*)out_host, out_host ? cap_host : 0u);
 }
 
 }  // namespace qhip

@@ -10,7 +10,7 @@ constexpr uint32_t kNullIdx = 0xFFFFFFFFu;   // NULL row index in u32 index vect
 // group table -> dense slot array (kernels.hip)
 void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned blocks, hipStream_t s);
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
-                          uint32_t out_capacity, hipStream_t s);
+                          uint32_t out_capacity, hipStream_t s, uint64_t* out_host = nullptr, uint32_t cap_host = 0);   // out_host: page-locked host memory for the first cap_host slots
 
 // scan / selection / gather (kernels_rel.hip)
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, hipStream_t s);
