@@ -659,7 +659,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     trace_point("aggregate: back from its wait");
     verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)
     // a join of deferred size that turned out to have produced nothing has no output batches (hash_join.rs:363-372)
-    if (in->rows_dev && in->rows_host && *in->rows_host == 0 && n_groups > 0) return no_batches_out();
+    if (in->rows_dev && in->deferred_count() == 0 && n_groups > 0) return no_batches_out();
     if (ctx->timing) QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
     check_status_words(status);
     if (!status[QS_OVERFLOW]) break;

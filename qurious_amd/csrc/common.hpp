@@ -78,7 +78,7 @@ struct DevBuf {
 };
 
 // Every host wait on the device goes through these two (counted: qhip_ctx_sync_count, the "host round trips" of a plan)
-uint64_t& sync_counter();
+uint64_t sync_counter();
 void note_sync();   // counts; QHIP_SYNC_TRACE=1 prints who waits (ctx.cpp)
 void trace_point(const char* what);   // QHIP_TRACE=2: absolute host time of a named point (where does the time between two queries go)
 // (polling hipStreamQuery / hipEventQuery instead of blocking was measured: no gain for Q3, Q1's step 0.71 -> 0.86 ms)
@@ -175,7 +175,13 @@ struct qhip_table {
   // it is (their kernels stop at *rows_dev); every other reader calls settle_rows() first.
   mutable std::shared_ptr<qhip::DevBuf> rows_blk;   // owns the device-side count
   mutable const uint32_t* rows_dev = nullptr;       // -> the pair total the join's pass 2 left there
-  mutable const uint32_t* rows_host = nullptr;      // -> its page-locked copy
+  mutable const uint32_t* rows_host = nullptr;      // -> its page-locked copy (a ring slot: valid until verify_pending_sizes has read it)
+  mutable std::shared_ptr<uint64_t> rows_final;     // the verified total, written by verify_pending_sizes (~0 = not yet)
+  // the exact row count of a table of deferred size; call only after a stream synchronisation + verify_pending_sizes
+  int64_t deferred_count() const {
+    const uint64_t m = (rows_final && *rows_final != ~0ull) ? *rows_final : (rows_host ? (uint64_t)*rows_host : (uint64_t)num_rows);
+    return (int64_t)(m < (uint64_t)num_rows ? m : (uint64_t)num_rows);
+  }
 };
 namespace qhip {
 // Make num_rows exact: wait for the stream, check the deferred joins' status words (verify_pending_sizes; may throw
@@ -215,7 +221,9 @@ struct Ctx {
   // (verify_pending_sizes): more pairs than the capacity / duplicate build keys -> the hint is dropped and the consumer
   // returns QHIP_RETRY (its input is re-executed, this time waiting).
   std::unordered_map<uint64_t, uint64_t> join_size_hints;
-  struct PendingSize { uint32_t* slot; uint64_t key; uint64_t capacity; uint64_t dup_hint; };
+  // (total_out: the output table's own host word — the page-locked slot is part of a ring and is reused by later joins, so
+  // the verified total is copied where the table can still find it however long it stays unsettled)
+  struct PendingSize { uint32_t* slot; uint64_t key; uint64_t capacity; uint64_t dup_hint; std::shared_ptr<uint64_t> total_out; };
   std::vector<PendingSize> pending_sizes;
   uint32_t* size_slots = nullptr;   // page-locked ring: kSizeSlots x 32 words
   int size_slot_next = 0;

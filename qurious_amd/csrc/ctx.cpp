@@ -16,7 +16,8 @@
 
 namespace qhip {
 
-uint64_t& sync_counter() { static uint64_t n = 0; return n; }
+static std::atomic<uint64_t> g_sync_count{0};   // process-wide (contexts on several threads): atomic
+uint64_t sync_counter() { return g_sync_count.load(std::memory_order_relaxed); }
 void trace_point(const char* what) {
   static const bool on = env_int("QHIP_TRACE", 0) >= 2;
   if (!on) return;
@@ -24,7 +25,7 @@ void trace_point(const char* what) {
   fprintf(stderr, "[qhip t] %10.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
 }
 void note_sync() {
-  ++sync_counter();
+  g_sync_count.fetch_add(1, std::memory_order_relaxed);
   static const bool trace = env_int("QHIP_SYNC_TRACE", 0) != 0;
   if (trace) {
     void* frames[6];
@@ -64,6 +65,7 @@ void verify_pending_sizes(Ctx* ctx) {
   for (const Ctx::PendingSize& p : pend) {
     const uint32_t* build = p.slot;                    // [build status | probe status | pair total]
     const uint64_t total = p.slot[2 * QS_WORDS];
+    if (p.total_out) *p.total_out = total;
     if (build[QS_MAXCOUNT] > 1) {                      // duplicate build keys after all: remember, run again the careful way
       if (ctx->join_dup_builds.size() > 4096) ctx->join_dup_builds.clear();
       ctx->join_dup_builds.insert(p.dup_hint);

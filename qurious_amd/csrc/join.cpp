@@ -203,7 +203,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (n_regions > 8192 || (((size_t)8 * (1 + W)) << slot_bits) + ((size_t)8 << bword_bits) > 64 * 1024) n_regions = 0;
   }
   const bool region_build = n_regions > 0;
-  if (L->rows_dev && !region_build) {   // only qk_join_scatter reads a device-side row count: wait, shrink, start over
+  // only qk_join_scatter reads a device-side row count: otherwise wait, shrink, start over. A join type with a build-side
+  // tail (Left / Full / LeftSemi / LeftAnti) needs the EXACT build row count as well: the visited bitmap is scanned over
+  // B rows, and the pad rows [count, capacity) of a deferred table are never inserted, hence never visited — they would
+  // surface as unmatched build rows.
+  if (L->rows_dev && (!region_build || (join_type != QHIP_JOIN_INNER && join_type != QHIP_JOIN_RIGHT))) {
     settle_rows(L);
     return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
   }
@@ -298,6 +302,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   uint64_t M = 0;
   const uint32_t* deferred_slot = nullptr;
   std::shared_ptr<DevBuf> rows_blk;
+  std::shared_ptr<uint64_t> rows_final;
   bool probe_timed = false;
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
@@ -342,7 +347,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       if (!ctx->size_slots) QHIP_HIP_CHECK(hipHostMalloc((void**)&ctx->size_slots, (size_t)kSizeSlots * 32 * 4, hipHostMallocDefault));
       if (ctx->pending_sizes.size() >= (size_t)kSizeSlots) fail(QHIP_HIP_ERROR, "too many joins of deferred size in flight (internal error)");
       uint32_t* slot = ctx->size_slots + (size_t)(ctx->size_slot_next++ % kSizeSlots) * 32;
-      ctx->pending_sizes.push_back({slot, size_key, defer_cap, dup_hint});
+      auto total_out = std::make_shared<uint64_t>(~0ull);
+      ctx->pending_sizes.push_back({slot, size_key, defer_cap, dup_hint, total_out});
+      rows_final = total_out;
       M = defer_cap;
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
@@ -506,6 +513,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     out->rows_blk = rows_blk;
     out->rows_dev = rows_blk->as<uint32_t>();
     out->rows_host = deferred_slot + 2 * QS_WORDS;
+    out->rows_final = rows_final;
   }
 
   // ---- output batches: one per non-empty probe batch (hash_join.rs:363-372), then the tail batch

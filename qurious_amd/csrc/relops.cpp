@@ -388,7 +388,7 @@ void qhip::settle_rows(const qhip_table* tc) {
     ctx->pending_sizes.clear();
     throw;
   }
-  const int64_t m = std::min<int64_t>((int64_t)*t->rows_host, t->num_rows);
+  const int64_t m = t->deferred_count();
   t->num_rows = m;
   for (DevColumn& c : t->cols) {
     c.length = m;
@@ -412,6 +412,7 @@ void qhip::settle_rows(const qhip_table* tc) {
   if (t->pending_offsets) { t->pending_offsets->total_rows = m; t->pending_offsets->search_m = (uint64_t)m; }
   t->rows_dev = nullptr;
   t->rows_host = nullptr;
+  t->rows_final.reset();
   t->rows_blk.reset();
 }
 

@@ -403,6 +403,11 @@ class DistributedHashJoinExec(HashJoinExec):
     ``torch.distributed``'s default group, then joined locally. Row order across ranks is not the single-process order
     (the north star asks for row-SET equality); inside a rank the reference's order holds."""
 
+    @property
+    def _exchanges(self) -> bool:
+        """plan.py `_feeding`: a subtree with an active exchange operator never runs joins of deferred size"""
+        return bool(_exchange_world(_dist()))
+
     def execute_device(self) -> DeviceTable:
         world = _exchange_world(_dist())
         if not world:
@@ -466,6 +471,8 @@ class BroadcastHashJoinExec(HashJoinExec):
     probe row or pair (Inner, Right); the others fall back to the repartitioned join. Inside a rank the reference's
     output order holds; across ranks the result is the union."""
 
+    _exchanges = DistributedHashJoinExec._exchanges
+
     def execute_device(self) -> DeviceTable:
         if not _exchange_world(_dist()):
             return HashJoinExec.execute_device(self)
@@ -512,6 +519,8 @@ def merge_aggregate_exprs(aggregate_exprs, n_groups: int):
 class DistributedHashAggregate(PhysicalPlan):
     """HashAggregate whose input rows of one group may live on several ranks: local (partial) aggregation, the partial
     groups repartitioned by the group key, then the merge aggregation. Afterwards every group is on exactly one rank."""
+
+    _exchanges = DistributedHashJoinExec._exchanges
 
     def __init__(self, schema, input: PhysicalPlan, group_exprs, aggregate_exprs):
         from .plan import HashAggregate

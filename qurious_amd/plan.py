@@ -121,11 +121,26 @@ def _feeding(ctx, node: "PhysicalPlan") -> DeviceTable:
     """Execute `node` as the input of an operator that reads a device-side row count (HashAggregate's input, a hash
     join's build side): a hash join at the top of `node` may then skip the wait for its output size
     (qhip.h: qhip_ctx_allow_deferred_sizes). The consumer runs right after, inside `_retrying`."""
+    if _subtree_exchanges(node):
+        # a join of deferred size can answer QHIP_RETRY on ONE rank only; re-executing `node` would then repeat the
+        # collectives of the exchange operator inside it alone, and the job would hang: such a subtree never defers
+        with ctx.no_deferred_sizes():
+            return node.execute_device()
     ctx.allow_deferred_sizes(+1)
     try:
         return node.execute_device()
     finally:
         ctx.allow_deferred_sizes(-1)
+
+
+def _subtree_exchanges(node) -> bool:
+    """True when `node` or a descendant is a multi-rank operator (exchange.py marks its classes `_exchanges = True`).
+    Walks the operator attributes rather than `children()`: Sort / Limit / NoGroupingAggregate report their
+    input's children (or none) there, like the reference's (sort.rs:83-85, limit.rs:59-61, no_grouping.rs:63-65)."""
+    if getattr(node, "_exchanges", False):
+        return True
+    return any(_subtree_exchanges(child) for attr in ("input", "left", "right", "partial")
+               for child in [getattr(node, attr, None)] if isinstance(child, PhysicalPlan))
 
 
 def _retrying(ctx, run):

@@ -222,3 +222,60 @@ def test_retry_protocol_of_the_host_mirror():
     # the status code maps to the exception the mirrors catch
     with pytest.raises(_ffi.RetryInput):
         _ffi._raise(_ffi.QHIP_RETRY, "x")
+
+
+def test_no_deferred_join_sizes_above_an_exchange_operator():
+    """A local operator ABOVE a multi-rank join must not run joins of deferred size: QHIP_RETRY can fire on one rank only,
+    whose re-execution of the input would repeat the exchange's collectives alone (round-2 advisor finding). `_feeding`
+    therefore runs a subtree that holds an active exchange operator under `no_deferred_sizes`, at any depth, and also
+    through nodes whose `children()` hide their input like the reference's (Sort / Limit)."""
+    import contextlib
+    from qurious_amd import plan as P
+
+    class Ctx:
+        def __init__(self):
+            self.depth, self.suppressed = 0, 0
+
+        def allow_deferred_sizes(self, d):
+            self.depth = 0 if d == 0 else self.depth + d
+
+        @contextlib.contextmanager
+        def no_deferred_sizes(self):
+            saved, self.depth = self.depth, 0
+            self.suppressed += 1
+            try:
+                yield
+            finally:
+                self.depth = saved
+
+    ctx, seen = Ctx(), []
+
+    class Leaf(P.PhysicalPlan):
+        def __init__(self, exchanges):
+            self._exchanges = exchanges
+
+        def execute_device(self):
+            seen.append(ctx.depth)
+            return "t"
+
+    class Through(P.PhysicalPlan):          # e.g. a local HashJoinExec / Sort between the consumer and the exchange
+        def __init__(self, left, right=None):
+            self.left, self.right = left, right
+
+        def children(self):
+            return None                      # (Sort::children returns its input's children: sort.rs:83-85)
+
+        def execute_device(self):
+            return self.left.execute_device()
+
+    assert not P._subtree_exchanges(Through(Leaf(False), Leaf(False)))
+    assert P._subtree_exchanges(Through(Through(Leaf(False)), Leaf(True)))
+    P._feeding(ctx, Through(Leaf(False)))
+    assert seen == [1] and ctx.suppressed == 0 and ctx.depth == 0          # a purely local subtree may defer
+    ctx.depth = 1                                                          # (an outer consumer already allowed deferral)
+    P._feeding(ctx, Through(Through(Leaf(True))))
+    assert seen == [1, 0] and ctx.suppressed == 1 and ctx.depth == 1       # ... one with an exchange inside never does
+    # the product's multi-rank operators carry the mark exactly while an exchange would really run
+    from qurious_amd import exchange as X
+    for cls in (X.DistributedHashJoinExec, X.BroadcastHashJoinExec, X.DistributedHashAggregate):
+        assert isinstance(cls.__dict__.get("_exchanges", None) or getattr(cls, "_exchanges"), property)
