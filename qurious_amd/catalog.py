@@ -78,6 +78,19 @@ def catalog_sources():
         os.environ.pop("QHIP_AGG_R", None)
         if saved is not None:
             os.environ["QHIP_AGG_R"] = saved
+    # the dense (direct-address) join layout: what Q3's joins run since round 3 (integer keys of a small value range,
+    # csrc/join.cpp): build + probe kernels of both joins, join 2's build also reading its row count on the device
+    os.environ["QHIP_PLAN_DENSE"] = "1"
+    try:
+        out.append(("q3 customer dense build", planning.scatter_source(CUSTOMER_SCHEMA, [j1.on[0][0]], j1.left.filter)))
+        out.append(("q3 join-1 output dense build", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        out.append(("q3 orders dense probe", planning.probe_source(ORDERS_SCHEMA, [j1.on[0][1]], j1.right.filter)))
+        out.append(("q3 lineitem dense probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))
+        os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
+        out.append(("q3 join-1 output dense build, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+    finally:
+        os.environ.pop("QHIP_PLAN_DENSE", None)
+        os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
     top = queries.q3_top10(*tabs)
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)

@@ -906,7 +906,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
-  const bool raw = kernel == KEYS_KERNEL_PROBE;
+  const bool raw = kernel == KEYS_KERNEL_PROBE || kernel == KEYS_KERNEL_DENSE_PROBE;
   if (raw) {
     // the probe kernel is software-pipelined over its tiles: a row's column loads are issued one stage (load(), branch-free,
     // tile-relative addressing) before its filter / key words are computed from them (keys())
@@ -928,7 +928,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   if (raw) {
-    out.probe_r = std::max(1, std::min(8, env_int("QHIP_PROBE_R", 4)));
+    out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", 4) : env_int("QHIP_PROBE_R", 4)));
     s << "  static constexpr int PROBE_R = " << out.probe_r << ";\n";
     s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
     s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
@@ -943,13 +943,21 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     // SIMD (<= 96 VGPRs): the three tiles in flight need ~90; at 98 the kernel fell to four waves and ran 10-20 % slower
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe(KArgs a, ProbeLaunch L) { qh_join_probe_body<P, true>(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe_onetable(KArgs a, ProbeLaunch L) { qh_join_probe_body<P, false>(a, L); }\n";
+  } else if (kernel == KEYS_KERNEL_DENSE_PROBE) {
+    // the dense stages keep ~half the state of the hashed ones (no key words / filter masks / slot images across stages)
+    const int waves = env_int("QHIP_DENSE_PROBE_WAVES", 8);
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe_dense(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, false>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, true>(a, L); }\n";
+  } else if (kernel == KEYS_KERNEL_DENSE_BUILD) {
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_dense_build(KArgs a, DenseBuildLaunch L) { qh_join_dense_build_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_SCATTER)
     s << "extern \"C\" __global__ __launch_bounds__(QH_SCATTER_BLOCK) void qk_join_scatter(KArgs a, ScatterLaunch L) { qh_join_scatter_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   else
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_eval_keys(KArgs a, u64* keys, u64* keyvalid, u32* status) { "
          "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
   out.source = s.str();
-  out.kernel_name = kernel == KEYS_KERNEL_PROBE ? "qk_join_probe" : kernel == KEYS_KERNEL_SCATTER ? "qk_join_scatter" : "qk_eval_keys";
+  out.kernel_name = kernel == KEYS_KERNEL_PROBE ? "qk_join_probe" : kernel == KEYS_KERNEL_SCATTER ? "qk_join_scatter" :
+                    kernel == KEYS_KERNEL_DENSE_PROBE ? "qk_join_probe_dense" : kernel == KEYS_KERNEL_DENSE_BUILD ? "qk_join_dense_build" : "qk_eval_keys";
   out.bind = g.bind;
 }
 

@@ -120,9 +120,11 @@ struct KeysPlan {
 };
 // which kernel wraps the generated key policy: qk_eval_keys (key words -> arrays), qk_join_probe (fused filter + key + lookup,
 // qh_join_probe_body) or qk_join_scatter (build rows -> region entries of the LDS-staged join build, qh_join_scatter_body)
-enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2 };
+// ... or the two kernels of the dense (direct-address) join layout: qk_join_dense_build (qh_join_dense_build_body) and
+// qk_join_probe_dense / qk_join_probe_dense_lds (qh_join_probe_dense_body)
+enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2, KEYS_KERNEL_DENSE_BUILD = 3, KEYS_KERNEL_DENSE_PROBE = 4 };
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
-               int kernel = KEYS_KERNEL_EVAL, bool dev_rows = false);   // (dev_rows: KEYS_KERNEL_SCATTER only)
+               int kernel = KEYS_KERNEL_EVAL, bool dev_rows = false);   // (dev_rows: the build kernels only)
 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };

@@ -92,6 +92,7 @@ inline void copy_sync(hipStream_t s, void* dst, const void* src, size_t n, hipMe
   QHIP_HIP_CHECK(sync_stream(s));
 }
 
+struct ColRange { bool known = false; int64_t min = 0, max = 0; };
 // One column of a device table, concatenated over all batches, Arrow layout.
 struct DevColumn {
   DType type;
@@ -106,6 +107,13 @@ struct DevColumn {
   // bits), computed on first use as an aggregate argument of a big input: lets the generated code multiply and accumulate
   // in 32 / 64 bits where the data allows (an upper bound stays one under gathering, like utf8_max_len)
   mutable uint64_t value_maxabs = 0;
+  // Value range [min, max] of an integer-like column, computed on first use as a hash join's build key (one reduction +
+  // one read-back; decides whether the join addresses its table by the key itself: join.cpp, dense layout). The object is
+  // SHARED by every copy of the column (a base table's column and the `src` of the deferred gathers made from it), so the
+  // statistic is computed once per table, not once per query. A gathered column INHERITS its source's object
+  // (range_inherited: a superset's bounds hold for the subset; the subset never writes its own, narrower, bounds into it).
+  mutable std::shared_ptr<struct ColRange> range = std::make_shared<struct ColRange>();
+  mutable bool range_inherited = false;
   // A join / filter output column may be DEFERRED: (source column, row index vector), gathered only when somebody reads
   // it (an expression that references it, an export, an exchange). The reference gathers every column of every join
   // output (utils/batch.rs:18-61) although most are never looked at downstream (Q3: c_mktsegment, o_custkey, ...).

@@ -922,6 +922,10 @@ struct ProbeLaunch {
   u32 n_regions;           // region layout (0 = legacy): regions of 2^slot_bits slots, each with a filter slice of
   u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; (dbg: unused)
   u32 tiles_per_wave, pad_;          // wavefront w of the grid owns tiles [w * tiles_per_wave, (w + 1) * tiles_per_wave)
+  // dense (direct-address) layout, qh_join_probe_dense_body: `bloom` = an EXACT bitmap over the build keys' value range
+  // [dense_min, dense_min + dense_n) as 32-bit words, `table` = u32 row_of[key - dense_min] (defined only where the bit is set)
+  u64 dense_min;
+  u32 dense_n, dense_words;          // keys in the range (<= 2^30); 32-bit words of the bitmap
 };
 
 // The build's hash filter is a blocked Bloom filter: FOUR bits per key inside ONE 64-bit word (two in each half), sized at
@@ -1126,6 +1130,184 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
   }
 #undef QH_PROBE_TRIP
   if (c.lane == 0) { L.tile_total[wave] = c.total; L.tile_nent[wave] = c.nent; }
+  qh_report(L.status, err);
+}
+
+// ------------------------------------------------------------------ hash join over a DENSE integer key: direct addressing
+// When the join key is ONE integer column whose values on the build side span a small range [min, max] (TPC-H's keys:
+// c_custkey 1 .. 1.5 M, o_orderkey < 60 M at SF10 — known from the column's cached value range), hashing is pointless:
+// the table is an exact bitmap over the range (one bit per possible key: 188 KB / 7.5 MB — L2 / Infinity-Cache resident,
+// and read in key order by a probe side that is stored in foreign-key order) plus row_of[key - min] (u32), which is read
+// only where the bit is set. A probing row costs a subtract, a range test, a shift and a bit test instead of a 64-bit
+// multiply, a 4-bit blocked-filter mask and region arithmetic (~26 VALU); there are no false positives, no probe
+// sequences, and a hit costs the 32-byte sector of row_of it needs, not a 128-byte line of a half-empty slot table.
+// JoinHashMap's semantics (hash_join.rs:39-108, 177-216) are unchanged: unique build keys are assumed and checked (a
+// second row with an equal key raises QS_MAXCOUNT and the join runs again with the hash / CSR layout, which yields the
+// reference's ascending chains); NULL keys and rows rejected by a fused scan filter have no valid key and are never
+// inserted or probed.
+struct DenseBuildLaunch {
+  u32* bits;        // zero-filled bitmap, 32-bit words
+  u32* row_of;      // uninitialised; row_of[key - kmin] = build row for every inserted key
+  u32* status;
+  u64 kmin;
+  u32 n;            // keys in the range
+  u32 pad_;
+};
+template <class P, bool DEVROWS = false>
+__device__ __forceinline__ void qh_join_dense_build_body(const KArgs& a, const DenseBuildLaunch& L) {
+  constexpr int R = 4;
+  const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
+  const i64 tile = (i64)QH_BLOCK * R;
+  u32 err = 0, dup = 0, out_of_range = 0;
+  for (i64 tb = (i64)blockIdx.x * tile; tb < nrows; tb += (i64)gridDim.x * tile) {
+    u64 k[R][P::W];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const i64 i = tb + (i64)r * QH_BLOCK + threadIdx.x;
+      const bool inb = i < nrows;
+      u32 e = 0;
+      ok[r] = P::keys(a, inb ? i : nrows - 1, k[r], e) && inb;
+      err |= inb ? e : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u64 idx = k[r][0] - L.kmin;
+      if (ok[r]) {
+        if (idx < (u64)L.n) {
+          const u32 bit = 1u << ((u32)idx & 31u);
+          const u32 old = __hip_atomic_fetch_or(&L.bits[(u32)idx >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dup |= (old & bit) ? 1u : 0u;
+          L.row_of[(u32)idx] = (u32)(tb + (i64)r * QH_BLOCK + threadIdx.x);
+        } else out_of_range = 1u;   // (cannot happen: the range comes from the column's own values; reported, never ignored)
+      }
+    }
+  }
+  qh_report(L.status, err | (out_of_range << QS_OVERFLOW));
+  // duplicate build keys: status[QS_MAXCOUNT] = 2 (one atomic per wavefront that saw one, none when it is already up)
+  if (__builtin_amdgcn_readfirstlane((int)(qh_ballot(dup != 0) != 0)) && qh_lane() == 0 &&
+      __hip_atomic_load(&L.status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
+    atomicMax(&L.status[QS_MAXCOUNT], 2u);
+}
+
+// Probe pass 1 over the dense layout: the same software pipeline over the wavefront's tiles as qh_join_probe_body (three
+// register sets rotating through the stages, every stage unconditional) with shorter stages:
+//   stage 1  issue the column loads of tile t + 3
+//   stage 2  fused scan filter + key of tile t + 2, idx = key - min, range test, issue the bitmap-word loads
+//   stage 3  bit test of tile t + 1, issue the row_of loads of the rows whose bit is set
+//   stage 4  the entries (build row, probe row) and counts of tile t
+// LDSBITS: every workgroup first copies the whole bitmap into LDS (ranges of <= 2^20 keys = 128 KB; 1 024-thread
+// workgroups so that one workgroup per CU still runs 16 wavefronts) and stage 2 reads it with DS loads instead of L2.
+template <class P>
+struct QhDenseTile {
+  typename P::Raw raw[P::PROBE_R];   // stage 1 -> 2
+  u32 idx[P::PROBE_R];               // stage 2 -> 3
+  u32 bw[P::PROBE_R];                // stage 2 -> 3: the key's bitmap word
+  u32 row[P::PROBE_R];               // stage 3 -> 4: row_of[idx]
+  bool ok[P::PROBE_R];
+  i64 tile;
+  bool live;
+};
+template <class P>
+__device__ __forceinline__ void qh_dense_stage1(const KArgs& a, QhDenseTile<P>& x, const QhProbeCtx& c, i64 j) {
+  constexpr int R = P::PROBE_R, TILE = 64 * R;
+  x.live = j < c.mine;
+  x.tile = x.live ? c.first + j : 0;
+  const i64 tb = x.tile * TILE;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32 o = (u32)r * 64 + (u32)c.lane;
+    P::load(a, tb, tb + (i64)o < a.nrows ? o : (u32)(a.nrows - 1 - tb), x.raw[r]);
+  }
+}
+template <class P, bool LDSBITS>
+__device__ __forceinline__ void qh_dense_stage2(const KArgs& a, const ProbeLaunch& L, QhDenseTile<P>& x, const QhProbeCtx& c, u32& err) {
+  constexpr int R = P::PROBE_R, TILE = 64 * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool inb = x.tile * TILE + r * 64 + c.lane < a.nrows;
+    u32 e = 0;
+    u64 k[P::W];
+    x.ok[r] = P::keys(a, x.raw[r], k, e) && inb;
+    err |= (inb && x.live) ? e : 0u;
+    const u64 idx = k[0] - L.dense_min;
+    x.ok[r] = x.ok[r] && idx < (u64)L.dense_n;
+    x.idx[r] = x.ok[r] ? (u32)idx : 0u;
+    // (32-bit byte offset from the scalar base: the bitmap holds <= 2^25 words)
+    if (LDSBITS) x.bw[r] = ((const u32*)qh_dyn_lds)[x.idx[r] >> 5];
+    else x.bw[r] = *(const u32*)((const char*)L.bloom + (size_t)((x.idx[r] >> 5) << 2));
+  }
+}
+template <class P>
+__device__ __forceinline__ void qh_dense_stage3(const ProbeLaunch& L, QhDenseTile<P>& x, const QhProbeCtx& c) {
+  constexpr int R = P::PROBE_R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    x.ok[r] = x.ok[r] && ((x.bw[r] >> (x.idx[r] & 31u)) & 1u);
+    x.row[r] = *(const u32*)((const char*)L.table + (size_t)((x.ok[r] ? x.idx[r] : 0u) << 2));   // (idx < 2^30)
+  }
+}
+template <class P>
+__device__ __forceinline__ void qh_dense_stage4(const ProbeLaunch& L, QhDenseTile<P>& x, QhProbeCtx& c) {
+  constexpr int R = P::PROBE_R, TILE = 64 * R;
+  if (!x.live) return;   // wave-uniform: a drain trip writes nothing
+  const int lane = c.lane;
+  u32 nent = c.nent;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u64 m = qh_ballot(x.ok[r]);
+    if (x.ok[r]) {
+      const size_t pos = (size_t)c.first * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+      L.ent_slot[pos] = x.row[r];
+      L.ent_row[pos] = (u32)(x.tile * TILE + r * 64 + lane);
+      if (L.visited) atomicOr(&L.visited[x.row[r] >> 5], 1u << (x.row[r] & 31));
+    }
+    nent += (u32)__builtin_popcountll(m);
+  }
+  c.nent = nent;
+}
+template <class P, bool LDSBITS>
+__device__ __forceinline__ void qh_join_probe_dense_body(const KArgs& a, const ProbeLaunch& L) {
+  constexpr int R = P::PROBE_R, TILE = 64 * R;
+  const int NW = (int)(blockDim.x >> 6);
+  if (LDSBITS) {
+    u32* lbits = (u32*)qh_dyn_lds;
+    for (u32 w = threadIdx.x; w < L.dense_words; w += blockDim.x) lbits[w] = ((const u32*)L.bloom)[w];
+    __syncthreads();
+  }
+  const i64 ntiles = (a.nrows + TILE - 1) / TILE;
+  QhProbeCtx c;
+  c.regions = false; c.smask = 0;
+  c.lane = qh_lane();
+  const i64 wave = (i64)blockIdx.x * NW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  c.first = wave * (i64)L.tiles_per_wave;
+  c.nent = 0; c.total = 0;
+  if (c.first >= ntiles) {
+    if (c.lane == 0) { L.tile_total[wave] = 0; L.tile_nent[wave] = 0; }
+    return;
+  }
+  c.mine = ntiles - c.first < (i64)L.tiles_per_wave ? ntiles - c.first : (i64)L.tiles_per_wave;
+  u32 err = 0;
+  QhDenseTile<P> A, B, C;
+  qh_dense_stage1<P>(a, A, c, 0);
+  qh_dense_stage2<P, LDSBITS>(a, L, A, c, err);
+  qh_dense_stage1<P>(a, B, c, 1);
+  qh_dense_stage3<P>(L, A, c);
+  qh_dense_stage2<P, LDSBITS>(a, L, B, c, err);
+  qh_dense_stage1<P>(a, C, c, 2);
+#define QH_DENSE_TRIP(X4, X3, X2, J)             \
+  qh_dense_stage4<P>(L, X4, c);                  \
+  qh_dense_stage3<P>(L, X3, c);                  \
+  qh_dense_stage2<P, LDSBITS>(a, L, X2, c, err); \
+  qh_dense_stage1<P>(a, X4, c, (J));
+  for (i64 j = 3; j < c.mine + 3; j += 3) {
+    QH_DENSE_TRIP(A, B, C, j)
+    QH_DENSE_TRIP(B, C, A, j + 1)
+    QH_DENSE_TRIP(C, A, B, j + 2)
+  }
+#undef QH_DENSE_TRIP
+  // unique build keys: every matching probe row is exactly one pair
+  if (c.lane == 0) { L.tile_total[wave] = c.nent; L.tile_nent[wave] = c.nent; }
   qh_report(L.status, err);
 }
 

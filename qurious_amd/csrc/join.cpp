@@ -68,6 +68,24 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // (measured on Q3's second join: reading the build key through join 1's index vector inside qk_join_scatter costs 17 us
   // more than the separate gather it saves — 92 vs 75 us — so the build side gathers; QHIP_LATE_GATHER_BUILD=1 switches it on)
   const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", 0) != 0;
+  // ---- dense (direct-address) layout? ONE integer key column whose build-side values span a small range [kmin, kmax]
+  // (DevColumn::range, found once per base table: looked at BEFORE the key column is gathered, while a deferred gather
+  // still names its source): the table is then an exact bitmap over the range + row_of[key - kmin]
+  // (qh_join_dense_build_body / qh_join_probe_dense_body). QHIP_JOIN_DENSE: 0 never, 1 when the range is within 256x the
+  // build rows (default), 2 whenever the key qualifies (tests).
+  const int dense_mode = env_int("QHIP_JOIN_DENSE", 1);
+  bool dense_candidate = false;
+  int64_t kmin = 0, kmax = 0;
+  uint64_t dense_n = 0;
+  if (dense_mode != 0 && n_on == 1 && B > 0 && on_l[0] >= 0 && on_l[0] < nlex && lex[on_l[0]].kind == QHIP_EXPR_COLUMN && lex[on_l[0]].column >= 0 &&
+      lex[on_l[0]].column < (int)L->cols.size()) {
+    const DevColumn& kc = L->cols[(size_t)lex[on_l[0]].column];
+    const int id = kc.type.id;
+    if ((id == QHIP_INT64 || id == QHIP_INT32 || id == QHIP_UINT8 || id == QHIP_DATE32 || id == QHIP_DATE64) && key_range_of(ctx, kc, kmin, kmax)) {
+      const uint64_t span = (uint64_t)kmax - (uint64_t)kmin;   // (kmax >= kmin; the difference fits 64 unsigned bits)
+      if (span < (1ULL << 30) && (dense_mode == 2 || span < 256 * B + 65536)) { dense_candidate = true; dense_n = span + 1; }
+    }
+  }
   resolve_referenced(ctx, L, lex, nlex, late_build);
   resolve_referenced(ctx, R, rex, nrex);
   std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
@@ -109,7 +127,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   for (int k = 0; k < n_on; ++k) dup_hint = dup_hint * 1099511628211ULL + (uint64_t)on_l[k];
   const bool speculate = env_int("QHIP_JOIN_FORCE_CSR", 0) == 0 && env_int("QHIP_JOIN_NO_SPECULATION", 0) == 0 && !ctx->join_dup_builds.count(dup_hint);
   const int region_mode = env_int("QHIP_JOIN_REGION", 1);   // LDS-staged region build: 0 never, 1 when it pays, 2 always (tests)
-  const bool want_regions = speculate && B > 0 && (region_mode == 2 || (region_mode == 1 && B >= 2048));
+  const bool dense = dense_candidate && speculate;   // (unique build keys assumed and checked, like the region build)
+  const bool want_regions = !dense && speculate && B > 0 && (region_mode == 2 || (region_mode == 1 && B >= 2048));
   // Deferred sizing (qhip.h: qhip_ctx_allow_deferred_sizes): this join as a whole is identified by both sides' expressions,
   // its type and the probe rows (the build rows too unless they are themselves a capacity)
   uint64_t size_key = (L->rows_dev ? 0 : B) * 0x9E3779B97F4A7C15ULL + P * 0xD6E8FEB86659FD93ULL + ((uint64_t)(join_type + 1) << 56) +
@@ -150,10 +169,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     put_exprs(rex, nrex);
     put(on_l, sizeof(int32_t) * (size_t)n_on);
     put(on_r, sizeof(int32_t) * (size_t)n_on);
-    const int v[4] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0};
+    const int v[5] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0, dense ? 1 : 0};
     put(v, sizeof v);
   }
-  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod, rmod_onetable; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
+  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod, rmod_onetable, rmod_lds; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
   std::shared_ptr<JoinPlan> jp;
   {
     auto cached = ctx->plan_cache.find(pkey);
@@ -163,8 +182,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       ExprSet les, res;
       les.build(lex, nlex, lcols);
       res.build(rex, nrex, rcols);
-      plan_keys(les, lcols, on_l, n_on, jp->lkp, lpred, want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL, want_regions && L->rows_dev);
-      plan_keys(res, rcols, on_r, n_on, jp->rkp, rpred, KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
+      plan_keys(les, lcols, on_l, n_on, jp->lkp, lpred, dense ? KEYS_KERNEL_DENSE_BUILD : want_regions ? KEYS_KERNEL_SCATTER : KEYS_KERNEL_EVAL,
+                (dense || want_regions) && L->rows_dev);
+      plan_keys(res, rcols, on_r, n_on, jp->rkp, rpred, dense ? KEYS_KERNEL_DENSE_PROBE : KEYS_KERNEL_PROBE);   // the probe side's keys are evaluated inside the probe kernel
       for (int k = 0; k < n_on; ++k)
         if (jp->lkp.keys[(size_t)k].type != jp->rkp.keys[(size_t)k].type)   // arrow's eq (hash_join.rs:203) needs identical types
           fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid comparison operation: " + dtype_name(jp->lkp.keys[(size_t)k].type) +
@@ -207,22 +227,40 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // tail (Left / Full / LeftSemi / LeftAnti) needs the EXACT build row count as well: the visited bitmap is scanned over
   // B rows, and the pad rows [count, capacity) of a deferred table are never inserted, hence never visited — they would
   // surface as unmatched build rows.
-  if (L->rows_dev && (!region_build || (join_type != QHIP_JOIN_INNER && join_type != QHIP_JOIN_RIGHT))) {
+  if (L->rows_dev && ((!region_build && !dense) || (join_type != QHIP_JOIN_INNER && join_type != QHIP_JOIN_RIGHT))) {
     settle_rows(L);
     return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
   }
-  const uint32_t nslots = region_build ? n_regions << slot_bits : std::max<uint32_t>(16, pow2_ceil32(B * 2));
+  const uint32_t dense_words = dense ? (uint32_t)((dense_n + 31) / 32) : 0;
+  const uint32_t nslots = dense ? 0 : region_build ? n_regions << slot_bits : std::max<uint32_t>(16, pow2_ceil32(B * 2));
   // hash filter: 64-bit words, 8 bits per slot (region layout: 2^bword_bits words per region)
-  const uint32_t filter_words = region_build ? n_regions << bword_bits : std::max<uint32_t>(16, nslots / 8);
+  const uint32_t filter_words = dense ? 0 : region_build ? n_regions << bword_bits : std::max<uint32_t>(16, nslots / 8);
   // one arena: [table | count | filter] (legacy: zero-filled; region layout: every byte of table and filter is stored by
   // k_join_region_build, the counts are not used)
-  const size_t table_bytes = (size_t)nslots * (1 + W) * 8, count_bytes = region_build ? 0 : (((size_t)nslots + 2) * 4 + 7) / 8 * 8, bloom_bytes = (size_t)filter_words * 8;
+  // (dense layout: table = u32 row_of[dense_n], never initialised — read only where the bitmap says a key is there; "filter"
+  // = the exact bitmap, the only part that is cleared)
+  const size_t table_bytes = dense ? ((size_t)dense_n * 4 + 127) / 128 * 128 : (size_t)nslots * (1 + W) * 8;
+  const size_t count_bytes = (region_build || dense) ? 0 : (((size_t)nslots + 2) * 4 + 7) / 8 * 8;
+  const size_t bloom_bytes = dense ? ((size_t)dense_words * 4 + 127) / 128 * 128 : (size_t)filter_words * 8;
   DevBuf arena(table_bytes + count_bytes + bloom_bytes);
   uint64_t* table = arena.as<uint64_t>();
   uint32_t* count = (uint32_t*)(arena.as<uint8_t>() + table_bytes);
   uint64_t* bloom = (uint64_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
   DevBuf start, row_slot, sorted_rows;
-  if (region_build) {
+  if (dense) {
+    if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);
+    HKArgs ka;
+    fill_kargs(ctx, L, lkp.bind, ka, jp->lstr);
+    QHIP_HIP_CHECK(hipMemsetAsync(bloom, 0, bloom_bytes, s));
+    HDenseBuildLaunch dl;
+    dl.bits = (uint32_t*)bloom; dl.row_of = (uint32_t*)table; dl.status = dstat;
+    dl.kmin = (uint64_t)kmin; dl.n = (uint32_t)dense_n;
+    void* args[] = {&ka, &dl};
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B + 1023) / 1024, (uint64_t)ctx->num_cus * 8));
+    trace_point("join: first launch");
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(jp->lmod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    trace_point("join: first launch done");
+  } else if (region_build) {
     if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);
     const std::shared_ptr<Module>& mod = jp->lmod;
     HKArgs ka;
@@ -307,8 +345,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
   if (P > 0) {
-    std::shared_ptr<Module>& rmod = region_build ? jp->rmod : jp->rmod_onetable;   // (the table layout is a template parameter of the kernel)
-    if (!rmod) rmod = get_module(ctx, rkp.source, region_build ? rkp.kernel_name : "qk_join_probe_onetable");
+    // dense layout, bitmap staged in LDS (QHIP_JOIN_DENSE_LDS=1: the measured alternative to reading it through L2): ranges
+    // of up to 2^20 keys; 1 024-thread workgroups, one per CU
+    const bool dense_lds = dense && env_int("QHIP_JOIN_DENSE_LDS", 0) != 0 && (size_t)dense_words * 4 <= 128 * 1024;
+    std::shared_ptr<Module>& rmod = dense_lds ? jp->rmod_lds : (region_build || dense) ? jp->rmod : jp->rmod_onetable;   // (the table layout is a template parameter of the kernel)
+    if (!rmod) rmod = get_module(ctx, rkp.source, dense_lds ? "qk_join_probe_dense_lds" : (region_build || dense) ? rkp.kernel_name : "qk_join_probe_onetable");
     const std::shared_ptr<Module>& mod = rmod;
     HKArgs ka;
     fill_kargs(ctx, R, rkp.bind, ka, jp->rstr);
@@ -322,8 +363,9 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const uint64_t tpw_max = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
     const uint64_t waves_wanted = std::max<uint64_t>(std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cus * 16), (ntiles + tpw_max - 1) / tpw_max);
     const uint64_t tiles_per_wave = (ntiles + waves_wanted - 1) / waves_wanted;
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, ((ntiles + tiles_per_wave - 1) / tiles_per_wave + 3) / 4);
-    const uint64_t nchunks = (uint64_t)grid * 4;
+    const unsigned waves_per_wg = dense_lds ? 16 : 4;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, ((ntiles + tiles_per_wave - 1) / tiles_per_wave + waves_per_wg - 1) / waves_per_wg);
+    const uint64_t nchunks = (uint64_t)grid * waves_per_wg;
     DevBuf tile_tot((nchunks + 1) * 4), tile_nent((nchunks + 1) * 4);
     HProbeLaunch pl;
     pl.table = table; pl.bloom = bloom; pl.count = count; pl.start = start_ptr; pl.rows = rows_ptr;
@@ -336,9 +378,13 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.nslots = nslots; pl.bloom_mask = filter_words - 1;
     pl.n_regions = n_regions; pl.slot_bits = slot_bits; pl.bword_bits = bword_bits;
     pl.tiles_per_wave = (uint32_t)tiles_per_wave;
+    if (dense) {
+      pl.count = nullptr;
+      pl.dense_min = (uint64_t)kmin; pl.dense_n = (uint32_t)dense_n; pl.dense_words = dense_words;
+    }
     void* args[] = {&ka, &pl};
     time_mark(ctx, 2);
-    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, waves_per_wg * 64, 1, 1, dense_lds ? dense_words * 4 : 0, s, args, nullptr));
     time_mark(ctx, 3);
     probe_timed = true;
     if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), nchunks, dstat + 2 * QS_WORDS, s);
@@ -548,8 +594,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   ctx->stats.rows_in = (int64_t)P;
   ctx->stats.rows_out = (int64_t)total_rows;
   ctx->stats.groups = (int64_t)M;
-  ctx->stats.table_capacity = nslots;
-  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "qk_join_probe");
+  ctx->stats.table_capacity = dense ? (int64_t)dense_n : nslots;
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, dense ? "qk_join_probe_dense" : "qk_join_probe");
   // bytes of column data the probe kernel / the build's key evaluation read per row (roofline figures)
   auto bytes_per_row = [&](const qhip_table* t, const KernelBindings& b) {
     double sum = 0;

@@ -359,6 +359,26 @@ __global__ __launch_bounds__(QH_BLOCK) void k_value_maxabs(const u64* v, u64 n, 
   }
 }
 
+// Value range of an integer-like column (sign-extended to 64 bits): out[0] = max of (v ^ sign bit), out[1] = max of
+// ~(v ^ sign bit), i.e. the order-preserving unsigned images of max and min, both gathered with atomic max from zero-filled
+// words (one atomic pair per wavefront, none when it would change nothing). NULL slots take part with whatever their value
+// slot holds: the range may only be wider for it. Decides whether a hash join can address its table by the key itself.
+template <class T>
+__global__ __launch_bounds__(QH_BLOCK) void k_value_range(const T* v, u64 n, u64* out) {
+  u64 hi = 0, lo = 0;
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
+    const u64 img = (u64)(i64)v[i] ^ 0x8000000000000000ULL;
+    hi = img > hi ? img : hi;
+    lo = ~img > lo ? ~img : lo;
+  }
+  hi = qh_wave_max_u64(hi);
+  lo = qh_wave_max_u64(lo);
+  if (qh_lane() == 0) {
+    if (hi > __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)__hip_atomic_fetch_max(&out[0], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lo > __hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)__hip_atomic_fetch_max(&out[1], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ================================================================ hash join
 // JoinHashMap (physical/plan/join/hash_join.rs:39-107) keeps `hash -> last row + 1` and a `next` chain, built in
 // reverse so that chains ascend. Here: an open-addressing table keyed by the REAL key words (so there is no
@@ -919,6 +939,19 @@ void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* ou
   const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);
   if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
   else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
+}
+void launch_value_range(const void* values, uint64_t n, int width, bool is_signed, uint64_t* out, hipStream_t s) {
+  if (!n) return;
+  const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);
+  switch (width * 2 + (is_signed ? 1 : 0)) {
+    case 2: hipLaunchKernelGGL(k_value_range<unsigned char>, g, b, 0, s, (const unsigned char*)values, (u64)n, (u64*)out); break;
+    case 3: hipLaunchKernelGGL(k_value_range<signed char>, g, b, 0, s, (const signed char*)values, (u64)n, (u64*)out); break;
+    case 4: hipLaunchKernelGGL(k_value_range<unsigned short>, g, b, 0, s, (const unsigned short*)values, (u64)n, (u64*)out); break;
+    case 5: hipLaunchKernelGGL(k_value_range<short>, g, b, 0, s, (const short*)values, (u64)n, (u64*)out); break;
+    case 8: hipLaunchKernelGGL(k_value_range<unsigned int>, g, b, 0, s, (const unsigned int*)values, (u64)n, (u64*)out); break;
+    case 9: hipLaunchKernelGGL(k_value_range<int>, g, b, 0, s, (const int*)values, (u64)n, (u64*)out); break;
+    default: hipLaunchKernelGGL(k_value_range<i64>, g, b, 0, s, (const i64*)values, (u64)n, (u64*)out); break;   // (UInt64 keys are not accepted by create_hashes)
+  }
 }
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s) { hipLaunchKernelGGL(k_store_u32, dim3(1), dim3(1), 0, s, (u32*)p, v); }
 void launch_iota_u32(uint32_t* out, uint64_t n, hipStream_t s, uint32_t first) {

@@ -91,7 +91,7 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
     auto in = make_input(col_types, col_has_nulls, n_cols);
     ExprSet es; es.build(exprs, n_exprs, in);
     KeysPlan p;
-    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_PROBE);
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, env_int("QHIP_PLAN_DENSE", 0) ? KEYS_KERNEL_DENSE_PROBE : KEYS_KERNEL_PROBE);   // (QHIP_PLAN_DENSE=1: the dense join layout's kernels)
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }
@@ -103,7 +103,7 @@ int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has
     auto in = make_input(col_types, col_has_nulls, n_cols);
     ExprSet es; es.build(exprs, n_exprs, in);
     KeysPlan p;
-    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_SCATTER, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0);
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, env_int("QHIP_PLAN_DENSE", 0) ? KEYS_KERNEL_DENSE_BUILD : KEYS_KERNEL_SCATTER, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0);
     return give(p.source, buf, buflen, needed);
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }

@@ -68,6 +68,7 @@ bool compact_column(Ctx* ctx, const DevColumn& col_in, const DevBuf& mask, const
   out.length = (int64_t)m;
   out.utf8_max_len = col.utf8_max_len;
   out.value_maxabs = col.value_maxabs;
+  out.range = col.range; out.range_inherited = true;   // (a subset's values lie inside its source's range)
   if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return true; }
   const int w = dtype_width(col.type);
   if (w > 0) {
@@ -143,6 +144,46 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   }
 }
 
+// Value range of an integer-like column (DevColumn::range): known, inherited from the column it was gathered from, or
+// computed now — one reduction + one read-back — over the base column's values: for a deferred gather that is its SOURCE
+// (the base table's column, whose ColRange object every query's gathers share), so a table's key range is found once.
+bool key_range_of(Ctx* ctx, const DevColumn& col_in, int64_t& mn, int64_t& mx) {
+  const DevColumn* col = &col_in;
+  if (!col->range->known) {
+    if (col->pending_upload) col = &resolved(ctx, *col);
+    const DevColumn* base = col;
+    if (col->deferred && !col->deferred->done) {
+      DevColumn& src = col->deferred->src;
+      if (src.pending_upload) (void)resolved(ctx, src);
+      base = &src;
+    } else if (col->deferred) {
+      base = &resolved(ctx, *col);
+      col = base;
+    }
+    if (!base->range->known) {
+      const int w = dtype_width(base->type);
+      if (!base->values || base->length <= 0 || w <= 0 || w > 8 || dtype_is_float(base->type)) return false;
+      if (base->range_inherited) {   // a gathered subset: its own (narrower) bounds must not reach its source's object
+        base->range = std::make_shared<ColRange>();
+        base->range_inherited = false;
+      }
+      DevBuf out(16);
+      QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, 16, ctx->stream));
+      const bool is_signed = !(base->type.id == QHIP_UINT8 || base->type.id == QHIP_UINT16 || base->type.id == QHIP_UINT32 || base->type.id == QHIP_UINT64);
+      launch_value_range(base->values->ptr, (uint64_t)base->length, w, is_signed, out.as<uint64_t>(), ctx->stream);
+      uint64_t h[2] = {0, 0};
+      copy_sync(ctx->stream, h, out.ptr, 16, hipMemcpyDeviceToHost);
+      base->range->max = (int64_t)(h[0] ^ 0x8000000000000000ULL);
+      base->range->min = (int64_t)(~h[1] ^ 0x8000000000000000ULL);
+      base->range->known = true;
+    }
+    if (base != col) { col->range = base->range; col->range_inherited = true; }
+  }
+  mn = col->range->min;
+  mx = col->range->max;
+  return true;
+}
+
 DevColumn materialize_upload(Ctx* ctx, const DeferredUpload& u);   // table.cpp
 
 const DevColumn& resolved(Ctx* ctx, const DevColumn& col) {
@@ -206,6 +247,7 @@ void defer_gather(Ctx* ctx, const std::vector<DevColumn>& cols, const std::share
     o.length = (int64_t)m;
     o.utf8_max_len = c.utf8_max_len;
     o.value_maxabs = c.value_maxabs;
+    o.range = c.range; o.range_inherited = true;   // (a subset's values lie inside its source's range)
     auto d = std::make_shared<DeferredGather>();
     d->m = m;
     if (c.deferred && !c.deferred->done) {
@@ -273,6 +315,7 @@ void resolve_referenced(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, i
         out.length = (int64_t)d.m;
         out.utf8_max_len = d.src.utf8_max_len;
         out.value_maxabs = d.src.value_maxabs;
+        out.range = d.src.range; out.range_inherited = true;   // (a subset's values lie inside its source's range)
         const int w = dtype_width(d.src.type);
         out.values = std::make_shared<DevBuf>((size_t)d.m * (size_t)w);
         gb.d[j] = GatherDesc{d.src.values->ptr, d.idx->as<uint32_t>(), out.values->ptr, d.m, (uint32_t)w, 0u};
@@ -299,6 +342,7 @@ DevColumn gather_column(Ctx* ctx, const DevColumn& col_in, const uint32_t* idx, 
   out.length = (int64_t)m;
   out.utf8_max_len = col.utf8_max_len;   // an upper bound stays an upper bound under gathering
   out.value_maxabs = col.value_maxabs;
+  out.range = col.range; out.range_inherited = true;   // (a subset's values lie inside its source's range)
   if (col.type.id == QHIP_NULL) { out.null_count = (int64_t)m; return out; }
   DevBuf counter(4);
   if (col.null_count > 0 || idx_may_be_null) {
