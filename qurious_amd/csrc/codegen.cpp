@@ -945,9 +945,15 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe_onetable(KArgs a, ProbeLaunch L) { qh_join_probe_body<P, false>(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_DENSE_PROBE) {
     // the dense stages keep ~half the state of the hashed ones (no key words / filter masks / slot images across stages)
-    const int waves = env_int("QHIP_DENSE_PROBE_WAVES", 8);
-    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) __attribute__((amdgpu_waves_per_eu(" << waves << "))) void qk_join_probe_dense(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, false>(a, L); }\n";
-    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, true>(a, L); }\n";
+    const int waves = env_int("QHIP_DENSE_PROBE_WAVES", 0);   // (0: no occupancy attribute — the kernels need <= 64 VGPRs anyway, and pinning 8 waves caps the SGPRs at 80: ~30 spills)
+    const std::string wattr = waves > 0 ? "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "))) " : std::string();
+    // qk_join_probe_dense: any table (rows r * 64 + lane, clamped per row); _wide: a lane owns R consecutive rows (16-byte
+    // column loads; tables of at least one tile); _lds / _hybrid: 1 024-thread workgroups with the bitmap (its first
+    // L.lds_words words) staged in LDS, wide loads
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_join_probe_dense(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 0, false>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_join_probe_dense_wide(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 0, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 1, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_hybrid(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 2, true>(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_DENSE_BUILD) {
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_dense_build(KArgs a, DenseBuildLaunch L) { qh_join_dense_build_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_SCATTER)

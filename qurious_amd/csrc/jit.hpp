@@ -13,6 +13,7 @@ namespace qhip {
 struct Module {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
+  int wgs_per_cu = 0;   // occupancy of the kernel at the launch shape its operator uses (0 = not asked yet)
   ~Module();
 };
 

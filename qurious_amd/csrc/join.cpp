@@ -15,6 +15,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <map>
 
 #include "common.hpp"
 #include "device/qhip_status.h"
@@ -172,7 +173,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const int v[5] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0, dense ? 1 : 0};
     put(v, sizeof v);
   }
-  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod, rmod, rmod_onetable, rmod_lds; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
+  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod; std::map<std::string, std::shared_ptr<Module>> rmods; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
   std::shared_ptr<JoinPlan> jp;
   {
     auto cached = ctx->plan_cache.find(pkey);
@@ -345,25 +346,47 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const bool want_pairs = !(semi_anti && froot < 0);
   const bool mark_in_probe = has_tail && froot < 0;             // with a residual filter only surviving pairs mark
   if (P > 0) {
-    // dense layout, bitmap staged in LDS (QHIP_JOIN_DENSE_LDS=1: the measured alternative to reading it through L2): ranges
-    // of up to 2^20 keys; 1 024-thread workgroups, one per CU
-    const bool dense_lds = dense && env_int("QHIP_JOIN_DENSE_LDS", 0) != 0 && (size_t)dense_words * 4 <= 128 * 1024;
-    std::shared_ptr<Module>& rmod = dense_lds ? jp->rmod_lds : (region_build || dense) ? jp->rmod : jp->rmod_onetable;   // (the table layout is a template parameter of the kernel)
-    if (!rmod) rmod = get_module(ctx, rkp.source, dense_lds ? "qk_join_probe_dense_lds" : (region_build || dense) ? rkp.kernel_name : "qk_join_probe_onetable");
+    // which probe kernel (the table layout is a template parameter of the generated kernel). Dense layout: probe sides of
+    // less than one tile run the general kernel; else a lane owns consecutive rows (16-byte column loads,
+    // QHIP_JOIN_DENSE_WIDE=0: not), and QHIP_JOIN_DENSE_LDS stages the bitmap in LDS: 1 = when all of it fits the CU's
+    // 160 KB, the hybrid kernel (first 160 KB in LDS, the rest through L2) up to four times that; 2 = hybrid always
+    const uint64_t kProbeTileRows = (uint64_t)64 * (uint64_t)rkp.probe_r;   // one wavefront's tile: 64 * P::PROBE_R consecutive probe rows
+    constexpr uint32_t kLdsWords = 160 * 1024 / 4;
+    const int lds_mode = env_int("QHIP_JOIN_DENSE_LDS", 0);
+    const char* probe_kernel = region_build ? "qk_join_probe" : "qk_join_probe_onetable";
+    uint32_t lds_words = 0;
+    if (dense) {
+      probe_kernel = "qk_join_probe_dense";
+      if (P >= kProbeTileRows) {
+        if (env_int("QHIP_JOIN_DENSE_WIDE", 1) != 0) probe_kernel = "qk_join_probe_dense_wide";
+        if (lds_mode == 1 && dense_words <= kLdsWords) { probe_kernel = "qk_join_probe_dense_lds"; lds_words = dense_words; }
+        else if (lds_mode == 2 || (lds_mode == 1 && dense_words <= 4 * kLdsWords)) { probe_kernel = "qk_join_probe_dense_hybrid"; lds_words = std::min(dense_words, kLdsWords); }
+      }
+    }
+    const bool dense_lds = lds_words > 0;
+    std::shared_ptr<Module>& rmod = jp->rmods[probe_kernel];
+    if (!rmod) rmod = get_module(ctx, rkp.source, probe_kernel);
     const std::shared_ptr<Module>& mod = rmod;
     HKArgs ka;
     fill_kargs(ctx, R, rkp.bind, ka, jp->rstr);
-    const uint64_t kProbeTileRows = (uint64_t)64 * (uint64_t)rkp.probe_r;   // one wavefront's tile: 64 * P::PROBE_R consecutive probe rows
     const uint64_t ntiles = (P + kProbeTileRows - 1) / kProbeTileRows;
-    // a wavefront owns a CHUNK of consecutive tiles (~12 once every CU has work: it pays three trips to fill and drain its
-    // pipeline); the workgroups are NOT assumed co-resident (the kernel's register counts admit 5 or 6 per CU; a grid of
-    // exactly the assumed residency that is one short runs its remainder as a second round) — the hardware deals them out as
-    // earlier ones finish, so the tail is a fraction of one workgroup's share. A chunk's matches are one run of entries with
-    // one count: the scan and pass 2 work per chunk.
-    const uint64_t tpw_max = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 12));
-    const uint64_t waves_wanted = std::max<uint64_t>(std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cus * 16), (ntiles + tpw_max - 1) / tpw_max);
-    const uint64_t tiles_per_wave = (ntiles + waves_wanted - 1) / waves_wanted;
+    // A wavefront owns a CHUNK of consecutive tiles; a chunk's matches are one run of entries with one count (the scan and
+    // pass 2 work per chunk). The grid is sized in whole ROUNDS of the wavefronts the chip holds at once (occupancy of the
+    // loaded kernel x CUs), each wavefront with at most QHIP_PROBE_TILES_PER_WAVE (32) tiles: a wavefront pays ~two extra
+    // trips to fill its pipeline whatever its chunk, and a last round that fills a third of the chip costs a whole round
+    // (round 2 gave every wavefront 12 tiles: Q3's lineitem probe ran 2.4 rounds at 12 / 14 pipeline efficiency — 63 % of the
+    // 6.5 TB/s a bare kernel with the same access pattern reaches, tools/micro/stream_widths.hip).
     const unsigned waves_per_wg = dense_lds ? 16 : 4;
+    if (mod->wgs_per_cu == 0) {
+      int nb = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mod->fn, (int)waves_per_wg * 64, (size_t)lds_words * 4) != hipSuccess || nb < 1) nb = 1;
+      mod->wgs_per_cu = nb;
+    }
+    const uint64_t resident = (uint64_t)ctx->num_cus * (uint64_t)mod->wgs_per_cu * waves_per_wg;   // wavefronts the chip runs at once
+    const uint64_t tpw_max = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 32));
+    const uint64_t rounds = std::max<uint64_t>(1, (ntiles + resident * tpw_max - 1) / (resident * tpw_max));
+    const uint64_t waves_wanted = std::min<uint64_t>(ntiles, rounds * resident);
+    const uint64_t tiles_per_wave = (ntiles + waves_wanted - 1) / waves_wanted;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, ((ntiles + tiles_per_wave - 1) / tiles_per_wave + waves_per_wg - 1) / waves_per_wg);
     const uint64_t nchunks = (uint64_t)grid * waves_per_wg;
     DevBuf tile_tot((nchunks + 1) * 4), tile_nent((nchunks + 1) * 4);
@@ -380,11 +403,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.tiles_per_wave = (uint32_t)tiles_per_wave;
     if (dense) {
       pl.count = nullptr;
-      pl.dense_min = (uint64_t)kmin; pl.dense_n = (uint32_t)dense_n; pl.dense_words = dense_words;
+      pl.dbg = (uint32_t)env_int("QHIP_DENSE_DBG", 0);   // (timing experiments only: qh_join_probe_dense_body)
+      pl.dense_min = (uint64_t)kmin; pl.dense_n = (uint32_t)dense_n; pl.dense_words = dense_words; pl.lds_words = lds_words;
     }
     void* args[] = {&ka, &pl};
     time_mark(ctx, 2);
-    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, waves_per_wg * 64, 1, 1, dense_lds ? dense_words * 4 : 0, s, args, nullptr));
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, waves_per_wg * 64, 1, 1, lds_words * 4, s, args, nullptr));
     time_mark(ctx, 3);
     probe_timed = true;
     if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), nchunks, dstat + 2 * QS_WORDS, s);

@@ -165,6 +165,13 @@ def test_catalog_holds_the_kernel_variants_a_repeated_q3_launches():
     # the probe kernel: one entry point per table layout, five waves per SIMD pinned
     probe = srcs["q3 lineitem probe"]
     assert "qk_join_probe(" in probe and "qk_join_probe_onetable(" in probe and "amdgpu_waves_per_eu(5)" in probe
+    # the dense (direct-address) join layout Q3's integer keys run since round 3: build kernel (also with the row count on the
+    # device) and the probe kernel's four entry points
+    db, db_dr, dp = srcs["q3 join-1 output dense build"], srcs["q3 join-1 output dense build, device-side row count"], srcs["q3 lineitem dense probe"]
+    assert "qh_join_dense_build_body<P>" in db and "qh_join_dense_build_body<P, true>" in db_dr
+    for entry in ("qk_join_probe_dense(", "qk_join_probe_dense_wide(", "qk_join_probe_dense_lds(", "qk_join_probe_dense_hybrid("):
+        assert entry in dp
+    assert "c_mktsegment" not in srcs["q3 customer dense build"] and "qh_streq_lit" in srcs["q3 customer dense build"]   # the fused scan filter
     # Q1's catalog variant knows what an execution finds out about the data: narrow values, one-byte flag columns
     q1 = srcs["q1_full filter+aggregate, bounded values"]
     assert q1 != srcs["q1_full filter+aggregate"]
