@@ -928,7 +928,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   if (raw) {
-    out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", 4) : env_int("QHIP_PROBE_R", 4)));
+    out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", 2) : env_int("QHIP_PROBE_R", 4)));
     s << "  static constexpr int PROBE_R = " << out.probe_r << ";\n";
     s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
     s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
@@ -952,8 +952,8 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     // L.lds_words words) staged in LDS, wide loads
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_join_probe_dense(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 0, false>(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_join_probe_dense_wide(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 0, true>(a, L); }\n";
-    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 1, true>(a, L); }\n";
-    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_hybrid(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 2, true>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 1, false>(a, L); }\n";
+    s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_hybrid(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 2, false>(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_DENSE_BUILD) {
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_dense_build(KArgs a, DenseBuildLaunch L) { qh_join_dense_build_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_SCATTER)

@@ -920,7 +920,7 @@ struct ProbeLaunch {
   u32* status;
   u32 nslots, bloom_mask;  // legacy layout: slots of the one table (power of two), 64-bit words of the filter - 1
   u32 n_regions;           // region layout (0 = legacy): regions of 2^slot_bits slots, each with a filter slice of
-  u32 slot_bits, bword_bits, dbg;    // 2^bword_bits 64-bit words; (dbg: unused)
+  u32 slot_bits, bword_bits, stage_cap;   // 2^bword_bits 64-bit words; dense layout: LDS staging entries per wavefront
   u32 tiles_per_wave, lds_words;     // wavefront w of the grid owns tiles [w * tiles_per_wave, (w + 1) * tiles_per_wave); (dense
                                      // layout, hybrid: the first lds_words 32-bit words of the bitmap are staged in LDS)
   // dense (direct-address) layout, qh_join_probe_dense_body: `bloom` = an EXACT bitmap over the build keys' value range
@@ -977,7 +977,7 @@ struct QhProbeTile {
   i64 tile;                                              // wave-uniform
   bool live;                                             // wave-uniform: a real tile of this wavefront (not a drain trip's)
 };
-struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, mine; u32 nent, total; u32 dbg; i64 tpw, nwaves; };   // (nent / total: the chunk so far, wave-uniform)
+struct QhProbeCtx { bool regions; u32 smask; int lane; i64 first, mine; u32 nent, total; };   // (nent / total: the chunk so far, wave-uniform)
 
 // stage 1: issue the column loads of the wavefront's j-th tile (j beyond its last tile: tile 0 once more, not live)
 template <class P>
@@ -1191,59 +1191,58 @@ __device__ __forceinline__ void qh_join_dense_build_body(const KArgs& a, const D
     atomicMax(&L.status[QS_MAXCOUNT], 2u);
 }
 
-// Probe pass 1 over the dense layout: the same software pipeline over the wavefront's tiles as qh_join_probe_body (three
-// register sets rotating through the stages, every stage unconditional) with shorter stages:
-//   stage 1  issue the column loads of tile t + 3
-//   stage 2  fused scan filter + key of tile t + 2, idx = key - min, range test, issue the bitmap-word loads
-//   stage 3  bit test of tile t + 1, issue the row_of loads of the rows whose bit is set
-//   stage 4  the entries (build row, probe row) and counts of tile t
+// Probe pass 1 over the dense layout — software-pipelined over the wavefront's tiles like qh_join_probe_body, but with
+// THREE stages and nothing but column and bitmap loads in its steady state:
+//   stage 1  issue the column loads of tile t + 2
+//   stage 2  fused scan filter + key of tile t + 1, idx = key - min, range test, issue the bitmap-word loads
+//   stage 3  bit test of tile t; the matching rows' (idx, probe row) go, ballot-ranked, into the wavefront's LDS staging area
+// The staging area (L.stage_cap entries per wavefront) is flushed to the chunk's entry run when the next tile might not fit
+// and at the end of the chunk: with the few matches of a selective join that is ONE burst of coalesced stores per chunk.
+// What is NOT in the loop any more, and why (tools/micro/probe_like.hip, 60 M clustered rows, 12 B/row, MI355X): columns +
+// predicate alone stream at 6.6-6.8 TB/s, with the dependent bitmap lookup 6.1 — and 4.9 once row_of[idx] is loaded per tile,
+// 4.3 with the entry stores per tile, 3.7-4.0 with both, although only 5 % of the rows match: vector-memory operations return
+// in order, so every trip's wait for its loads also waits for the acknowledgement of the stores and the return of the
+// lookups issued in front of them, however few lanes they carry. So the build row is looked up by PASS 2 (k_join_emit reads
+// row_of[idx] for the matching entries only — 0.3 M of Q3's 60 M lineitem rows), and stores leave the loop through LDS.
 // WIDE: a lane owns R CONSECUTIVE rows of the tile (row = tile base + lane * R + r) instead of rows r * 64 + lane, so that
-// the R loads of a column are adjacent and merge into 16-byte loads (a 4-byte column: ONE global_load_dwordx4 per tile
-// instead of four dword loads; 8-byte accesses stream at 0.54-0.70x the rate of 16-byte ones on this chip). The hashed
-// probe lost by that shape (its filter / slot lookups of one instruction spread over 4x the keys); the bitmap of a probe
-// side stored in foreign-key order is read in key order either way. Needs a table of at least one tile: the last, partial
+// the R loads of a column are adjacent and merge into wider loads. Needs a table of at least one tile: the last, partial
 // tile is read as the table's LAST whole tile (wave-uniform base shift, its already-seen rows masked), so that no load is
 // clamped per row — a per-row select on the index is what keeps the loads from merging.
-// LDSBITS: 1 = every workgroup first copies the whole bitmap into LDS (ranges of <= 1.3 M keys = 160 KB; 1 024-thread
-// workgroups so that the one workgroup a CU holds still runs 16 wavefronts) and stage 2 reads it with DS loads instead of
-// going through L1 / L2; 2 = hybrid: the first L.lds_words words live in LDS, keys beyond them are looked up in L2.
+// LDSBITS: 1 = every workgroup first copies the whole bitmap into LDS (1 024-thread workgroups so that the one workgroup a
+// CU holds still runs 16 wavefronts) and stage 2 reads it with DS loads instead of going through L1 / L2; 2 = hybrid: the
+// first L.lds_words words live in LDS, keys beyond them are looked up in L2.
+// LeftSemi / LeftAnti joins (L.visited set, no pairs wanted): the flush looks the build rows up itself and marks them.
 template <class P>
 struct QhDenseTile {
   typename P::Raw raw[P::PROBE_R];   // stage 1 -> 2
   u32 idx[P::PROBE_R];               // stage 2 -> 3
   u32 bw[P::PROBE_R];                // stage 2 -> 3: the key's bitmap word (from L2 / from LDS when LDSBITS == 1)
   u32 bl[P::PROBE_R];                // stage 2 -> 3: ... from LDS (LDSBITS == 2: which one counts is decided in stage 3)
-  u32 row[P::PROBE_R];               // stage 3 -> 4: row_of[idx]
   bool ok[P::PROBE_R];
   i64 tile;                          // wave-uniform
   i64 tb;                            // wave-uniform: first row the tile's loads read (WIDE: shifted back for the last tile)
-  bool live;
-  // the tile whose column loads are in flight into `raw` (issued by stage 1 THREE trips before stage 2 consumes them: the
-  // set's previous tile is still passing through stages 3 and 4 meanwhile)
-  i64 n_tile, n_tb;
-  bool n_live;
+  bool live;                         // wave-uniform: a real tile of this wavefront (not a drain trip's)
 };
+struct QhDenseStage { u32* idx; u32* row; u32 cap, nbuf, nflushed; };   // the wavefront's staging area (LDS) and its counters (wave-uniform)
 template <class P, bool WIDE>
 __device__ __forceinline__ u32 qh_dense_row_off(int r, int lane) { return WIDE ? (u32)lane * P::PROBE_R + (u32)r : (u32)r * 64 + (u32)lane; }
 template <class P, bool WIDE>
 __device__ __forceinline__ void qh_dense_stage1(const KArgs& a, QhDenseTile<P>& x, const QhProbeCtx& c, i64 j) {
   constexpr int R = P::PROBE_R, TILE = 64 * R;
-  x.n_live = j < c.mine;
-  x.n_tile = x.n_live ? c.first + j : 0;
-  if (c.dbg & 8u) x.n_tile = x.n_live ? (c.first / c.tpw) + j * c.nwaves : 0;   // (timing experiment, results wrong: grid-strided tiles)
-  const i64 tb = x.n_tile * TILE;
-  x.n_tb = WIDE ? (tb + TILE <= a.nrows ? tb : a.nrows - TILE) : tb;
+  x.live = j < c.mine;
+  x.tile = x.live ? c.first + j : 0;   // (a drain trip reads tile 0: the same L2-resident lines for every wavefront)
+  const i64 tb = x.tile * TILE;
+  x.tb = WIDE ? (tb + TILE <= a.nrows ? tb : a.nrows - TILE) : tb;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const u32 o = qh_dense_row_off<P, WIDE>(r, c.lane);
-    if (WIDE) P::load(a, x.n_tb, o, x.raw[r]);
+    if (WIDE) P::load(a, x.tb, o, x.raw[r]);
     else P::load(a, tb, tb + (i64)o < a.nrows ? o : (u32)(a.nrows - 1 - tb), x.raw[r]);
   }
 }
 template <class P, int LDSBITS, bool WIDE>
 __device__ __forceinline__ void qh_dense_stage2(const KArgs& a, const ProbeLaunch& L, QhDenseTile<P>& x, const QhProbeCtx& c, u32& err) {
   constexpr int R = P::PROBE_R, TILE = 64 * R;
-  x.tile = x.n_tile; x.tb = x.n_tb; x.live = x.n_live;   // the prefetched tile enters the pipeline
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const i64 row = x.tb + qh_dense_row_off<P, WIDE>(r, c.lane);
@@ -1257,8 +1256,7 @@ __device__ __forceinline__ void qh_dense_stage2(const KArgs& a, const ProbeLaunc
     x.idx[r] = x.ok[r] ? (u32)idx : 0u;
     const u32 w = x.idx[r] >> 5;
     // (32-bit byte offset from the scalar base: the bitmap holds <= 2^25 words)
-    if (c.dbg & 1u) x.bw[r] = 0u;   // (timing experiment: no bitmap lookup, nothing matches)
-    else if (LDSBITS == 1) x.bw[r] = ((const u32*)qh_dyn_lds)[w];
+    if (LDSBITS == 1) x.bw[r] = ((const u32*)qh_dyn_lds)[w];
     else if (LDSBITS == 2) {
       const bool in_lds = w < L.lds_words;
       x.bl[r] = ((const u32*)qh_dyn_lds)[in_lds ? w : 0u];
@@ -1266,118 +1264,111 @@ __device__ __forceinline__ void qh_dense_stage2(const KArgs& a, const ProbeLaunc
     } else x.bw[r] = *(const u32*)((const char*)L.bloom + (size_t)(w << 2));
   }
 }
-template <class P, int LDSBITS>
-__device__ __forceinline__ void qh_dense_stage3(const ProbeLaunch& L, QhDenseTile<P>& x, const QhProbeCtx& c) {
-  constexpr int R = P::PROBE_R;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const u32 word = (LDSBITS == 2 && (x.idx[r] >> 5) < L.lds_words) ? x.bl[r] : x.bw[r];
-    x.ok[r] = x.ok[r] && ((word >> (x.idx[r] & 31u)) & 1u);
-    if (c.dbg & 2u) x.row[r] = x.idx[r];   // (timing experiment: no row_of lookup)
-    else x.row[r] = *(const u32*)((const char*)L.table + (size_t)((x.ok[r] ? x.idx[r] : 0u) << 2));   // (idx < 2^30)
+// the staged entries -> the chunk's run in ent_slot / ent_row (coalesced), behind what was flushed before
+__device__ __forceinline__ void qh_dense_flush(const ProbeLaunch& L, QhDenseStage& st, u64 chunk_base, int lane) {
+  for (u32 j = (u32)lane; j < st.nbuf; j += 64) {
+    const u32 idx = st.idx[j];
+    L.ent_slot[chunk_base + st.nflushed + j] = idx;
+    L.ent_row[chunk_base + st.nflushed + j] = st.row[j];
+    if (L.visited) { const u32 b = ((const u32*)L.table)[idx]; atomicOr(&L.visited[b >> 5], 1u << (b & 31)); }
   }
+  st.nflushed += st.nbuf;
+  st.nbuf = 0;
 }
-template <class P, bool WIDE>
-__device__ __forceinline__ void qh_dense_stage4(const ProbeLaunch& L, QhDenseTile<P>& x, QhProbeCtx& c) {
+template <class P, int LDSBITS, bool WIDE>
+__device__ __forceinline__ void qh_dense_stage3(const ProbeLaunch& L, QhDenseTile<P>& x, QhProbeCtx& c, QhDenseStage& st) {
   constexpr int R = P::PROBE_R, TILE = 64 * R;
   if (!x.live) return;   // wave-uniform: a drain trip writes nothing
   const int lane = c.lane;
   const u64 below = (1ULL << lane) - 1;
+  if (st.nbuf + (u32)TILE > st.cap) qh_dense_flush(L, st, (u64)c.first * TILE, lane);   // wave-uniform, rare
+  bool hit[R];
+  u64 m[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32 word = (LDSBITS == 2 && (x.idx[r] >> 5) < L.lds_words) ? x.bl[r] : x.bw[r];
+    hit[r] = x.ok[r] && ((word >> (x.idx[r] & 31u)) & 1u);
+    m[r] = qh_ballot(hit[r]);
+  }
   if (WIDE) {
     // a lane's rows are consecutive: its entries go, in row order, behind the entries of all lower lanes
     u32 before = 0, total = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u64 m = qh_ballot(x.ok[r]);
-      before += (u32)__builtin_popcountll(m & below);
-      total += (u32)__builtin_popcountll(m);
-    }
-    size_t pos = (size_t)c.first * TILE + c.nent + before;
+    for (int r = 0; r < R; ++r) { before += (u32)__builtin_popcountll(m[r] & below); total += (u32)__builtin_popcountll(m[r]); }
+    u32 pos = st.nbuf + before;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (hit[r]) { st.idx[pos] = x.idx[r]; st.row[pos] = (u32)(x.tb + (i64)((u32)lane * R + (u32)r)); ++pos; }
+    st.nbuf += total;
+  } else {
+    u32 n = st.nbuf;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (x.ok[r]) {
-        L.ent_slot[pos] = x.row[r];
-        L.ent_row[pos] = (u32)(x.tb + (i64)((u32)lane * R + (u32)r));
-        if (L.visited) atomicOr(&L.visited[x.row[r] >> 5], 1u << (x.row[r] & 31));
-        ++pos;
+      if (hit[r]) {
+        const u32 pos = n + (u32)__builtin_popcountll(m[r] & below);
+        st.idx[pos] = x.idx[r];
+        st.row[pos] = (u32)(x.tile * TILE + r * 64 + lane);
       }
+      n += (u32)__builtin_popcountll(m[r]);
     }
-    c.nent += total;
-    return;
+    st.nbuf = n;
   }
-  u32 nent = c.nent;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const u64 m = qh_ballot(x.ok[r]);
-    if (x.ok[r]) {
-      const size_t pos = (size_t)c.first * TILE + nent + (u32)__builtin_popcountll(m & below);
-      L.ent_slot[pos] = x.row[r];
-      L.ent_row[pos] = (u32)(x.tile * TILE + r * 64 + lane);
-      if (L.visited) atomicOr(&L.visited[x.row[r] >> 5], 1u << (x.row[r] & 31));
-    }
-    nent += (u32)__builtin_popcountll(m);
-  }
-  c.nent = nent;
 }
 template <class P, int LDSBITS, bool WIDE>
 __device__ __forceinline__ void qh_join_probe_dense_body(const KArgs& a, const ProbeLaunch& L) {
   constexpr int R = P::PROBE_R, TILE = 64 * R;
   const int NW = (int)(blockDim.x >> 6);
+  const u32 nbits = LDSBITS == 1 ? L.dense_words : LDSBITS == 2 ? L.lds_words : 0u;
   if (LDSBITS) {
     u32* lbits = (u32*)qh_dyn_lds;
-    const u32 nw = LDSBITS == 1 ? L.dense_words : L.lds_words;
-    for (u32 w = threadIdx.x; w < nw; w += blockDim.x) lbits[w] = ((const u32*)L.bloom)[w];
+    for (u32 w = threadIdx.x; w < nbits; w += blockDim.x) lbits[w] = ((const u32*)L.bloom)[w];
     __syncthreads();
   }
   const i64 ntiles = (a.nrows + TILE - 1) / TILE;
   QhProbeCtx c;
   c.regions = false; c.smask = 0;
   c.lane = qh_lane();
-  const i64 wave = (i64)blockIdx.x * NW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const i64 wave = (i64)blockIdx.x * NW + wave_in_wg;
   c.first = wave * (i64)L.tiles_per_wave;
   c.nent = 0; c.total = 0;
-  c.dbg = L.dbg; c.tpw = (i64)L.tiles_per_wave; c.nwaves = (i64)gridDim.x * NW;
   if (c.first >= ntiles) {
     if (c.lane == 0) { L.tile_total[wave] = 0; L.tile_nent[wave] = 0; }
     return;
   }
   c.mine = ntiles - c.first < (i64)L.tiles_per_wave ? ntiles - c.first : (i64)L.tiles_per_wave;
+  // the wavefront's staging area: [idx | row] x stage_cap, behind the bitmap words of the LDS variants
+  QhDenseStage st;
+  st.cap = L.stage_cap;
+  st.idx = (u32*)qh_dyn_lds + ((nbits + 1u) & ~1u) + (u32)wave_in_wg * 2u * L.stage_cap;
+  st.row = st.idx + L.stage_cap;
+  st.nbuf = 0; st.nflushed = 0;
   u32 err = 0;
   QhDenseTile<P> A, B, C;
-  // fill the pipeline: the column loads of the wavefront's first three tiles, then tile 0 through stage 2 and 3, tile 1
-  // through stage 2 — each stage 2 followed at once by the column loads of the tile THREE ahead into the registers it has
-  // just read. (First version: the loads were issued one trip before their stage 2, i.e. a wavefront had ONE tile's columns
-  // — 3 KB — in flight and paid a whole HBM latency per trip: 4.3-4.7 TB/s whatever the load width, rows per thread or
-  // where the bitmap lived; a trip now waits for an L2 access while three tiles' columns are on their way.)
+  // fill the pipeline. EVERY stage call below and in the loop is unconditional and works on a real tile (the trips behind the
+  // wavefront's last tile run on tile 0 without writing), and a compiler barrier ends every trip: the loads stay where they
+  // are issued (without it the machine-sink pass moved loads into the next trip's conditional blocks, right in front of
+  // their use and behind an s_waitcnt vmcnt(0); seen in the ISA)
   qh_dense_stage1<P, WIDE>(a, A, c, 0);
   qh_dense_stage1<P, WIDE>(a, B, c, 1);
-  qh_dense_stage1<P, WIDE>(a, C, c, 2);
   asm volatile("" ::: "memory");
   qh_dense_stage2<P, LDSBITS, WIDE>(a, L, A, c, err);
-  qh_dense_stage1<P, WIDE>(a, A, c, 3);
   asm volatile("" ::: "memory");
-  qh_dense_stage3<P, LDSBITS>(L, A, c);
-  qh_dense_stage2<P, LDSBITS, WIDE>(a, L, B, c, err);
-  qh_dense_stage1<P, WIDE>(a, B, c, 4);
-  asm volatile("" ::: "memory");
-  // one trip: finish X4's tile, bit-test X3's, key + bitmap loads of X2's, then refill X2's column registers
-  // (the compiler barrier at the end of a trip keeps the trip's loads where they are issued: without it the machine-sink
-  // pass moves a row_of load of stage 3 into the NEXT trip's conditional store block — right in front of its use, behind an
-  // s_waitcnt vmcnt(0) that drains the whole pipeline every trip; seen in the ISA)
-#define QH_DENSE_TRIP(X4, X3, X2, J)                   \
-  qh_dense_stage4<P, WIDE>(L, X4, c);                  \
-  qh_dense_stage3<P, LDSBITS>(L, X3, c);               \
+  // one trip: finish X3's tile, key + bitmap loads of X2's, column loads of the tile two ahead into X1
+#define QH_DENSE_TRIP(X3, X2, X1, J)                   \
+  qh_dense_stage3<P, LDSBITS, WIDE>(L, X3, c, st);     \
   qh_dense_stage2<P, LDSBITS, WIDE>(a, L, X2, c, err); \
-  qh_dense_stage1<P, WIDE>(a, X2, c, (J));             \
+  qh_dense_stage1<P, WIDE>(a, X1, c, (J));             \
   asm volatile("" ::: "memory");
-  for (i64 j = 0; j < c.mine; j += 3) {   // wave-uniform; stage 4 runs for tiles j, j + 1, j + 2 (not live beyond the last: no writes)
-    QH_DENSE_TRIP(A, B, C, j + 5)
-    QH_DENSE_TRIP(B, C, A, j + 6)
-    QH_DENSE_TRIP(C, A, B, j + 7)
+  for (i64 j = 0; j < c.mine; j += 3) {   // wave-uniform; stage 3 runs for tiles j, j + 1, j + 2 (not live beyond the last: no writes)
+    QH_DENSE_TRIP(A, B, C, j + 2)
+    QH_DENSE_TRIP(B, C, A, j + 3)
+    QH_DENSE_TRIP(C, A, B, j + 4)
   }
 #undef QH_DENSE_TRIP
+  qh_dense_flush(L, st, (u64)c.first * TILE, c.lane);
   // unique build keys: every matching probe row is exactly one pair
-  if (c.lane == 0) { L.tile_total[wave] = c.nent; L.tile_nent[wave] = c.nent; }
+  if (c.lane == 0) { L.tile_total[wave] = st.nflushed; L.tile_nent[wave] = st.nflushed; }
   qh_report(L.status, err);
 }
 

@@ -351,16 +351,25 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     // QHIP_JOIN_DENSE_WIDE=0: not), and QHIP_JOIN_DENSE_LDS stages the bitmap in LDS: 1 = when all of it fits the CU's
     // 160 KB, the hybrid kernel (first 160 KB in LDS, the rest through L2) up to four times that; 2 = hybrid always
     const uint64_t kProbeTileRows = (uint64_t)64 * (uint64_t)rkp.probe_r;   // one wavefront's tile: 64 * P::PROBE_R consecutive probe rows
-    constexpr uint32_t kLdsWords = 160 * 1024 / 4;
-    const int lds_mode = env_int("QHIP_JOIN_DENSE_LDS", 0);
+    // LDS staging of the dense probe's entries: per wavefront, at least one tile's worth behind the flush threshold
+    const uint32_t stage_extra = (uint32_t)std::max(0, env_int("QHIP_DENSE_STAGE_EXTRA", 256));
+    const uint32_t stage_cap_small = (uint32_t)kProbeTileRows + stage_extra, stage_cap_lds = (uint32_t)kProbeTileRows + 128;
+    const uint32_t kLdsWords = (160 * 1024 - 16 * 2 * 4 * stage_cap_lds) / 4 - 2;   // what the 16 wavefronts' staging areas leave of the CU's 160 KB
+    // QHIP_JOIN_DENSE_LDS: 0 never, 1 (default) when at least half of the bitmap fits the CU's LDS and the probe side is
+    // big enough to pay for every workgroup's copy of it, 2 always (tests). Measured on Q3 SF10's first join (15 M orders
+    // probing 1.5 M customer keys at random, 188 KB of bitmap, 60 % of it staged): 55-59 us against 72-80 us through L1 / L2
+    // — a random 4-byte lookup drags a 128-byte line from L2 into L1; the second join's bitmap (7.5 MB, read in key order
+    // by lineitem) gains nothing from LDS.
+    const int lds_mode = env_int("QHIP_JOIN_DENSE_LDS", 1);
     const char* probe_kernel = region_build ? "qk_join_probe" : "qk_join_probe_onetable";
     uint32_t lds_words = 0;
     if (dense) {
       probe_kernel = "qk_join_probe_dense";
       if (P >= kProbeTileRows) {
         if (env_int("QHIP_JOIN_DENSE_WIDE", 1) != 0) probe_kernel = "qk_join_probe_dense_wide";
-        if (lds_mode == 1 && dense_words <= kLdsWords) { probe_kernel = "qk_join_probe_dense_lds"; lds_words = dense_words; }
-        else if (lds_mode == 2 || (lds_mode == 1 && dense_words <= 4 * kLdsWords)) { probe_kernel = "qk_join_probe_dense_hybrid"; lds_words = std::min(dense_words, kLdsWords); }
+        const bool pays = lds_mode == 2 || (lds_mode == 1 && P >= (1u << 20) && P >= 32ull * std::min(dense_words, kLdsWords) && dense_words <= 2 * kLdsWords);
+        if (pays && dense_words <= kLdsWords) { probe_kernel = "qk_join_probe_dense_lds"; lds_words = dense_words; }
+        else if (pays) { probe_kernel = "qk_join_probe_dense_hybrid"; lds_words = kLdsWords; }
       }
     }
     const bool dense_lds = lds_words > 0;
@@ -377,9 +386,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     // (round 2 gave every wavefront 12 tiles: Q3's lineitem probe ran 2.4 rounds at 12 / 14 pipeline efficiency — 63 % of the
     // 6.5 TB/s a bare kernel with the same access pattern reaches, tools/micro/stream_widths.hip).
     const unsigned waves_per_wg = dense_lds ? 16 : 4;
+    // dynamic LDS: [bitmap words of the LDS variants | per wavefront: stage_cap x (idx, row)] (dense layout only)
+    const size_t dyn_lds = !dense ? 0 : (((size_t)lds_words + 1) & ~(size_t)1) * 4 + (size_t)waves_per_wg * 2 * 4 * (dense_lds ? stage_cap_lds : stage_cap_small);
     if (mod->wgs_per_cu == 0) {
       int nb = 0;
-      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mod->fn, (int)waves_per_wg * 64, (size_t)lds_words * 4) != hipSuccess || nb < 1) nb = 1;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mod->fn, (int)waves_per_wg * 64, dyn_lds) != hipSuccess || nb < 1) nb = 1;
       mod->wgs_per_cu = nb;
     }
     const uint64_t resident = (uint64_t)ctx->num_cus * (uint64_t)mod->wgs_per_cu * waves_per_wg;   // wavefronts the chip runs at once
@@ -403,12 +414,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pl.tiles_per_wave = (uint32_t)tiles_per_wave;
     if (dense) {
       pl.count = nullptr;
-      pl.dbg = (uint32_t)env_int("QHIP_DENSE_DBG", 0);   // (timing experiments only: qh_join_probe_dense_body)
+      pl.stage_cap = dense_lds ? stage_cap_lds : stage_cap_small;
       pl.dense_min = (uint64_t)kmin; pl.dense_n = (uint32_t)dense_n; pl.dense_words = dense_words; pl.lds_words = lds_words;
     }
     void* args[] = {&ka, &pl};
     time_mark(ctx, 2);
-    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, waves_per_wg * 64, 1, 1, lds_words * 4, s, args, nullptr));
+    QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, waves_per_wg * 64, 1, 1, (unsigned)dyn_lds, s, args, nullptr));
     time_mark(ctx, 3);
     probe_timed = true;
     if (want_pairs) exclusive_scan_u32(tile_tot.as<uint32_t>(), tile_tot.as<uint32_t>(), nchunks, dstat + 2 * QS_WORDS, s);
@@ -425,7 +436,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       p_idx.alloc((M + 1) * 4);
       rows_blk = std::make_shared<DevBuf>(64);   // the output table's device-side row count
       // pass 2 also pads the index vectors up to the capacity, publishes the status block to `slot` and the total to rows_blk
-      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, dense ? (const uint32_t*)table : nullptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        nullptr, nullptr, nullptr, (uint32_t)M, dstat, slot, rows_blk->as<uint32_t>(), s);
       deferred_slot = slot;
     } else {
@@ -455,7 +466,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
         pair_off.alloc((P + 1) * 4);
         QHIP_HIP_CHECK(hipMemsetAsync(cnt.ptr, 0, cnt.bytes, s));   // pass 2 only visits matching probe rows
       }
-      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
+      launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, dense ? (const uint32_t*)table : nullptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
                        mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, nullptr, nullptr, nullptr, s);
     }

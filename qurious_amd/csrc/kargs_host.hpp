@@ -72,7 +72,7 @@ struct HProbeLaunch {
   uint32_t* visited;
   uint32_t* status;
   uint32_t nslots, bloom_mask;
-  uint32_t n_regions = 0, slot_bits = 0, bword_bits = 0, dbg = 0;   // region layout of the LDS-staged build (0 = legacy)
+  uint32_t n_regions = 0, slot_bits = 0, bword_bits = 0, stage_cap = 0;   // region layout of the LDS-staged build (0 = legacy)
   uint32_t tiles_per_wave = 1, lds_words = 0;
   uint64_t dense_min = 0;                        // dense (direct-address) layout: bloom = exact bitmap, table = u32 row_of[]
   uint32_t dense_n = 0, dense_words = 0;

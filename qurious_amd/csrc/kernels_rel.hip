@@ -559,7 +559,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table,
 // (start == nullptr): the entry already holds the one build row. cnt_out / pair_off (Right / Full joins) receive the
 // pair count and first pair position of every MATCHING probe row (cnt_out is zero-filled by the caller).
 __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* chunk_nent, const u32* chunk_off,
-                                                       const u32* count, const u32* start, const u32* rows, u64 nchunks, u64 chunk_rows, u32* b_idx,
+                                                       const u32* count, const u32* start, const u32* rows, const u32* row_of, u64 nchunks, u64 chunk_rows, u32* b_idx,
                                                        u32* p_idx, u32* pair_off, u32* cnt_out, u32* visited, u32 cap, const u32* stat_block,
                                                        u32* publish, u32* rows_out) {
   // a join of deferred size (cap = the room its output has; stat_block = [build status | probe status | pair total]): rows
@@ -584,7 +584,11 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, con
     for (u32 j0 = 0; j0 < n; j0 += 64) {
       const u32 j = j0 + lane;
       const bool live = j < n;
-      const u32 sid = live ? ent_slot[e0 + j] : 0u, p = live ? ent_row[e0 + j] : 0u;
+      u32 sid = live ? ent_slot[e0 + j] : 0u;
+      const u32 p = live ? ent_row[e0 + j] : 0u;
+      // dense (direct-address) layout: the entry holds key - min; the build row is looked up HERE, for the matching rows only
+      // (qh_join_probe_dense_body keeps the lookup out of its streaming loop)
+      if (row_of && live) sid = row_of[sid];
       u32 c = start ? count[sid] : 1u;
       c = live ? c : 0u;
       const u32 incl = wave_incl_scan_u32(c);
@@ -1032,12 +1036,12 @@ void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u32*)m_dev, (const u64*)bound, nb, (u32*)pos);
 }
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
-                      const uint32_t* start, const uint32_t* rows, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
+                      const uint32_t* start, const uint32_t* rows, const uint32_t* row_of, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
                       uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish,
                       uint32_t* rows_out, hipStream_t s) {
   if (!nchunks) return;
   hipLaunchKernelGGL(k_join_emit, dim3(grid_for(nchunks * 64, QH_BLOCK)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
-                     (const u32*)chunk_nent, (const u32*)chunk_off, (const u32*)count, (const u32*)start, (const u32*)rows, (u64)nchunks,
+                     (const u32*)chunk_nent, (const u32*)chunk_off, (const u32*)count, (const u32*)start, (const u32*)rows, (const u32*)row_of, (u64)nchunks,
                      (u64)chunk_rows, (u32*)b_idx, (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap, (const u32*)stat_block,
                      (u32*)publish, (u32*)rows_out);
 }

@@ -93,5 +93,5 @@ def join_layout(request, monkeypatch):
     elif request.param in ("dense", "dense_lds"):
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
         if request.param == "dense_lds":
-            monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "1")
+            monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "2")
     return request.param

@@ -32,7 +32,7 @@ def dense(request, monkeypatch):
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
     elif request.param == "lds":
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
-        monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "1")
+        monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "2")
     elif request.param == "off":
         monkeypatch.setenv("QHIP_JOIN_DENSE", "0")
     return request.param

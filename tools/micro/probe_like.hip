@@ -66,8 +66,33 @@ __global__ __launch_bounds__(256) void k_probe(const u64* __restrict__ key, cons
       continue;
     }
     u32 row[R];
+    if (MODE == 4) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) row[r] = row_of[ok[r] ? idx[r] : 0u];
+      for (int r = 0; r < R; ++r) row[r] = idx[r];                       // no row_of loads, stores as in the full kernel
+    } else if (MODE == 5) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { row[r] = 0; if (ok[r]) row[r] = row_of[idx[r]]; }   // loads only by the lanes with a hit (EXEC-masked)
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) row[r] = row_of[ok[r] ? idx[r] : 0u];
+    }
+    if (MODE == 3) {   // row_of loads, no stores
+#pragma unroll
+      for (int r = 0; r < R; ++r) nent += (u32)__builtin_popcountll(__ballot(ok[r] && row[r] != 0xFFFFFFFFu));
+      continue;
+    }
+    if (MODE == 6) {   // ONE 8-byte store per entry into an interleaved (slot, row) array
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const u64 m = __ballot(ok[r]);
+        if (ok[r]) {
+          const u64 pos = first * TILE + nent + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+          ((u64*)ent_slot)[pos] = ((u64)(u32)(tb + r * 64 + lane) << 32) | row[r];
+        }
+        nent += (u32)__builtin_popcountll(m);
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const u64 m = __ballot(ok[r]);
@@ -100,7 +125,7 @@ int main() {
   const u32 dense_n = (u32)((norders >> 3) * 32 + 40);
   u64* key; u32 *date, *bits, *row_of, *ent_slot, *ent_row, *cn;
   CHECK(hipMalloc(&key, n * 8)); CHECK(hipMalloc(&date, n * 4)); CHECK(hipMalloc(&bits, (size_t)dense_n / 8 + 64)); CHECK(hipMalloc(&row_of, (size_t)dense_n * 4 + 64));
-  CHECK(hipMalloc(&ent_slot, n * 4)); CHECK(hipMalloc(&ent_row, n * 4)); CHECK(hipMalloc(&cn, 4 << 20));
+  CHECK(hipMalloc(&ent_slot, n * 8)); CHECK(hipMalloc(&ent_row, n * 4)); CHECK(hipMalloc(&cn, 4 << 20));
   CHECK(hipMemset(bits, 0, (size_t)dense_n / 8 + 64));
   hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, key, date, n);
   hipLaunchKernelGGL(k_build, dim3(2048), dim3(256), 0, 0, bits, row_of, norders);
@@ -108,7 +133,8 @@ int main() {
   printf("%llu rows, key range %u (bitmap %.1f MB), 12 B/row; GB/s of column bytes\n", (unsigned long long)n, dense_n, dense_n / 8e6);
 #define RUN(R, MODE, TPW) { const u64 ntiles = n / (64 * R); const u64 waves = (ntiles + (TPW) - 1) / (TPW); const unsigned grid = (unsigned)((waves + 3) / 4); \
     double ms = time_ms([&] { hipLaunchKernelGGL((k_probe<R, MODE>), dim3(grid), dim3(256), 0, 0, key, date, bits, row_of, n, (u32)(TPW), dense_n, ent_slot, ent_row, cn); }); \
-    printf("R=%d mode %d (%s) tiles/wave %3d, %6u wgs: %7.1f us  %6.0f GB/s\n", R, MODE, MODE == 0 ? "full" : MODE == 1 ? "no row_of / stores" : "columns + predicate", (int)(TPW), grid, ms * 1e3, n * 12 / ms / 1e6); }
+    printf("R=%d mode %d (%s) tiles/wave %3d, %6u wgs: %7.1f us  %6.0f GB/s\n", R, MODE, MODE == 0 ? "full" : MODE == 1 ? "no row_of / stores" : MODE == 2 ? "columns + predicate" : MODE == 3 ? "row_of loads, no stores" : MODE == 4 ? "stores, no row_of loads" : MODE == 5 ? "full, row_of loads EXEC-masked" : "full, one 8-byte store per entry", (int)(TPW), grid, ms * 1e3, n * 12 / ms / 1e6); }
+  RUN(4, 3, 12) RUN(4, 4, 12) RUN(4, 5, 12) RUN(4, 6, 12)
   RUN(4, 2, 12) RUN(4, 1, 12) RUN(4, 0, 12) RUN(4, 0, 29) RUN(4, 0, 6) RUN(2, 0, 24) RUN(2, 0, 58) RUN(8, 0, 6) RUN(8, 0, 15) RUN(1, 0, 48) RUN(4, 2, 29) RUN(8, 2, 15)
   u32 h[4]; CHECK(hipMemcpy(h, cn, 16, hipMemcpyDeviceToHost));
   printf("(first chunk counts %u %u)\n", h[0], h[1]);
