@@ -126,3 +126,63 @@ def test_sort_60m_rows_is_the_stable_sorted_permutation(ctx):
     plan, batches = sort_plan_with_rowid(l)
     n = check_stable_sorted_permutation(plan.execute(), batches)
     assert n > 59_000_000
+
+
+def test_q3_sf100_zipf_slice_of_one_rank_equals_exact_numpy(ctx, monkeypatch):
+    """BASELINE configs[4] at its own workload, as far as one GPU goes: rank 0's 1/8 slice of TPC-H Q3 at SF100 with the join
+    keys re-drawn from Zipf(1.1) (75 M lineitem rows, 18.75 M orders, 1.875 M customers; hot keys in both joins and in the
+    GROUP BY; probe keys far outside the slice's build-key range) through the HIP path, against an exact numpy restatement
+    on the raw buffers: group set, total revenue, key-weighted checksum mod 2^64, every group's date, the top-10, and the LDS
+    hash-table occupancy figures the config asks to be reported."""
+    c, o, l = synth.q3_tables_skewed(100.0, 1.1, 0, 8)
+    day = _days(1995, 3, 15)
+    # ---- exact restatement for a SLICE: keys may point outside the slice's customers / orders (no match there)
+    import pyarrow.compute as pc
+    from .numpy_checks import _concat_np
+    n_c = sum(b.num_rows for b in c)
+    building = np.concatenate([pc.equal(b.column(1), "BUILDING").to_numpy(zero_copy_only=False) for b in c])
+    okey, ocust, odate = _concat_np(o, 0, np.int64), _concat_np(o, 1, np.int64), _concat_np(o, 2, np.int32)
+    n_o = len(okey)
+    k = np.arange(n_o, dtype=np.int64)
+    assert (okey == (k // 8) * 32 + k % 8 + 1).all()
+    in_c = ocust <= n_c
+    order_ok = (odate < day) & in_c & building[np.minimum(ocust, n_c) - 1]
+    lkey, lship = _concat_np(l, 0, np.int64), _concat_np(l, 1, np.int32)
+    price = np.concatenate([_dec_lo(b.column(2)) for b in l])
+    disc = np.concatenate([_dec_lo(b.column(3)) for b in l])
+    oidx = order_row_of(lkey)
+    in_o = (oidx < n_o) & ((lkey - 1) % 32 < 8)
+    keep = (lship > day) & in_o & order_ok[np.minimum(oidx, n_o - 1)]
+    revenue = price[keep] * (100 - disc[keep])
+    per_order = np.zeros(n_o, dtype=np.int64)
+    np.add.at(per_order, oidx[keep], revenue)
+    hit = np.zeros(n_o, dtype=bool)
+    hit[oidx[keep]] = True
+    want_groups, want_total = int(hit.sum()), int(revenue.sum())
+    want_mix = int((revenue.astype(U64) * lkey[keep].astype(U64)).sum(dtype=U64))
+    assert want_groups > 100_000 and int(keep.sum()) > 5 * want_groups          # skew: many rows per hot group
+    # ---- the HIP path (three executions: sizes waited for, then remembered)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
+            q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    plan = queries.q3(*tabs)
+    for execution in range(3):
+        out = pa.Table.from_batches(plan.execute()).combine_chunks()
+        assert out.num_rows == want_groups, execution
+        g_key = out.column(0).to_numpy()
+        g_rev = _dec_lo(out.column(3).chunk(0))
+        g_idx = order_row_of(g_key)
+        assert len(np.unique(g_key)) == want_groups and hit[g_idx].all()
+        assert int(g_rev.sum()) == want_total
+        assert int((g_rev.astype(U64) * g_key.astype(U64)).sum(dtype=U64)) == want_mix
+        assert (g_rev == per_order[g_idx]).all()                                  # every group's revenue, exactly
+        assert (out.column(1).cast(pa.int32()).to_numpy() == odate[g_idx]).all() and (out.column(2).to_numpy() == 0).all()
+    top = rows_of(queries.q3_top10(*tabs).execute())
+    order = np.lexsort((out.column(1).cast(pa.int32()).to_numpy(), -g_rev))[:10]
+    assert [r[0] for r in top] == [int(g_key[i]) for i in order]
+    assert [_unscaled(r[3], 4) for r in top] == [int(g_rev[i]) for i in order]
+    # the occupancy figures configs[4] asks for (instrumented aggregate)
+    monkeypatch.setenv("QHIP_AGG_STATS", "1")
+    again = pa.Table.from_batches(plan.execute()).combine_chunks()
+    st = ctx.last_stats()
+    assert again.num_rows == want_groups and st["groups"] == want_groups
+    assert st["lds_table_slots"] > 0 and 0.0 < st["lds_occupancy"] <= 1.0 and 0.0 < st["hbm_table_load"] <= 1.0
