@@ -344,6 +344,41 @@ int qhip_table_unpack_concat(qhip_ctx* ctx, const char* const* names, const qhip
                              const int64_t* metas /* n x (2 + 2 * n_cols) */, const void* const* device_images,
                              int32_t n, qhip_table** out);
 
+/* ---------------------------------------------------------------- RCCL inside the library */
+/* The transport of the exchange for a host without torch (the reference's host is Rust): a communicator over the ranks of
+ * the job, one per process and GPU, and the two collective steps of a partitioned hash join. librccl.so is dlopen'ed at
+ * first use (QHIP_RCCL_LIB overrides the name; a copy the process already holds is reused), failures are QHIP_RCCL_ERROR.
+ * All transfers run on the context's own stream, grouped ncclSend / ncclRecv (xGMI is point-to-point: one group drives
+ * all of a GPU's links at once); the one host wait of an exchange is the read-back of the incoming parts' sizes.
+ * No reference counterpart (the reference is a single process).
+ *   rank 0:      qhip_comm_unique_id(id, 128)  -> distribute the 128 bytes to every rank (the host's own channel)
+ *   every rank:  qhip_comm_create(ctx, id, rank, world, &comm)     (world == 1: no RCCL call is made at all)
+ *   per join:    qhip_partition_by_key -> qhip_exchange_tables (repartition)   or   qhip_all_gather_table (broadcast) */
+typedef struct qhip_comm qhip_comm;
+typedef struct qhip_comm_stats {
+  uint64_t bytes_sent;        /* to other ranks, since the last reset */
+  uint64_t bytes_received;    /* from other ranks */
+  uint64_t bytes_packed;      /* wire images built, incl. the part that stayed on this rank */
+  uint64_t exchanges;         /* qhip_exchange_tables + qhip_all_gather_table calls */
+  uint64_t host_waits;        /* stream synchronisations made inside them (one per exchange: the sizes) */
+  double transfer_seconds;    /* device time between the first and the last transfer of every exchange (HIP events) */
+  int32_t rank, world;
+  int32_t rccl_version;       /* ncclGetVersion, 0 for a world of one */
+  int32_t reserved;
+} qhip_comm_stats;
+int qhip_comm_unique_id(void* id_out, size_t id_bytes /* >= 128 */);
+int qhip_comm_create(qhip_ctx* ctx, const void* unique_id /* 128 bytes */, int32_t rank, int32_t world, qhip_comm** out);
+void qhip_comm_destroy(qhip_comm* comm);
+int qhip_comm_get_stats(qhip_comm* comm, qhip_comm_stats* out, int32_t reset);
+/* parts[r] (world tables of one schema, e.g. from qhip_partition_by_key) is sent to rank r; *out = the concatenation, in
+ * rank order, of the parts every rank sent to this one (one batch per rank). names / dtypes: the schema, n_cols columns
+ * (a column dropped by qhip_table_keep_columns is QHIP_NULL on both sides). */
+int qhip_exchange_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* const* parts, const char* const* names,
+                         const qhip_dtype* dtypes, int32_t n_cols, qhip_table** out);
+/* Every rank ends up with the concatenation (rank order) of all ranks' `t`: the build side of a broadcast join. */
+int qhip_all_gather_table(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* t, const char* const* names,
+                          const qhip_dtype* dtypes, int32_t n_cols, qhip_table** out);
+
 /* ---------------------------------------------------------------- plan-only entry points (no GPU needed) */
 /* Return (snprintf-style; *needed = bytes incl. NUL) the policy source libqhip instantiates the kernel
  * templates of csrc/device/qhip_device.hpp with, for an input whose column c has type col_types[c] and

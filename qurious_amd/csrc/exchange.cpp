@@ -3,6 +3,7 @@
 //   qhip_table_column_buffer / qhip_table_from_device   raw device buffers for the RCCL all-to-all (moved by torch.distributed)
 //   qhip_table_concat       append the tables received from the peers
 // The reference has no exchange operator (it is single-process); only the joined RESULT must match it.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -204,7 +205,7 @@ void table_wire_meta(Ctx* ctx, const qhip_table* t, int64_t* meta) {
   meta[1] = (int64_t)wire_layout(types_of(t), t->num_rows, meta + 2, lay);
 }
 
-void table_pack(Ctx* ctx, const qhip_table* t, void* dst, int64_t dst_bytes) {
+void table_pack(Ctx* ctx, const qhip_table* t, void* dst, int64_t dst_bytes, bool sync = true) {
   std::vector<int64_t> meta(2 + 2 * t->cols.size());
   table_wire_meta(ctx, t, meta.data());
   if (dst_bytes < meta[1]) fail(QHIP_INVALID_ARGUMENT, "qhip_table_pack: destination smaller than the wire image");
@@ -221,11 +222,11 @@ void table_pack(Ctx* ctx, const qhip_table* t, void* dst, int64_t dst_bytes) {
     put(lay[c].validity_off, lay[c].validity_bytes, t->cols[c].validity);
     put(lay[c].data_off, lay[c].data_bytes, t->cols[c].data);
   }
-  QHIP_HIP_CHECK(sync_stream(s));   // the transport reads the image on its own stream
+  if (sync) QHIP_HIP_CHECK(sync_stream(s));   // the transport reads the image on its own stream (RCCL inside libqhip runs on this one)
 }
 
 qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_dtype* dtypes, int n_cols, const int64_t* metas,
-                                const void* const* images, int n) {
+                                const void* const* images, int n, bool sync = true) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   if (n <= 0 || n_cols < 0) fail(QHIP_INVALID_ARGUMENT, "qhip_table_unpack_concat: bad arguments");
   std::vector<DType> types;
@@ -263,7 +264,7 @@ qhip_table* table_unpack_concat(Ctx* ctx, const char* const* names, const qhip_d
     out->names.push_back(names && names[c] ? names[c] : ("c" + std::to_string(c)));
     out->nullable.push_back(true);
   }
-  QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the caller frees the images when this returns
+  if (sync) QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the caller frees the images when this returns (images from the stream-ordered pool need no wait)
   return out.release();
 }
 
@@ -325,6 +326,216 @@ qhip_table* table_from_device(Ctx* ctx, const char* const* names, const qhip_dev
   return t.release();
 }
 
+
+// ================================================================ RCCL inside libqhip
+// The exchange of a repartitioned / broadcast hash join behind the C ABI: a host that has no torch (the reference's is
+// Rust) creates a communicator from an ncclUniqueId it distributed itself and calls qhip_exchange_tables /
+// qhip_all_gather_table. librccl is dlopen'ed at first use (an already loaded copy — torch's — is reused), so the
+// library builds, links and runs single-GPU without RCCL on the machine. Everything is enqueued on the context's own
+// stream: packing, the metadata all-gather, the grouped ncclSend / ncclRecv (xGMI is point-to-point: one group puts all
+// 7 links of a GPU to work at once) and the unpacking are stream-ordered, and the ONE host wait of an exchange is the
+// read-back of the received parts' sizes.
+typedef struct { char internal[128]; } qh_nccl_unique_id;
+typedef void* qh_nccl_comm;
+enum { QH_NCCL_UINT8 = 1, QH_NCCL_INT64 = 4 };
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(qh_nccl_unique_id*) = nullptr;
+  int (*CommInitRank)(qh_nccl_comm*, int, qh_nccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(qh_nccl_comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, qh_nccl_comm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, qh_nccl_comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, qh_nccl_comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  std::string error;
+};
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    const char* names[] = {getenv("QHIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if (n && *n && !x.lib) x.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   // a copy the process already holds
+    for (const char* n : names) if (n && *n && !x.lib) x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!x.lib) { x.error = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "not found"); return x; }
+    auto sym = [&](const char* name) { void* p = dlsym(x.lib, name); if (!p && x.error.empty()) x.error = std::string("librccl lacks ") + name; return p; };
+    x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
+    x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+    x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+    x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+    x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+    x.Send = (decltype(x.Send))sym("ncclSend");
+    x.Recv = (decltype(x.Recv))sym("ncclRecv");
+    x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+    x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+    x.GetVersion = (decltype(x.GetVersion))sym("ncclGetVersion");
+    return x;
+  }();
+  if (!r.error.empty()) fail(QHIP_RCCL_ERROR, r.error);
+  return r;
+}
+void rccl_check(int rc, const char* what) {
+  if (rc != 0) fail(QHIP_RCCL_ERROR, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+struct qhip_comm {
+  Ctx* ctx = nullptr;
+  qh_nccl_comm comm = nullptr;   // nullptr for a world of one (nothing to talk to: no RCCL call is made)
+  int rank = 0, world = 1;
+  qhip_comm_stats stats;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool timed = false;            // ev[0] .. ev[1] bracket the last exchange's transfers, not yet added to stats.seconds
+};
+
+namespace {
+void comm_settle_time(qhip_comm* c) {
+  if (!c->timed) return;
+  float ms = 0;
+  if (sync_event(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.transfer_seconds += (double)ms * 1e-3;
+  c->timed = false;
+}
+
+// parts[r] goes to rank r (n = world parts) — or, all_gather, the ONE table parts[0] goes to every rank; the result is the
+// concatenation, in rank order, of what every rank sent here
+qhip_table* comm_exchange(Ctx* ctx, qhip_comm* c, const qhip_table* const* parts, bool all_gather, const char* const* names,
+                          const qhip_dtype* dtypes, int n_cols) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int W = c->world, me = c->rank;
+  // (QHIP_COMM_SELF_RCCL=1, tests: this rank's own part travels through RCCL too — ncclSend / ncclRecv to itself inside the
+  // group, the metadata through ncclAllGather — so that a ONE-rank communicator exercises every RCCL entry point)
+  const bool self_rccl = c->comm != nullptr && env_int("QHIP_COMM_SELF_RCCL", 0) != 0;
+  const size_t M = 2 + 2 * (size_t)n_cols;
+  const int n_mine = all_gather ? 1 : W;
+  for (int p = 0; p < n_mine; ++p) {
+    if (!parts[p] || (int)parts[p]->cols.size() != n_cols) fail(QHIP_INVALID_ARGUMENT, "exchange: a part is missing or has a different number of columns");
+    settle_rows(parts[p]);
+  }
+  comm_settle_time(c);
+  // ---- my parts' metadata and ONE send buffer with their wire images back to back (no wait: everything stays on the stream)
+  std::vector<int64_t> meta_out((size_t)W * M);
+  for (int p = 0; p < n_mine; ++p) table_wire_meta(ctx, parts[p], meta_out.data() + (size_t)p * M);
+  if (all_gather) for (int p = 1; p < W; ++p) memcpy(meta_out.data() + (size_t)p * M, meta_out.data(), M * 8);
+  std::vector<size_t> send_off((size_t)W + 1, 0);
+  for (int p = 0; p < n_mine; ++p) send_off[(size_t)p + 1] = send_off[(size_t)p] + align16((size_t)meta_out[(size_t)p * M + 1]);
+  DevBuf send_buf(send_off[(size_t)n_mine]);
+  for (int p = 0; p < n_mine; ++p)
+    table_pack(ctx, parts[p], send_buf.as<uint8_t>() + send_off[(size_t)p], meta_out[(size_t)p * M + 1], false);
+  auto send_ptr = [&](int dst) { return send_buf.as<uint8_t>() + (all_gather ? 0 : send_off[(size_t)dst]); };
+  // ---- what will I receive? every rank's metadata rows, all-gathered (fixed size: world x M words per rank); the one wait
+  std::vector<int64_t> meta_in((size_t)W * M);   // row r: the part rank r sends HERE
+  if (W == 1 && !self_rccl) memcpy(meta_in.data(), meta_out.data(), M * 8);
+  else {
+    const size_t words = (size_t)W * M;
+    DevBuf dmine(words * 8), dall(words * 8 * (size_t)W);
+    int64_t* stage = (int64_t*)ctx->pinned;
+    if ((words * (size_t)(W + 1)) * 8 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "exchange: metadata of this many columns x ranks exceeds the read-back scratch");
+    memcpy(stage, meta_out.data(), words * 8);
+    QHIP_HIP_CHECK(hipMemcpyAsync(dmine.ptr, stage, words * 8, hipMemcpyHostToDevice, s));
+    rccl_check(rccl().AllGather(dmine.ptr, dall.ptr, words, QH_NCCL_INT64, c->comm, s), "ncclAllGather (exchange metadata)");
+    int64_t* all = stage + words;
+    QHIP_HIP_CHECK(hipMemcpyAsync(all, dall.ptr, words * 8 * (size_t)W, hipMemcpyDeviceToHost, s));
+    QHIP_HIP_CHECK(sync_stream(s));
+    ++c->stats.host_waits;
+    for (int r = 0; r < W; ++r) memcpy(meta_in.data() + (size_t)r * M, all + ((size_t)r * W + (size_t)me) * M, M * 8);
+  }
+  // ---- the images: one group of point-to-point operations, my own part by a device copy
+  std::vector<size_t> recv_off((size_t)W + 1, 0);
+  for (int r = 0; r < W; ++r) recv_off[(size_t)r + 1] = recv_off[(size_t)r] + align16((size_t)meta_in[(size_t)r * M + 1]);
+  DevBuf recv_buf(recv_off[(size_t)W]);
+  QHIP_HIP_CHECK(hipEventRecord(c->ev[0], s));
+  const size_t own = (size_t)meta_in[(size_t)me * M + 1];
+  if (own && !self_rccl) QHIP_HIP_CHECK(hipMemcpyAsync(recv_buf.as<uint8_t>() + recv_off[(size_t)me], send_ptr(me), own, hipMemcpyDeviceToDevice, s));
+  if (W > 1 || self_rccl) {
+    rccl_check(rccl().GroupStart(), "ncclGroupStart");
+    for (int r = 0; r < W; ++r) {
+      if (r == me && !self_rccl) continue;
+      const size_t out_bytes = (size_t)meta_out[(size_t)r * M + 1], in_bytes = (size_t)meta_in[(size_t)r * M + 1];
+      if (out_bytes) { rccl_check(rccl().Send(send_ptr(r), out_bytes, QH_NCCL_UINT8, r, c->comm, s), "ncclSend"); c->stats.bytes_sent += out_bytes; }
+      if (in_bytes) { rccl_check(rccl().Recv(recv_buf.as<uint8_t>() + recv_off[(size_t)r], in_bytes, QH_NCCL_UINT8, r, c->comm, s), "ncclRecv"); c->stats.bytes_received += in_bytes; }
+    }
+    rccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  }
+  QHIP_HIP_CHECK(hipEventRecord(c->ev[1], s));
+  c->timed = true;
+  for (int p = 0; p < W; ++p) c->stats.bytes_packed += (uint64_t)meta_out[(size_t)p * M + 1];
+  ++c->stats.exchanges;
+  // ---- unpack straight into the concatenated table (stream-ordered: the buffers go back to the pool behind it)
+  std::vector<const void*> images((size_t)W);
+  for (int r = 0; r < W; ++r) images[(size_t)r] = meta_in[(size_t)r * M + 1] ? recv_buf.as<uint8_t>() + recv_off[(size_t)r] : nullptr;
+  return table_unpack_concat(ctx, names, dtypes, n_cols, meta_in.data(), images.data(), W, false);
+}
+}  // namespace
+
+extern "C" {
+
+int qhip_comm_unique_id(void* id_out, size_t id_bytes) {
+  if (!id_out || id_bytes < 128) return QHIP_INVALID_ARGUMENT;
+  return guarded(nullptr, [&] {
+    qh_nccl_unique_id id;
+    rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id_out, &id, 128);
+  });
+}
+
+int qhip_comm_create(qhip_ctx* ctx, const void* unique_id, int32_t rank, int32_t world, qhip_comm** out) {
+  if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id)) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+    std::unique_ptr<qhip_comm> c(new qhip_comm());
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    memset(&c->stats, 0, sizeof c->stats);
+    for (auto& e : c->ev) QHIP_HIP_CHECK(hipEventCreate(&e));
+    if (world > 1 || env_int("QHIP_COMM_FORCE_RCCL", 0) != 0) {
+      // (QHIP_COMM_FORCE_RCCL=1: a ONE-rank communicator is a real RCCL communicator too — the one-GPU rehearsal of the init path)
+      qh_nccl_unique_id id;
+      if (unique_id) memcpy(&id, unique_id, 128);
+      else rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+      rccl_check(rccl().CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+      int v = 0;
+      if (rccl().GetVersion && rccl().GetVersion(&v) == 0) c->stats.rccl_version = v;
+    }
+    *out = c.release();
+  });
+}
+
+void qhip_comm_destroy(qhip_comm* c) {
+  if (!c) return;
+  if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  delete c;
+}
+
+int qhip_comm_get_stats(qhip_comm* c, qhip_comm_stats* out, int32_t reset) {
+  if (!c || !out) return QHIP_INVALID_ARGUMENT;
+  comm_settle_time(c);
+  *out = c->stats;
+  out->rank = c->rank; out->world = c->world;
+  if (reset) { const int32_t v = c->stats.rccl_version; memset(&c->stats, 0, sizeof c->stats); c->stats.rccl_version = v; }
+  return QHIP_OK;
+}
+
+int qhip_exchange_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* const* parts, const char* const* names, const qhip_dtype* dtypes,
+                         int32_t n_cols, qhip_table** out) {
+  if (!ctx || !comm || !parts || !out || n_cols < 0 || (n_cols > 0 && !dtypes) || comm->ctx != ctx) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = comm_exchange(ctx, comm, parts, false, names, dtypes, n_cols); });
+}
+
+int qhip_all_gather_table(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* t, const char* const* names, const qhip_dtype* dtypes, int32_t n_cols,
+                          qhip_table** out) {
+  if (!ctx || !comm || !t || !out || n_cols < 0 || (n_cols > 0 && !dtypes) || comm->ctx != ctx) return QHIP_INVALID_ARGUMENT;
+  *out = nullptr;
+  return guarded(ctx, [&] { *out = comm_exchange(ctx, comm, &t, true, names, dtypes, n_cols); });
+}
+
+}  // extern "C"
+
+namespace {
 }  // namespace
 
 extern "C" {

@@ -48,16 +48,101 @@ def _exchange_world(dist) -> int:
     return world if world > 1 or os.environ.get("QHIP_EXCHANGE_FORCE") == "1" else 0
 
 
+class qhip_comm_stats(C.Structure):
+    _fields_ = [("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("bytes_packed", C.c_uint64), ("exchanges", C.c_uint64),
+                ("host_waits", C.c_uint64), ("transfer_seconds", C.c_double), ("rank", C.c_int32), ("world", C.c_int32),
+                ("rccl_version", C.c_int32), ("reserved", C.c_int32)]
+
+
+def transport() -> str:
+    """Who moves the wire images: "rccl" = libqhip's own communicator (qhip_exchange_tables / qhip_all_gather_table: RCCL
+    dlopen'ed inside the library, everything on the context's stream, ONE host wait per exchange — what a torch-less host
+    binds, include/qhip.h) or "torch" = torch.distributed point-to-point operations over device buffers. QHIP_TRANSPORT
+    chooses; default: rccl when the process group runs on the nccl (= RCCL) backend, torch otherwise (gloo moves host memory)."""
+    want = os.environ.get("QHIP_TRANSPORT", "")
+    if want in ("rccl", "torch"):
+        return want
+    dist = _dist()
+    return "rccl" if dist.is_initialized() and dist.get_backend() == "nccl" else "torch"
+
+
+_COMM = {}
+
+
+def get_comm(ctx=None):
+    """libqhip's communicator over the ranks of torch.distributed's default group (created once per process): rank 0 draws
+    the ncclUniqueId, the process group only carries its 128 bytes to the other ranks."""
+    import torch
+    ctx = ctx or get_context()
+    if "h" in _COMM:
+        return _COMM["h"]
+    dist = _dist()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lib = ctx.lib
+    lib.qhip_comm_unique_id.restype = C.c_int
+    lib.qhip_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    lib.qhip_comm_create.restype = C.c_int
+    lib.qhip_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.qhip_comm_get_stats.restype = C.c_int
+    lib.qhip_comm_get_stats.argtypes = [C.c_void_p, C.POINTER(qhip_comm_stats), C.c_int32]
+    lib.qhip_exchange_tables.restype = C.c_int
+    lib.qhip_exchange_tables.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_char_p), C.POINTER(_ffi.qhip_dtype), C.c_int32,
+                                         C.POINTER(C.c_void_p)]
+    lib.qhip_all_gather_table.restype = C.c_int
+    lib.qhip_all_gather_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(_ffi.qhip_dtype), C.c_int32,
+                                          C.POINTER(C.c_void_p)]
+    ident = (C.c_uint8 * 128)()
+    if world > 1:
+        if rank == 0:
+            rc = lib.qhip_comm_unique_id(ident, 128)
+            if rc != 0:
+                _ffi._raise(rc, lib.qhip_last_error(None).decode())
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+    h = C.c_void_p()
+    ctx.check(lib.qhip_comm_create(ctx.handle, ident if world > 1 else None, rank, world, C.byref(h)))
+    _COMM["h"], _COMM["ctx"] = h, ctx
+    return h
+
+
+def _schema_arrays(schema):
+    ncols = len(schema)
+    names = (C.c_char_p * max(1, ncols))(*[f.name.encode() for f in schema])
+    dtypes = (_ffi.qhip_dtype * max(1, ncols))(*[to_qhip_dtype(f.type) for f in schema])
+    return names, dtypes, ncols
+
+
+def _comm_stats_into(reset: bool):
+    """fold libqhip's communicator counters into _STATS (and clear them there)"""
+    if "h" not in _COMM:
+        return
+    st = qhip_comm_stats()
+    _COMM["ctx"].check(_COMM["ctx"].lib.qhip_comm_get_stats(_COMM["h"], C.byref(st), 1 if reset else 0))
+    _STATS["bytes_sent"] += int(st.bytes_sent)
+    _STATS["bytes_received"] += int(st.bytes_received)
+    _STATS["bytes_packed"] += int(st.bytes_packed)
+    _STATS["exchanges"] += int(st.exchanges)
+    _STATS["seconds"] += float(st.transfer_seconds)
+    _STATS["transport_waits"] = _STATS.get("transport_waits", 0) + int(st.host_waits)
+    _STATS["rccl_version"] = int(st.rccl_version)
+
+
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
-_STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0, "heavy_keys": 0, "probe_rows_received": 0}
+_STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0, "heavy_keys": 0, "probe_rows_received": 0,
+          "transport_waits": 0, "heavy_key_rounds": 0}
 
 
 def exchange_stats(reset: bool = True) -> dict:
     """Totals since the last reset plus the derived GB/s per rank (to compare with 7 links x 153 GB/s of xGMI)."""
+    _comm_stats_into(reset)
     out = dict(_STATS)
     out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
     if reset:
-        _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0, heavy_keys=0, probe_rows_received=0)
+        _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0, heavy_keys=0, probe_rows_received=0,
+                      transport_waits=0, heavy_key_rounds=0)
     return out
 
 
@@ -125,6 +210,7 @@ def all_to_all_bytes(send: Sequence["torch.Tensor"], group=None, meta: Optional[
     _STATS["seconds"] += time.perf_counter() - t_start
     _STATS["bytes_packed"] += sum(int(t.numel()) for t in send)     # incl. the part that stays on this rank
     _STATS["exchanges"] += 1
+    _STATS["transport_waits"] = _STATS.get("transport_waits", 0) + (2 if dev.type == "cuda" else 0)   # the header read-back + the final synchronize
     return recv
 
 
@@ -222,6 +308,13 @@ def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> 
     images are unpacked straight into the concatenated table."""
     dist = _dist()
     assert len(parts) == dist.get_world_size(group)
+    if group is None and transport() == "rccl":
+        ctx = parts[0].ctx
+        names, dtypes, ncols = _schema_arrays(schema)
+        hs = (C.c_void_p * len(parts))(*[p.handle for p in parts])
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_exchange_tables(ctx.handle, get_comm(ctx), hs, names, dtypes, ncols, C.byref(out)))
+        return DeviceTable(ctx, out)
     packed = [pack_table(p) for p in parts]
     got = all_to_all_bytes([img for _, img in packed], group, meta=[m for m, _ in packed])
     return unpack_concat(parts[0].ctx, schema, got.meta, got)
@@ -324,17 +417,36 @@ class DeviceSource(PhysicalPlan):
 # therefore found on a SAMPLE first; their probe rows stay where they are and their (few) build rows are broadcast.
 HEAVY_SAMPLE_STRIDE = 64      # every 64th probe row is counted
 HEAVY_CANDIDATES = 64         # per rank: its most frequent sampled keys (a globally heavy key is among the top 4 n <= 32 somewhere)
+HEAVY_REFRESH = 16            # executions of one join plan between two samplings of its probe side
 
 
 def heavy_keys(local_top: Sequence[Tuple[object, int]], local_sample_rows: int, group=None) -> List[object]:
     """The globally heavy keys, identical on every rank: every rank contributes its most frequent sampled keys with their
-    counts and its sample size (one small all-gather of Python objects); a key is heavy when the sum of its reported counts
-    exceeds total sample / (4 world). (A key not among some rank's candidates is under-counted there by less than that
-    rank's 1/HEAVY_CANDIDATES share: only keys right at the threshold can be missed, and missing one costs balance only.)"""
+    counts and its sample size; a key is heavy when the sum of its reported counts exceeds total sample / (4 world). (A key
+    not among some rank's candidates is under-counted there by less than that rank's 1/HEAVY_CANDIDATES share: only keys
+    right at the threshold can be missed, and missing one costs balance only.)
+    Integer keys travel as ONE fixed-shape int64 tensor all-gather ([sample rows | HEAVY_CANDIDATES x (key, count)]: no
+    pickling, no size round); other key types (strings) fall back to an all-gather of Python objects."""
+    import torch
     dist = _dist()
     world = dist.get_world_size(group)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (list(local_top), int(local_sample_rows)), group=group)
+    local_top = [(k, int(c)) for k, c in local_top if k is not None][:HEAVY_CANDIDATES]
+    ints = all(isinstance(k, int) and -(1 << 63) <= k < (1 << 63) for k, _ in local_top)
+    row = [int(local_sample_rows)]
+    for k, c in (local_top if ints else []):
+        row += [int(k), int(c)]
+    row += [0, 0] * (HEAVY_CANDIDATES - (len(local_top) if ints else 0))
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor(row + [1 if ints else 0], dtype=torch.int64, device=dev)     # last word: "my keys are integers"
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine, group=group)                                      # (every rank, whatever its key type)
+    rows = [t.cpu().tolist() for t in everyone]
+    if all(r[-1] == 1 for r in rows):
+        gathered = [([(r[1 + 2 * j], r[2 + 2 * j]) for j in range(HEAVY_CANDIDATES) if r[2 + 2 * j] > 0], r[0]) for r in rows]
+    else:   # some rank holds non-integer keys: every rank saw that in the flag words and takes the object path
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (list(local_top), int(local_sample_rows)), group=group)
+    _STATS["heavy_key_rounds"] = _STATS.get("heavy_key_rounds", 0) + 1
     total = sum(n for _, n in gathered)
     counts = {}
     for top, _ in gathered:
@@ -430,8 +542,17 @@ class DistributedHashJoinExec(HashJoinExec):
             lkey, rkey = self.on[0]
             rdtype = _expr_type(rkey, rs)
             if rdtype is not None:
-                top, n_sample = _local_top_keys(right, rw, rkey, rdtype)
-                keys = heavy_keys(top, n_sample)
+                # the heavy-key set is a learnt property of the join like its pair counts: found on the first execution and
+                # kept, refreshed every HEAVY_REFRESH executions (all ranks count executions alike, so they refresh together);
+                # a stale set costs balance, never correctness (the two predicates split the rows exactly whatever the keys)
+                cached = getattr(self, "_heavy_cache", None)
+                if cached is not None and cached[0] == world and cached[2] > 0 and os.environ.get("QHIP_EXCHANGE_NO_HEAVY_CACHE") != "1":
+                    keys = cached[1]
+                    self._heavy_cache = (world, keys, cached[2] - 1)
+                else:
+                    top, n_sample = _local_top_keys(right, rw, rkey, rdtype)
+                    keys = heavy_keys(top, n_sample)
+                    self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
                 hl, ll = heavy_split_predicates(lkey, _expr_type(lkey, ls), keys) if keys else (None, None)
                 hr, lr = heavy_split_predicates(rkey, rdtype, keys) if keys else (None, None)
                 if hl is not None and hr is not None:
@@ -460,6 +581,12 @@ def _expr_type(e: PhysicalExpr, schema):
 def all_gather_device_table(table: DeviceTable, schema, group=None) -> DeviceTable:
     """Every rank ends up with the concatenation (rank order) of all ranks' tables."""
     world = _dist().get_world_size(group)
+    if group is None and transport() == "rccl":
+        ctx = table.ctx
+        names, dtypes, ncols = _schema_arrays(schema)
+        out = C.c_void_p()
+        ctx.check(ctx.lib.qhip_all_gather_table(ctx.handle, get_comm(ctx), table.handle, names, dtypes, ncols, C.byref(out)))
+        return DeviceTable(ctx, out)
     meta, img = pack_table(table)          # packed once, the same image goes to every peer
     got = all_to_all_bytes([img] * world, group, meta=[meta] * world)
     return unpack_concat(table.ctx, schema, got.meta, got)

@@ -21,6 +21,11 @@ import qurious_amd as q  # noqa: E402
 from qurious_amd import exchange, queries, synth  # noqa: E402
 
 
+# host waits (stream synchronisations inside libqhip, the transport's included) of one REPEATED Q3 through the multi-rank
+# operators, measured on the one-rank rehearsal; asserted as ceilings
+WAIT_CEILING = {"repartition": 40, "broadcast": 40}
+
+
 def rows_of(batches):
     out = []
     for b in batches:
@@ -96,6 +101,10 @@ def main():
         print("REHEARSAL OK")
         return
     os.environ["QHIP_EXCHANGE_FORCE"] = "1"
+    # libqhip's own transport (qhip_exchange_tables / qhip_all_gather_table) over a REAL one-rank RCCL communicator whose own
+    # part travels through ncclSend / ncclRecv / ncclAllGather too: every RCCL entry point the library binds is executed
+    os.environ["QHIP_COMM_FORCE_RCCL"] = "1"
+    os.environ["QHIP_COMM_SELF_RCCL"] = "1"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
     ctx = q.get_context()
@@ -114,21 +123,39 @@ def main():
         plain = queries.q3(*tabs)
         want = rows_of(plain.execute())
         assert want == rows_of(qoracle.execute(plain)) and len(want) > 100
-        wire = {}
+        wire, waits = {}, {}
         for prune in (False, True):
-            for name, plan in (("repartition", queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)),
-                               ("broadcast", queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
-                if prune:
-                    exchange.prune_exchange_columns(plan)
-                exchange.exchange_stats()
-                got = rows_of(plan.execute_device().to_batches())
-                st = exchange.exchange_stats()
-                assert st["exchanges"] >= 3, st     # the exchange steps really ran
-                assert got == want, f"{name}: distributed plan differs from the single-process plan"
-                wire[(name, prune)] = st["bytes_packed"]
-                print(f"[rehearsal] {name}{' (pruned columns)' if prune else ''}: {len(got)} groups equal to the plain plan and the oracle; "
-                      f"{st['exchanges']} exchanges, {st['bytes_packed'] / 1e6:.1f} MB of wire images")
-        assert wire[("repartition", True)] < wire[("repartition", False)] and wire[("broadcast", True)] < wire[("broadcast", False)]
+            for name, make in (("repartition", lambda: queries.q3(*tabs, join_cls=exchange.DistributedHashJoinExec)),
+                               ("broadcast", lambda: queries.q3(*tabs, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
+                for transport in ("rccl", "torch"):     # libqhip's communicator / torch.distributed point-to-point: bit for bit the same
+                    os.environ["QHIP_TRANSPORT"] = transport
+                    plan = make()
+                    if prune:
+                        exchange.prune_exchange_columns(plan)
+                    for execution in range(3):          # (from the second execution on the heavy-key set is remembered)
+                        exchange.exchange_stats()
+                        before = ctx.sync_count()
+                        t_dev = plan.execute_device()
+                        lib_waits = ctx.sync_count() - before
+                        got = rows_of(t_dev.to_batches())
+                        st = exchange.exchange_stats()
+                        assert st["exchanges"] >= 3, st     # the exchange steps really ran
+                        assert got == want, f"{name} over {transport}: distributed plan differs from the single-process plan"
+                    if transport == "rccl":
+                        assert st["rccl_version"] > 0, st   # a real RCCL communicator moved the images
+                    wire[(name, prune, transport)] = st["bytes_packed"]
+                    waits[(name, prune, transport)] = (lib_waits, st["transport_waits"], st["heavy_key_rounds"])
+                    print(f"[rehearsal] {name}{' (pruned columns)' if prune else ''} over {transport}: {len(got)} groups equal to the plain plan and the "
+                          f"oracle; {st['exchanges']} exchanges, {st['bytes_packed'] / 1e6:.1f} MB of wire images; host waits of a repeated query: "
+                          f"{lib_waits} in libqhip (incl. the transport's {st['transport_waits'] if transport == 'rccl' else 0}) + "
+                          f"{st['transport_waits'] if transport == 'torch' else 0} in torch; heavy-key rounds {st['heavy_key_rounds']}")
+                os.environ.pop("QHIP_TRANSPORT", None)
+        for name in ("repartition", "broadcast"):
+            assert wire[(name, True, "rccl")] < wire[(name, False, "rccl")] and wire[(name, True, "rccl")] == wire[(name, True, "torch")]
+            # the host-wait budget of a REPEATED query through libqhip's transport (ceilings asserted so that a regression shows):
+            # no heavy-key sampling any more, ONE wait per exchange inside the transport
+            lib_waits, transport_waits, heavy_rounds = waits[(name, True, "rccl")]
+            assert heavy_rounds == 0 and transport_waits <= 5 and lib_waits <= WAIT_CEILING[name], (name, waits)
         # a join output with NULLs and strings through the exchange (Full join: both sides padded)
         import numpy as np
         import pyarrow as pa
