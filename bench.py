@@ -17,7 +17,7 @@ sides by key hash; both are measured at N > 1, `value` uses --strategy).
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries
   roofline      the step's dominant kernel (Q1's fused filter + aggregate): bytes the kernel actually reads per launch /
                 its mean device time (HIP events on the library's stream) against the 8 TB/s HBM peak; `traffic` = HBM
-                bytes per launch from this round's PMC profile (profiles/r02_pmc_summary.json) when that profile was taken
+                bytes per launch from this round's PMC profile (profiles/r03_pmc_summary.json) when that profile was taken
                 on the same kernel, row count and bytes per row — otherwise null with the reason
   cpu_baseline  the CPU oracle (oracle/qoracle.c, a faithful-cost restatement of the reference executor, 1 thread because
                 the reference is single-threaded) on a bounded sample of the same two queries: 1 warm-up + median of 5
@@ -50,7 +50,8 @@ Q3_SURVEY_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 XGMI_PEAK_GBS = 7 * 153.0                               # 7 links x ~153 GB/s per GPU
 SF10_LINEITEM_ROWS = 59_986_052
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+SETTLE_STEPS = 3   # untimed executions in front of the W warm-up steps: a plan reaches its steady state on its third execution
 
 USE_DIST = False   # set by main(): a torch.distributed process group (RCCL) is up
 
@@ -94,7 +95,10 @@ class Clock:
         self.ctx.synchronize()
 
     def run(self, step, steps, warmup):
-        for _ in range(warmup):
+        # (a hash join runs with its size left on the device only from the execution after the one that remembered it, and its
+        # consumer from the execution after that: three untimed executions in front of the W warm-up steps settle that,
+        # whatever W is — first_execution_ms in the records says what the very first one costs)
+        for _ in range(SETTLE_STEPS + warmup):
             step()
         self.barrier()
         t0 = time.perf_counter()
@@ -152,7 +156,7 @@ def pmc_traffic(workload, kernel, rows, bytes_per_row):
         if k.get("kernel") != kernel:
             continue
         if int(k.get("rows", -1)) == int(rows) and abs(float(k.get("kernel_bytes_per_row", -1)) - float(bytes_per_row)) < 1e-6:
-            return k.get("hbm_bytes_per_launch"), f"{os.path.relpath(PMC_SUMMARY, ROOT)} ({prof.get('collected', 'r02')})"
+            return k.get("hbm_bytes_per_launch"), f"{os.path.relpath(PMC_SUMMARY, ROOT)} ({prof.get('collected', 'r03')})"
         seen.append(f"rows={k.get('rows')} bytes/row={k.get('kernel_bytes_per_row')}")
     if seen:
         return None, f"profile has {kernel} at {'; '.join(seen)} — this run: rows={rows} bytes/row={bytes_per_row}"
@@ -166,6 +170,30 @@ def roofline(kernel, kernel_ms, bytes_per_launch, traffic=None, traffic_source=N
          "bytes_read_per_launch": bytes_per_launch}
     r.update(extra)
     return r
+
+
+def cold_and_export_ms(ctx, make_plan, runs=3):
+    """(first_execution_ms, execute_with_export_ms): the first execution of a NEW plan object after the context forgot what it
+    had learnt about earlier plans (qhip_ctx_forget_plans: lowered plans, join sizes, group counts — compiled kernels stay
+    loaded, table-column statistics stay), through to the synchronised device result; and a repeated `execute()` of a warm
+    plan through to host Arrow batches (the reference's contract: PhysicalPlan::execute -> Vec<RecordBatch>). Medians of `runs`."""
+    cold, export = [], []
+    for _ in range(runs):
+        ctx.synchronize()
+        ctx.forget_plans()
+        plan = make_plan()
+        t0 = time.perf_counter()
+        plan.execute_device()
+        ctx.synchronize()
+        cold.append((time.perf_counter() - t0) * 1e3)
+    plan = make_plan()
+    for _ in range(SETTLE_STEPS):
+        plan.execute()
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        plan.execute()
+        export.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(cold), statistics.median(export)
 
 
 def median_runs(fn, runs=5):
@@ -259,6 +287,8 @@ class Q1:
                                     algorithmic_bytes_per_row=SURVEY_BYTES_PER_ROW[self.workload], kernel_bytes_per_row=bpr,
                                     rows_per_launch=self.rows),
                "cpu_baseline": None}
+        if not USE_DIST:
+            rec["first_execution_ms"], rec["execute_with_export_ms"] = cold_and_export_ms(self.ctx, lambda: getattr(queries, self.workload)(self.table))
         if with_cpu:
             rec["cpu_baseline"] = cpu_scan_aggregate(self.workload, self.table, self.batch_rows, args.cpu_sample_rows)
         return rec, elapsed
@@ -344,7 +374,9 @@ class Q3:
         ex = self.exchange
         if USE_DIST:
             ex.exchange_stats(reset=True)
+        waits_before = self.ctx.sync_count()
         elapsed = clock.run(lambda: self.step(strategy), args.steps, args.warmup)
+        lib_waits = self.ctx.sync_count() - waits_before - 2   # (minus the clock's own two synchronisations)
         xg = ex.exchange_stats(reset=True) if USE_DIST else None
         tot = self.totals(torch, dist)
         ops = operator_stats(lambda: self.step(strategy), passes=3)
@@ -353,11 +385,22 @@ class Q3:
         kernels = []
         for k, j in enumerate(joins):
             pb = j["rows_in"] * j["bytes_per_row_read"]
-            t, src = pmc_traffic("q3", "qk_join_probe", j["rows_in"], j["bytes_per_row_read"])
-            kernels.append(dict(roofline("qk_join_probe", j["main_kernel_ms"], pb, t, src, kernel_bytes_per_row=j["bytes_per_row_read"],
-                                         rows_per_launch=j["rows_in"]), operator=f"join {k + 1} probe", pairs=j["groups"]))
-            bb = j["build_rows"] * j["build_bytes_per_row"] + j["table_capacity"] * 17.0   # key columns read + table and filter written
-            kernels.append(dict(roofline("qk_join_scatter + k_join_region_build", j["build_ms"], bb, None, "not profiled per launch",
+            pname = j["main_kernel_name"]
+            dense = pname == "qk_join_probe_dense"
+            t, src = pmc_traffic("q3", pname, j["rows_in"], j["bytes_per_row_read"])
+            if t is not None:
+                src += ("; FETCH_SIZE x 2 is calibrated for wide streaming reads (MI355X_MICROARCH.md): the random 4 / 8 / 16-byte lookups of "
+                        "a probe make its traffic an UPPER bound")
+            kernels.append(dict(roofline(pname, j["main_kernel_ms"], pb, t, src, kernel_bytes_per_row=j["bytes_per_row_read"],
+                                         rows_per_launch=j["rows_in"]), operator=f"join {k + 1} probe", pairs=j["groups"],
+                                table_layout="dense: exact bitmap over the key range + row_of[key - min]" if dense else "hashed: open addressing + blocked filter"))
+            if dense:   # key columns read + bitmap cleared and set + one row_of entry written per build row
+                bb = j["build_rows"] * (j["build_bytes_per_row"] + 4.0) + j["table_capacity"] / 8.0 * 2
+                bname = "memset + qk_join_dense_build"
+            else:       # key columns read + table and filter written
+                bb = j["build_rows"] * j["build_bytes_per_row"] + j["table_capacity"] * 17.0
+                bname = "qk_join_scatter + k_join_region_build"
+            kernels.append(dict(roofline(bname, j["build_ms"], bb, None, "not profiled per launch",
                                          rows_per_launch=j["build_rows"], table_slots=j["table_capacity"]), operator=f"join {k + 1} build"))
         for a in aggs:
             kernels.append(dict(roofline(a["main_kernel_name"], a["main_kernel_ms"], a["rows_in"] * a["bytes_per_row_read"], None,
@@ -376,14 +419,23 @@ class Q3:
                "roofline": dominant, "kernels": kernels,
                "survey_algorithmic_bytes": survey, "survey_algorithmic_GBps_of_wall_time": survey / (elapsed / args.steps) / 1e9 / self.world,
                "device_ms_per_query": {"join": [j["total_device_ms"] for j in joins], "aggregate_kernel": [a["main_kernel_ms"] for a in aggs]},
+               "host_waits_per_query": lib_waits / (SETTLE_STEPS + args.warmup + args.steps),
                "cpu_baseline": None}
+        if not USE_DIST and not self.slice_of:
+            rec["first_execution_ms"], rec["execute_with_export_ms"] = cold_and_export_ms(self.ctx, lambda: queries.q3(*self.tabs))
         if xg:
-            nq = args.steps + args.warmup   # queries since the counters were reset
+            nq = args.steps + args.warmup + SETTLE_STEPS   # queries since the counters were reset
             secs = max(xg.get("seconds", 0.0), 1e-12)
             rec["exchange"] = {"bytes_sent_per_query": xg.get("bytes_sent", 0) / nq, "bytes_received_per_query": xg.get("bytes_received", 0) / nq,
                                "seconds_per_query": xg.get("seconds", 0.0) / nq, "exchanges_per_query": xg.get("exchanges", 0) / nq,
                                "send_GBps": xg.get("bytes_sent", 0) / secs / 1e9, "xgmi_peak_GBps": XGMI_PEAK_GBS,
-                               "frac_of_xgmi": xg.get("bytes_sent", 0) / secs / 1e9 / XGMI_PEAK_GBS, "note": "rank 0 only"}
+                               "frac_of_xgmi": xg.get("bytes_sent", 0) / secs / 1e9 / XGMI_PEAK_GBS,
+                               "transport": ex.transport(), "rccl_version_seen_by_libqhip": xg.get("rccl_version"),
+                               # host waits of a query: stream synchronisations inside libqhip (its own transport's included)
+                               # plus, with the torch transport, torch's header read-backs / synchronisations
+                               "host_waits_per_query": (lib_waits + (xg.get("transport_waits", 0) if ex.transport() == "torch" else 0)) / nq,
+                               "transport_waits_per_query": xg.get("transport_waits", 0) / nq,
+                               "heavy_key_rounds_per_query": xg.get("heavy_key_rounds", 0) / nq, "note": "rank 0 only"}
         if with_cpu:
             rec["cpu_baseline"] = cpu_q3(min(self.sf, args.cpu_q3_sf))
         return rec, elapsed
@@ -485,7 +537,10 @@ def main():
     with_cpu = not args.no_cpu_baseline and world == 1 and not USE_DIST
     log("torch imported")
     line = {"metric": METRIC, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-            "vs_baseline": None, "dtype": "i128", "data": "synthetic", "device": ctx.device_name()}
+            "vs_baseline": None, "dtype": "i128", "data": "synthetic", "device": ctx.device_name(),
+            "state": f"warm: the timed steps repeat cached plans over resident tables ({SETTLE_STEPS} untimed settling executions + W warm-up "
+                     "steps first: learnt join sizes, one host wait per query, remembered group counts); records.*.first_execution_ms = a new "
+                     "plan with that knowledge forgotten (code cache warm), records.*.execute_with_export_ms = through execute() to host Arrow batches"}
     if USE_DIST:
         line["distributed"] = {"world_size": dist.get_world_size(), "backend": "nccl (RCCL)", "rccl_version": rccl}
 
@@ -544,6 +599,23 @@ def main():
     if USE_DIST:
         other = "repartition" if args.strategy == "broadcast" else "broadcast"
         records[f"q3_sf10_{other}"], _ = q3.record(args, clock, torch, dist, False, strategy=other)
+    if USE_DIST and os.environ.get("QHIP_BENCH_NO_SF100") != "1":
+        # BASELINE configs[4]: Q3 with Zipf(1.1) join keys, every rank holding what ONE OF EIGHT ranks holds at SF100 (12.5
+        # scale-factor units per rank: exactly SF100 at N = 8, SF25 / SF50 at N = 2 / 4) — the size at which a rank's local
+        # work dwarfs the exchange; both strategies, the aggregate's LDS-table occupancy and the exchange's GB/s against xGMI
+        try:
+            za = argparse.Namespace(**vars(args))
+            za.sf, za.skew, za.steps, za.warmup = float(os.environ.get("QHIP_BENCH_ZIPF_SF", 12.5 * world)), 1.1, max(2, min(args.steps, 5)), 1
+            del q3
+            zq = Q3(za, ctx, rank, world, args.strategy)
+            zrec, _ = zq.record(za, clock, torch, dist, False)
+            zrec["aggregate_table"] = zq.table_stats()
+            other = "repartition" if args.strategy == "broadcast" else "broadcast"
+            orec, _ = zq.record(za, clock, torch, dist, False, strategy=other)
+            zrec["other_strategy"] = {k: orec[k] for k in ("strategy", "value", "ms_per_step", "exchange", "groups") if k in orec}
+            records["q3_sf100_zipf"] = zrec
+        except Exception as e:   # the headline line must not depend on this record
+            records["q3_sf100_zipf_error"] = f"{type(e).__name__}: {e}"
     cpu = None
     if with_cpu:
         c1, c3 = records["q1_sf10"]["cpu_baseline"], records["q3_sf10"]["cpu_baseline"]

@@ -219,6 +219,12 @@ int qhip_ctx_set_timing(qhip_ctx* ctx, int32_t on);
  * No reference counterpart. */
 int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta);
 int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
+/* Forget what the context has LEARNT about the plans it ran — lowered plans, remembered join output sizes, duplicate-key
+ * flags, the aggregates' group counts and pre-zeroed tables — while compiled kernels stay loaded: the next execution of a
+ * query is then a first execution with a warm code cache (what the reference's caller sees for every new
+ * `session.sql`, execution/session.rs:74-104: it builds a new plan each time). Statistics cached on TABLE columns (value
+ * ranges, longest strings) are properties of the data and stay. bench.py measures first_execution_ms this way. */
+int qhip_ctx_forget_plans(qhip_ctx* ctx);
 
 /* ---------------------------------------------------------------- tables (Vec<RecordBatch> in HBM) */
 /* Upload n_batches struct-typed ArrowArrays (one per RecordBatch, children = columns)

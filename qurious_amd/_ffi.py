@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
             "qhip_ctx_sync_count": (C.c_uint64, [vp]),
             "qhip_ctx_set_timing": (C.c_int, [vp, i32]),
             "qhip_ctx_allow_deferred_sizes": (C.c_int, [vp, i32]),
+            "qhip_ctx_forget_plans": (C.c_int, [vp]),
             "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
@@ -210,6 +211,10 @@ class Context:
     def sync_count(self) -> int:
         """Host waits on the device made through the library so far (the difference around a plan = its round trips)."""
         return int(self.lib.qhip_ctx_sync_count(self.handle))
+
+    def forget_plans(self):
+        """Drop everything learnt about executed plans (lowered plans, join sizes, group counts); compiled kernels stay."""
+        self.check(self.lib.qhip_ctx_forget_plans(self.handle))
 
     def allow_deferred_sizes(self, delta: int):
         self._allow_depth = 0 if delta == 0 else max(0, getattr(self, "_allow_depth", 0) + int(delta))

@@ -367,6 +367,18 @@ int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta) {
   return QHIP_OK;
 }
 
+int qhip_ctx_forget_plans(qhip_ctx* ctx) {
+  if (!ctx) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] {
+    QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+    QHIP_HIP_CHECK(sync_stream(ctx->stream));   // (plans own device arenas: nothing of theirs may still be in flight)
+    ctx->plan_cache.clear();
+    ctx->join_size_hints.clear();
+    ctx->join_dup_builds.clear();
+    ctx->pending_sizes.clear();
+  });
+}
+
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
   if (!ctx || !out) return QHIP_INVALID_ARGUMENT;
   if (ctx->stats_timing_pending) {

@@ -203,7 +203,8 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2", "--skew", "1.1"],
                        env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and "heavy keys per rank" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-    env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.update(QHIP_BENCH_FORCE_DIST="1", QHIP_EXCHANGE_FORCE="1", MASTER_PORT="29549", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               QHIP_BENCH_ZIPF_SF="0.2")   # (the configs[4] record of the N > 1 line at a size that fits a test)
     # (1) exactly the command the driver's scaling run issues per rank (default workload: the metric's step = Q1 at SF10 +
     # Q3 at SF10), with the multi-rank branch forced on: Q1 partial groups merged through an all-gather, Q3 through both
     # exchange strategies; (2) single-configuration modes at small sizes
@@ -222,6 +223,13 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
             assert rec["q3_sf10"]["groups"] == rec["q3_sf10_repartition"]["groups"] > 100000
             assert rec["q3_sf10"]["exchange"]["exchanges_per_query"] > 0 and line["exchange"]["bytes_sent_per_query"] >= 0
             assert line["roofline"]["kernel"] == "qk_filter_agg" and 0 < line["roofline"]["frac"] < 1
+            # configs[4] in the N > 1 line: Zipf(1.1) keys, both strategies, LDS-table occupancy, exchange rate against xGMI, host waits
+            z = rec["q3_sf100_zipf"]
+            assert "configs[4]" in z["workload"] and z["groups"] > 100 and z["other_strategy"]["groups"] == z["groups"]
+            assert 0 < z["aggregate_table"]["lds_occupancy"] <= 1 and z["aggregate_table"]["groups"] > 0
+            assert z["exchange"]["xgmi_peak_GBps"] == 7 * 153.0 and z["exchange"]["transport"] == "rccl"
+            assert 0 < z["exchange"]["host_waits_per_query"] < 60 and z["exchange"]["heavy_key_rounds_per_query"] <= 1
+            assert rec["q3_sf10"]["exchange"]["transport"] == "rccl" and rec["q3_sf10"]["exchange"]["host_waits_per_query"] < 60
         if "q3" in extra:
             assert line["exchange"]["exchanges_per_query"] > 0
 
