@@ -857,14 +857,24 @@ __device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32
   const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
   const int lane = qh_lane();
   u32 err = 0;
-  for (i64 j = wave_global; j < nwords; j += nwaves) {
-    const i64 i = j * 64 + lane;
-    const bool inb = i < a.nrows;
-    u32 e = 0;
-    const bool keep = P::pred(a, inb ? i : a.nrows - 1, e) && inb;
-    err |= inb ? e : 0u;
-    u64 m = qh_ballot(keep);
-    if (lane == 0) { mask[j] = m; wave_count[j] = (u32)__builtin_popcountll(m); }
+  // U consecutive words (64 U rows) per trip, evaluated back to back: the predicate's column loads of the U rows a lane
+  // owns are independent, so they are in flight together (one word per trip streamed a 4-byte column at 2.9 TB/s)
+  constexpr int U = 4;
+  for (i64 j0 = wave_global * U; j0 < nwords; j0 += nwaves * U) {
+    bool keep[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const i64 i = (j0 + u) * 64 + lane;
+      const bool inb = i < a.nrows;
+      u32 e = 0;
+      keep[u] = P::pred(a, inb ? i : a.nrows - 1, e) && inb;
+      err |= inb ? e : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u64 m = qh_ballot(keep[u]);
+      if (lane == 0 && j0 + u < nwords) { mask[j0 + u] = m; wave_count[j0 + u] = (u32)__builtin_popcountll(m); }
+    }
   }
   qh_report(status, err);
 }

@@ -13,7 +13,7 @@
 namespace qhip {
 
 void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, int root, DevBuf& mask,
-                   DevBuf& wave_count) {
+                   DevBuf& wave_count, uint32_t* status_dev) {
   const int64_t N = t->num_rows;
   const uint64_t nwords = (uint64_t)(N + 63) / 64;
   mask.alloc(nwords * 8);
@@ -25,13 +25,17 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
   HKArgs ka;
   DevBuf strlit;
   fill_kargs(ctx, t, mp.bind, ka, strlit);
-  QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
+  // status_dev: a pre-zeroed status block of the caller, who reads it back with whatever else it waits for (no memset,
+  // no wait here); nullptr: the context's block, checked before returning
+  if (!status_dev) QHIP_HIP_CHECK(hipMemsetAsync(ctx->status.ptr, 0, QS_WORDS * 4, ctx->stream));
   void* mptr = mask.ptr;
   void* wptr = wave_count.ptr;
-  void* sptr = ctx->status.ptr;
+  void* sptr = status_dev ? (void*)status_dev : ctx->status.ptr;
   void* args[] = {&ka, &mptr, &wptr, &sptr};
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 3) / 4, (uint64_t)ctx->num_cus * 8));
+  // (a wavefront takes 4 mask words per trip: 16 words per workgroup and trip)
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 15) / 16, (uint64_t)ctx->num_cus * 8));
   QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  if (status_dev) return;   // (the pooled literal buffer may be recycled: any later writer runs on the same stream, i.e. after this kernel)
   uint32_t status[QS_WORDS];
   QHIP_HIP_CHECK(hipMemcpyAsync(status, ctx->status.ptr, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
   QHIP_HIP_CHECK(sync_stream(ctx->stream));

@@ -18,7 +18,7 @@ void check_status_words(const uint32_t* st);
 // relops.cpp
 // keep-mask of `root` over every row of t: mask word j = ballot of rows 64j..64j+63, wave_count[j] = its popcount
 void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::vector<InputCol>& icols, int root, DevBuf& mask,
-                   DevBuf& wave_count);
+                   DevBuf& wave_count, uint32_t* status_dev = nullptr);
 // wave_count is scanned in place into per-wave output offsets; sel receives the kept row indices; returns their number
 uint32_t select_from_mask(Ctx* ctx, const DevBuf& mask, DevBuf& wave_count, int64_t nrows, DevBuf& sel);
 // ... in two steps: count_from_mask scans and returns the number of kept rows, indices_from_mask fills `sel` when (and if)
