@@ -500,8 +500,19 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
     const int pa_mode = env_int("QHIP_AGG_PARTITION", 1);
     // (an instrumented run, QHIP_AGG_STATS, measures the fused kernel's LDS table and keeps to it)
+    // Mid-sized inputs (2^18 .. 2^22 rows with >= 16 k groups — BASELINE configs[4]'s per-rank aggregate: 2 M joined rows ->
+    // 200 k groups, LDS tables 100 % full, 0.27-0.35 ms in the fused kernel) CAN take the same three passes without a host
+    // round trip in between (QHIP_AGG_PARTITION_MID=1: the reduce pass derives its work items — bin slices — from the scanned
+    // histogram on the device). Measured on that aggregate (round 3, rocprofv3): histogram 71 us + staged pass 168 us + reduce
+    // pass 317 us = 0.57 ms against the fused kernel's 0.35 ms — the input is read through the joins' index vectors (twice
+    // here) and Zipf's heavy keys serialise the LDS atomics of their bins, which the fused kernel's wave-resident hot keys
+    // avoid. Off by default; what this size needs is a combiner in front of the partitioning, not fewer host waits.
+    const bool mid = N < ((int64_t)1 << 22);
+    const bool mid_on = env_int("QHIP_AGG_PARTITION_MID", 0) != 0;
     bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
-                             (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768));
+                             (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768) ||
+                              (pa_mode == 1 && mid && N >= ((int64_t)1 << 18) && plan.last_groups >= 16384 && mid_on));
+    const bool device_items = partitioned && mid && (mid_on || pa_mode == 2);
     std::vector<uint32_t> item_first;   // (kept alive until the call's next synchronisation)
     // the record buffer is as big as the input's key + argument columns: when HBM cannot hold it the fused kernel runs
     DevBuf pa_records;
@@ -558,6 +569,28 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         QHIP_HIP_CHECK(hipModuleLaunchKernel(m_stage->fn, (unsigned)g1, 1, 1, 1024, 1, 1, (unsigned)stage_lds, s, pargs, nullptr));
       } else
         QHIP_HIP_CHECK(hipModuleLaunchKernel(m_scat->fn, (unsigned)g1, 1, 1, 256, 1, 1, n_bins * 4, s, pargs, nullptr));
+      if (device_items) {
+        // the bins' slices as work items, computed by the reduce kernel itself from the scanned histogram: a bin of `cnt`
+        // records is cut into `slices` slices of at least 4 096 records (a heavy key's bin is aggregated by several
+        // workgroups, each merging its LDS table into the HBM table); empty slices return at once
+        HReduceLaunch rl;
+        rl.records = records.as<uint64_t>();
+        rl.item_first = nullptr;
+        rl.slices = (uint32_t)std::max(1, env_int("QHIP_AGG_PART_SLICES", 8));
+        rl.n_items = n_bins * rl.slices;
+        rl.hist = hist.as<uint32_t>();
+        rl.g1 = (uint32_t)g1; rl.n_bins = n_bins; rl.min_slice = 4096;
+        HAggLaunch Lp = L;
+        Lp.l_nslots = l_nslots_p;
+        void* rargs[] = {&rl, &Lp};
+        if (wide) {
+          std::shared_ptr<Module> m_wide = get_module(ctx, plan.source, "qk_agg_reduce_wide");
+          QHIP_HIP_CHECK(hipModuleLaunchKernel(m_wide->fn, std::min<unsigned>(rl.n_items, (unsigned)ctx->num_cus * 8), 1, 1, 1024, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
+        } else {
+          QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, std::min<unsigned>(rl.n_items, (unsigned)ctx->num_cus * 16), 1, 1, 256, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
+        }
+        // (hist / records go back to the stream-ordered pool: no wait; the call's one synchronisation follows below)
+      } else {
       // first record of every bin (= of its first workgroup's run) + the record total: one strided read-back
       uint32_t* first = (uint32_t*)((uint8_t*)ctx->pinned + 128);
       QHIP_HIP_CHECK(hipMemcpy2DAsync(first, 4, hist.ptr, (size_t)g1 * 4, 4, n_bins, hipMemcpyDeviceToHost, s));
@@ -591,6 +624,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
           QHIP_HIP_CHECK(hipModuleLaunchKernel(m_red->fn, rgrid, 1, 1, 256, 1, 1, (unsigned)((size_t)l_nslots_p * slot_bytes), s, rargs, nullptr));
         }
         QHIP_HIP_CHECK(sync_stream(s));   // hist / records / items go back to the pool here; item_first is pageable
+      }
       }
 
     } else if (N > 0)

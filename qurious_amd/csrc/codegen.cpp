@@ -470,7 +470,10 @@ void ExprGen::emit(int k, std::string& out) {
 }
 
 // ---------------------------------------------------------------- key packing shared by aggregate / join / partition kernels
-// create_hashes (utils/array.rs:190-210) accepts exactly these key types; anything else is an InternalError there.
+// Key types: the reference's create_hashes (utils/array.rs:190-210) hashes Int64, UInt8, Int32, Utf8, Date32 / Date64,
+// Time32 / Time64, Decimal128 and Decimal256 and raises an InternalError for anything else. The HIP path takes the same list
+// MINUS Time32 / Time64 (no such type id crosses the C ABI: qhip_type_id) and Decimal256 (out of scope): a plan with
+// such a key gets the reference's own error text here and the shim keeps the CPU node — a documented gap, not a drop-in.
 static void check_key_type(const DType& t) {
   switch (t.id) {
     case QHIP_INT64: case QHIP_UINT8: case QHIP_INT32: case QHIP_UTF8: case QHIP_DATE32: case QHIP_DATE64: case QHIP_DECIMAL128:

@@ -804,8 +804,14 @@ __device__ __forceinline__ void qh_agg_part_stage_body(const KArgs& a, const Par
 
 struct ReduceLaunch {
   const u64* records;
-  const u32* item_first;   // work item k = records [item_first[k], item_first[k + 1]), all of one bin
+  const u32* item_first;   // work item k = records [item_first[k], item_first[k + 1]), all of one bin — or nullptr:
   u32 n_items;
+  // ... the items are derived ON THE DEVICE from the scanned histogram (mid-sized inputs: no host round trip between the
+  // passes): item k = slice k % slices of bin k / slices; bin b = records [hist[b * g1], hist[(b + 1) * g1]) (the last bin
+  // ends at hist[n_bins * g1], the record total); a bin is cut into `slices` slices of at least min_slice records
+  u32 slices;
+  const u32* hist;
+  u32 g1, n_bins, min_slice, pad_;
 };
 
 // (TB: threads per workgroup — 256, or 1 024 with a 128 KB LDS table: one workgroup per CU still runs 16 wavefronts, and
@@ -818,9 +824,20 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
   const u32 lwords = L.l_nslots * (u32)P::SLOT_WORDS;
   u32 err = 0;
   for (u32 item = blockIdx.x; item < R.n_items; item += gridDim.x) {
+    u32 r0, r1;
+    if (R.item_first) { r0 = R.item_first[item]; r1 = R.item_first[item + 1]; }
+    else {
+      const u32 b = item / R.slices, sl = item - b * R.slices;
+      const u32 b0 = R.hist[(size_t)b * R.g1], b1 = R.hist[(size_t)(b + 1) * R.g1];   // (bin-major: the next bin's first run)
+      const u32 cnt = b1 - b0;
+      u32 per = (cnt + R.slices - 1) / R.slices;
+      per = per < R.min_slice ? R.min_slice : per;
+      r0 = b0 + sl * per;
+      r1 = r0 + per < b1 ? r0 + per : b1;
+      if (sl * per >= cnt) continue;   // (workgroup-uniform: this slice of the bin is empty)
+    }
     for (u32 k = tid; k < lwords; k += TB) ltable[k] = 0;
     __syncthreads();
-    const u32 r0 = R.item_first[item], r1 = R.item_first[item + 1];
     constexpr int RR = 4;   // records per thread and iteration: their loads are issued together
     for (u32 i0 = r0; i0 < r1; i0 += TB * RR) {
       u64 key[RR][W > 0 ? W : 1];

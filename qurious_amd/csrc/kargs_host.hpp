@@ -49,9 +49,11 @@ struct HReduceLaunch {
   const uint64_t* records;
   const uint32_t* item_first;
   uint32_t n_items;
-  uint32_t pad_ = 0;
+  uint32_t slices = 1;
+  const uint32_t* hist = nullptr;   // device-side work items (item_first == nullptr)
+  uint32_t g1 = 0, n_bins = 0, min_slice = 0, pad_ = 0;
 };
-static_assert(sizeof(HReduceLaunch) == 24, "ReduceLaunch layout");
+static_assert(sizeof(HReduceLaunch) == 48, "ReduceLaunch layout");
 
 struct HProjOut {
   void* v[kMaxCols];
