@@ -158,6 +158,7 @@ struct PendingOffsets {
   // search_m pairs whose probe row is >= bounds[b]): the search runs when somebody asks (a parent's build side or an
   // aggregate never does — one launch less per join)
   std::shared_ptr<DevBuf> search_in, bounds;
+  std::vector<uint64_t> bounds_host;   // the boundary rows when `bounds` has not been uploaded (nobody may ever ask)
   uint64_t search_m = 0;
 };
 }  // namespace qhip

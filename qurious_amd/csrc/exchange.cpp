@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "device/qhip_status.h"
 #include "kernels.hpp"
 #include "relops.hpp"
 
@@ -36,15 +37,27 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   es.build(exprs, n_exprs, icols);
   KeysPlan kp;
   DevBuf keys, valid;
-  eval_key_words(ctx, in, es, icols, roots, n_keys, kp, keys, valid);
+  uint32_t* const dstat = zeroed_block(ctx);   // the key expressions' status words: read back with the histogram (ONE wait)
+  eval_key_words(ctx, in, es, icols, roots, n_keys, kp, keys, valid, -1, true, dstat);
   DevBuf part((N + 1) * 4), hist((size_t)(n_parts + 1) * 4), iota((N + 1) * 4), sorted_part((N + 1) * 4), sorted_rows((N + 1) * 4);
   QHIP_HIP_CHECK(hipMemsetAsync(hist.ptr, 0, hist.bytes, s));
   launch_partition_ids(kp.W, keys.as<uint64_t>(), N, (uint32_t)n_parts, part.as<uint32_t>(), hist.as<uint32_t>(), s);
   launch_iota_u32(iota.as<uint32_t>(), N, s);
   stable_sort_pairs_u32(part.as<uint32_t>(), sorted_part.as<uint32_t>(), iota.as<uint32_t>(), sorted_rows.as<uint32_t>(), N,
                         std::max(1, log2u((uint32_t)n_parts)), s);
-  std::vector<uint32_t> h((size_t)n_parts);
-  copy_sync(s, h.data(), hist.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost);
+  uint32_t* const back = (uint32_t*)ctx->pinned;   // [status words | histogram]
+  if ((size_t)(QS_WORDS + n_parts) * 4 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "qhip_partition_by_key: too many parts for the read-back scratch");
+  QHIP_HIP_CHECK(hipMemcpyAsync(back, dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
+  QHIP_HIP_CHECK(hipMemcpyAsync(back + QS_WORDS, hist.ptr, (size_t)n_parts * 4, hipMemcpyDeviceToHost, s));
+  QHIP_HIP_CHECK(sync_stream(s));
+  check_status_words(back);
+  std::vector<uint32_t> h(back + QS_WORDS, back + QS_WORDS + n_parts);
+  // the parts' columns: every plain column (fixed width, no NULLs) of every part goes into batched gather launches (8 gathers
+  // each) instead of one launch per (part, column); the others (validity bits, strings) take their own gathers
+  GatherBatch gb;
+  memset(&gb, 0, sizeof gb);
+  int n_batched = 0;
+  auto flush = [&] { if (n_batched) { launch_gather_multi(gb, n_batched, s); n_batched = 0; } };
   uint64_t pos = 0;
   for (int p = 0; p < n_parts; ++p) {
     std::unique_ptr<qhip_table> t(new qhip_table());
@@ -52,12 +65,28 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
     t->names = in->names;
     t->nullable = in->nullable;
     const uint64_t m = h[(size_t)p];
-    for (auto& c : in->cols) t->cols.push_back(gather_column(ctx, c, sorted_rows.as<uint32_t>() + pos, m, false));
+    for (auto& c : in->cols) {
+      const DevColumn& src = resolved(ctx, c);
+      const int w = dtype_width(src.type);
+      if (w > 0 && src.null_count == 0 && m > 0) {
+        DevColumn oc;
+        oc.type = src.type;
+        oc.length = (int64_t)m;
+        oc.value_maxabs = src.value_maxabs;
+        oc.range = src.range; oc.range_inherited = true;
+        oc.values = std::make_shared<DevBuf>((size_t)m * (size_t)w);
+        gb.d[n_batched++] = GatherDesc{src.values->ptr, sorted_rows.as<uint32_t>() + pos, oc.values->ptr, m, (uint32_t)w, 0u};
+        if (n_batched == kGatherBatch) flush();
+        t->cols.push_back(std::move(oc));
+      } else
+        t->cols.push_back(gather_column(ctx, c, sorted_rows.as<uint32_t>() + pos, m, false));
+    }
     t->num_rows = (int64_t)m;
     t->batch_offsets = {0, (int64_t)m};
     pos += m;
     out_parts[p] = t.release();
   }
+  flush();
 }
 
 // One destination column assembled from n source sections on the device (shared by qhip_table_concat and the unpacking of
@@ -277,7 +306,9 @@ qhip_table* table_keep_columns(Ctx* ctx, const qhip_table* in, const int32_t* ke
   out->names = in->names;
   out->nullable = in->nullable;
   out->num_rows = in->num_rows;
-  out->batch_offsets = in->offsets();
+  // (batch boundaries an operator left on the device stay there: whoever asks the view for them fetches them itself)
+  out->batch_offsets = in->batch_offsets;
+  out->pending_offsets = in->pending_offsets;
   for (size_t c = 0; c < in->cols.size(); ++c) {
     if (keep[c]) { out->cols.push_back(in->cols[c]); continue; }
     DevColumn nc;
@@ -390,10 +421,14 @@ struct qhip_comm {
 };
 
 namespace {
-void comm_settle_time(qhip_comm* c) {
+// add the last exchange's transfer time to the statistics; `wait`: block for its end event (qhip_comm_get_stats), else only
+// when the event has already happened (the next exchange: never a host wait — a sample that is not ready yet is dropped)
+void comm_settle_time(qhip_comm* c, bool wait) {
   if (!c->timed) return;
   float ms = 0;
-  if (sync_event(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.transfer_seconds += (double)ms * 1e-3;
+  const hipError_t ready = wait ? sync_event(c->ev[1]) : hipEventQuery(c->ev[1]);
+  if (ready == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.transfer_seconds += (double)ms * 1e-3;
+  else (void)hipGetLastError();
   c->timed = false;
 }
 
@@ -407,16 +442,29 @@ qhip_table* comm_exchange(Ctx* ctx, qhip_comm* c, const qhip_table* const* parts
   // (QHIP_COMM_SELF_RCCL=1, tests: this rank's own part travels through RCCL too — ncclSend / ncclRecv to itself inside the
   // group, the metadata through ncclAllGather — so that a ONE-rank communicator exercises every RCCL entry point)
   const bool self_rccl = c->comm != nullptr && env_int("QHIP_COMM_SELF_RCCL", 0) != 0;
-  const size_t M = 2 + 2 * (size_t)n_cols;
+  // metadata words per part: the wire image's [rows, bytes, (nulls, utf8 bytes) per column] + per column [range known, min,
+  // max] — a join above the exchange then knows its integer key's value range (the dense table layout) without a
+  // reduction and a host wait of its own over the freshly unpacked column
+  const size_t M0 = 2 + 2 * (size_t)n_cols, M = M0 + 3 * (size_t)n_cols;
   const int n_mine = all_gather ? 1 : W;
   for (int p = 0; p < n_mine; ++p) {
     if (!parts[p] || (int)parts[p]->cols.size() != n_cols) fail(QHIP_INVALID_ARGUMENT, "exchange: a part is missing or has a different number of columns");
     settle_rows(parts[p]);
   }
-  comm_settle_time(c);
+  comm_settle_time(c, false);
   // ---- my parts' metadata and ONE send buffer with their wire images back to back (no wait: everything stays on the stream)
   std::vector<int64_t> meta_out((size_t)W * M);
-  for (int p = 0; p < n_mine; ++p) table_wire_meta(ctx, parts[p], meta_out.data() + (size_t)p * M);
+  for (int p = 0; p < n_mine; ++p) {
+    int64_t* m = meta_out.data() + (size_t)p * M;
+    table_wire_meta(ctx, parts[p], m);
+    for (int col = 0; col < n_cols; ++col) {
+      const DevColumn& dc = parts[p]->cols[(size_t)col];
+      const bool known = dc.range && dc.range->known;
+      m[M0 + 3 * col] = known ? 1 : 0;
+      m[M0 + 3 * col + 1] = known ? dc.range->min : 0;
+      m[M0 + 3 * col + 2] = known ? dc.range->max : 0;
+    }
+  }
   if (all_gather) for (int p = 1; p < W; ++p) memcpy(meta_out.data() + (size_t)p * M, meta_out.data(), M * 8);
   std::vector<size_t> send_off((size_t)W + 1, 0);
   for (int p = 0; p < n_mine; ++p) send_off[(size_t)p + 1] = send_off[(size_t)p] + align16((size_t)meta_out[(size_t)p * M + 1]);
@@ -465,7 +513,28 @@ qhip_table* comm_exchange(Ctx* ctx, qhip_comm* c, const qhip_table* const* parts
   // ---- unpack straight into the concatenated table (stream-ordered: the buffers go back to the pool behind it)
   std::vector<const void*> images((size_t)W);
   for (int r = 0; r < W; ++r) images[(size_t)r] = meta_in[(size_t)r * M + 1] ? recv_buf.as<uint8_t>() + recv_off[(size_t)r] : nullptr;
-  return table_unpack_concat(ctx, names, dtypes, n_cols, meta_in.data(), images.data(), W, false);
+  std::vector<int64_t> wire_meta((size_t)W * M0);
+  for (int r = 0; r < W; ++r) memcpy(wire_meta.data() + (size_t)r * M0, meta_in.data() + (size_t)r * M, M0 * 8);
+  qhip_table* out = table_unpack_concat(ctx, names, dtypes, n_cols, wire_meta.data(), images.data(), W, false);
+  for (int col = 0; col < n_cols; ++col) {   // the union of the parts' ranges (parts without rows say nothing)
+    bool all = true, any = false;
+    int64_t lo = 0, hi = 0;
+    for (int r = 0; r < W; ++r) {
+      const int64_t* m = meta_in.data() + (size_t)r * M;
+      if (m[0] == 0) continue;
+      if (!m[M0 + 3 * col]) { all = false; break; }
+      lo = any ? std::min(lo, m[M0 + 3 * col + 1]) : m[M0 + 3 * col + 1];
+      hi = any ? std::max(hi, m[M0 + 3 * col + 2]) : m[M0 + 3 * col + 2];
+      any = true;
+    }
+    if (all && any) {
+      DevColumn& dc = out->cols[(size_t)col];
+      dc.range = std::make_shared<ColRange>();
+      dc.range->known = true; dc.range->min = lo; dc.range->max = hi;
+      dc.range_inherited = false;
+    }
+  }
+  return out;
 }
 }  // namespace
 
@@ -512,7 +581,7 @@ void qhip_comm_destroy(qhip_comm* c) {
 
 int qhip_comm_get_stats(qhip_comm* c, qhip_comm_stats* out, int32_t reset) {
   if (!c || !out) return QHIP_INVALID_ARGUMENT;
-  comm_settle_time(c);
+  comm_settle_time(c, true);
   *out = c->stats;
   out->rank = c->rank; out->world = c->world;
   if (reset) { const int32_t v = c->stats.rccl_version; memset(&c->stats, 0, sizeof c->stats); c->stats.rccl_version = v; }

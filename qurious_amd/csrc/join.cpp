@@ -604,7 +604,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const size_t nb1 = R->offsets().size();
     // first output row of every probe batch, computed on the device and LEFT there (qhip_table::offsets() fetches it when
     // somebody asks: a download, a Filter / Limit / probe side above; a parent's build side or an aggregate never does)
-    const uint64_t* drows = R->device_offsets();
     auto pend = std::make_shared<PendingOffsets>();
     pend->n = nb1;
     pend->skip_empty = true;
@@ -612,11 +611,14 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     pend->total_rows = (int64_t)total_rows;
     if (pad_right) {
       pend->pos = std::make_shared<DevBuf>(nb1 * 4);
-      launch_lookup_u32(final_off, drows, (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
+      launch_lookup_u32(final_off, R->device_offsets(), (uint32_t)nb1, P, (uint32_t)M, pend->pos->as<uint32_t>(), s);
     } else {   // the pairs' probe rows ascend: a binary search per batch boundary, run when somebody asks (PendingOffsets)
       pend->search_in = p_all;
       pend->search_m = M;
-      pend->bounds = R->offsets_dev;
+      // (the probe side's batch boundaries go along on the host, or as the device copy another operator already made:
+      // uploading them here would be a host wait per join for something a parent join or an aggregate never asks for)
+      if (R->offsets_dev) pend->bounds = R->offsets_dev;
+      else pend->bounds_host.assign(R->offsets().begin(), R->offsets().end());
     }
     out->batch_offsets.clear();
     out->pending_offsets = pend;

@@ -478,6 +478,10 @@ const std::vector<int64_t>& qhip_table::offsets() const {
   if (p.search_in) {
     qhip::settle_rows(this);   // (a join of deferred size: the number of pairs must be exact before it is searched)
     pending_offsets->pos = std::make_shared<qhip::DevBuf>(p.n * 4);
+    if (!p.bounds) {   // the boundary rows were left on the host: uploaded now that somebody asks
+      pending_offsets->bounds = std::make_shared<qhip::DevBuf>(p.bounds_host.size() * 8);
+      qhip::copy_sync(ctx->stream, p.bounds->ptr, p.bounds_host.data(), p.bounds_host.size() * 8, hipMemcpyHostToDevice);
+    }
     qhip::launch_lower_bound_u32(p.search_in->as<uint32_t>(), p.search_m, nullptr, p.bounds->as<uint64_t>(), (uint32_t)p.n, p.pos->as<uint32_t>(), ctx->stream);
   }
   QHIP_HIP_CHECK(hipMemcpyAsync(pos, p.pos->ptr, p.n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -228,8 +228,8 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
             assert "configs[4]" in z["workload"] and z["groups"] > 100 and z["other_strategy"]["groups"] == z["groups"]
             assert 0 < z["aggregate_table"]["lds_occupancy"] <= 1 and z["aggregate_table"]["groups"] > 0
             assert z["exchange"]["xgmi_peak_GBps"] == 7 * 153.0 and z["exchange"]["transport"] == "rccl"
-            assert 0 < z["exchange"]["host_waits_per_query"] < 60 and z["exchange"]["heavy_key_rounds_per_query"] <= 1
-            assert rec["q3_sf10"]["exchange"]["transport"] == "rccl" and rec["q3_sf10"]["exchange"]["host_waits_per_query"] < 60
+            assert 0 < z["exchange"]["host_waits_per_query"] < 40 and z["exchange"]["heavy_key_rounds_per_query"] <= 1
+            assert rec["q3_sf10"]["exchange"]["transport"] == "rccl" and rec["q3_sf10"]["exchange"]["host_waits_per_query"] < 40
         if "q3" in extra:
             assert line["exchange"]["exchanges_per_query"] > 0
 

@@ -23,7 +23,7 @@ from qurious_amd import exchange, queries, synth  # noqa: E402
 
 # host waits (stream synchronisations inside libqhip, the transport's included) of one REPEATED Q3 through the multi-rank
 # operators, measured on the one-rank rehearsal; asserted as ceilings
-WAIT_CEILING = {"repartition": 40, "broadcast": 40}
+WAIT_CEILING = {"repartition": 24, "broadcast": 24}
 
 
 def rows_of(batches):
