@@ -88,9 +88,15 @@ def catalog_sources():
         out.append(("q3 lineitem dense probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))
         os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
         out.append(("q3 join-1 output dense build, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        # ... which reads its key through join 1's index vector (a deferred gather, InputCol::indirect)
+        os.environ["QHIP_PLAN_INDIRECT"] = "1"
+        out.append(("q3 join-1 output dense build, indirect key, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
+        os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
+        out.append(("q3 join-1 output dense build, indirect key", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
     finally:
         os.environ.pop("QHIP_PLAN_DENSE", None)
         os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
+        os.environ.pop("QHIP_PLAN_INDIRECT", None)
     top = queries.q3_top10(*tabs)
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)

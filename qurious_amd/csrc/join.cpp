@@ -68,7 +68,6 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // ---- key words of both sides (only the columns the key / scan-filter expressions read are gathered if deferred)
   // (measured on Q3's second join: reading the build key through join 1's index vector inside qk_join_scatter costs 17 us
   // more than the separate gather it saves — 92 vs 75 us — so the build side gathers; QHIP_LATE_GATHER_BUILD=1 switches it on)
-  const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", 0) != 0;
   // ---- dense (direct-address) layout? ONE integer key column whose build-side values span a small range [kmin, kmax]
   // (DevColumn::range, found once per base table: looked at BEFORE the key column is gathered, while a deferred gather
   // still names its source): the table is then an exact bitmap over the range + row_of[key - kmin]
@@ -87,6 +86,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       if (span < (1ULL << 30) && (dense_mode == 2 || span < 256 * B + 65536)) { dense_candidate = true; dense_n = span + 1; }
     }
   }
+  // the build key of a join over a join's output is a deferred gather: the dense build kernel reads it THROUGH the index
+  // vector (one dependent load more per row, no gather launch + write + re-read of the key: Q3's join 2 24 + 38 -> 54 us);
+  // the region build's scatter kernel lost by that (92 vs 75 us), so the hashed layouts gather first
+  const bool late_build = env_int("QHIP_LATE_GATHER_BUILD", dense_candidate ? 1 : 0) != 0;
   resolve_referenced(ctx, L, lex, nlex, late_build);
   resolve_referenced(ctx, R, rex, nrex);
   std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
