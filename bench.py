@@ -386,7 +386,7 @@ class Q3:
         for k, j in enumerate(joins):
             pb = j["rows_in"] * j["bytes_per_row_read"]
             pname = j["main_kernel_name"]
-            dense = pname == "qk_join_probe_dense"
+            dense = pname.startswith("qk_join_probe_dense")
             t, src = pmc_traffic("q3", pname, j["rows_in"], j["bytes_per_row_read"])
             if t is not None:
                 src += ("; FETCH_SIZE x 2 is calibrated for wide streaming reads (MI355X_MICROARCH.md): the random 4 / 8 / 16-byte lookups of "

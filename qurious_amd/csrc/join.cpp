@@ -341,6 +341,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // (slot, probe row) entry per MATCHING probe row and one pair count per 256-row tile; the tile counts are scanned; pass 2 writes the pairs in
   // probe-row order. LeftSemi / LeftAnti without a residual filter only need the visited bits: pass 1 sets them.
   DevBuf ent_slot((P + 1) * 4), ent_row((P + 1) * 4), cnt, pair_off, b_idx, p_idx;
+  std::string probe_name = dense ? "qk_join_probe_dense" : "qk_join_probe";   // (the entry point launched, for the statistics)
   uint64_t M = 0;
   const uint32_t* deferred_slot = nullptr;
   std::shared_ptr<DevBuf> rows_blk;
@@ -376,6 +377,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       }
     }
     const bool dense_lds = lds_words > 0;
+    probe_name = probe_kernel;
     std::shared_ptr<Module>& rmod = jp->rmods[probe_kernel];
     if (!rmod) rmod = get_module(ctx, rkp.source, probe_kernel);
     const std::shared_ptr<Module>& mod = rmod;
@@ -635,7 +637,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   ctx->stats.rows_out = (int64_t)total_rows;
   ctx->stats.groups = (int64_t)M;
   ctx->stats.table_capacity = dense ? (int64_t)dense_n : nslots;
-  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, dense ? "qk_join_probe_dense" : "qk_join_probe");
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", probe_name.c_str());
   // bytes of column data the probe kernel / the build's key evaluation read per row (roofline figures)
   auto bytes_per_row = [&](const qhip_table* t, const KernelBindings& b) {
     double sum = 0;

@@ -86,9 +86,9 @@ def test_dense_layout_every_key_type_and_range(ctx, oracle, dense, key_type, lo,
         plan = q.HashJoinExec.try_new(left, right, jt, on, None)
         _same(plan.execute(), oracle.execute(plan))
         if dense in ("forced", "lds"):
-            assert _layout_of(ctx) == "qk_join_probe_dense", (jt, _layout_of(ctx))
+            assert _layout_of(ctx).startswith("qk_join_probe_dense"), (jt, _layout_of(ctx))
         elif dense == "off":
-            assert _layout_of(ctx) == "qk_join_probe"
+            assert _layout_of(ctx) in ("qk_join_probe", "qk_join_probe_onetable")
 
 
 def test_dense_layout_is_what_runs_for_tpch_shaped_keys_and_not_for_wide_ranges(ctx, oracle, monkeypatch):
@@ -98,7 +98,7 @@ def test_dense_layout_is_what_runs_for_tpch_shaped_keys_and_not_for_wide_ranges(
     plan = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb]), JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
     _same(plan.execute(), oracle.execute(plan))
     st = ctx.last_stats()
-    assert st["main_kernel_name"] == "qk_join_probe_dense" and st["table_capacity"] == 80_000
+    assert st["main_kernel_name"].startswith("qk_join_probe_dense") and st["table_capacity"] == 80_000
     # 3 000 keys scattered over 2^40 values: range >> 256 x rows -> the hashed layout, unless forced — and forcing is
     # refused beyond 2^30 keys
     wide = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 2 ** 40, 3000), I64), pa.array(np.arange(3000), I64)], schema=ls)
@@ -108,17 +108,17 @@ def test_dense_layout_is_what_runs_for_tpch_shaped_keys_and_not_for_wide_ranges(
     for mode in ("1", "2"):
         monkeypatch.setenv("QHIP_JOIN_DENSE", mode)
         got = plan.execute()
-        assert ctx.last_stats()["main_kernel_name"] == "qk_join_probe"
+        assert ctx.last_stats()["main_kernel_name"] in ("qk_join_probe", "qk_join_probe_onetable")
         _same(got, oracle.execute(plan))
     # a modest range with few rows: automatic says no (range > 256 x rows + 64 k), forced says yes
     few = pa.RecordBatch.from_arrays([pa.array(rng.permutation(4_000_000)[:100], I64), pa.array(np.arange(100), I64)], schema=ls)
     plan = q.HashJoinExec.try_new(table_scan(ls, [few]), table_scan(rs, [probe]), JoinType.Left, [(col("bk", 0), col("pk", 0))], None)
     monkeypatch.setenv("QHIP_JOIN_DENSE", "1")
     _same(plan.execute(), oracle.execute(plan))
-    assert ctx.last_stats()["main_kernel_name"] == "qk_join_probe"
+    assert ctx.last_stats()["main_kernel_name"] in ("qk_join_probe", "qk_join_probe_onetable")
     monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
     _same(plan.execute(), oracle.execute(plan))
-    assert ctx.last_stats()["main_kernel_name"] == "qk_join_probe_dense"
+    assert ctx.last_stats()["main_kernel_name"].startswith("qk_join_probe_dense")
 
 
 def test_dense_layout_duplicate_build_keys_fall_back_to_the_chains_order(ctx, oracle, dense):
@@ -169,7 +169,7 @@ def test_dense_layout_fused_scan_filters_residual_filter_and_expression_probe_ke
     # ... and a computed BUILD key takes the hashed layout
     plan = q.HashJoinExec.try_new(table_scan(ls, [lb]), right, JoinType.Inner, [(q.BinaryExpr(col("bk", 0), Operator.Add, q.Literal(S.Int64(1))), col("pk", 0))], None)
     _same(plan.execute(), oracle.execute(plan))
-    assert _layout_of(ctx) == "qk_join_probe"
+    assert _layout_of(ctx) in ("qk_join_probe", "qk_join_probe_onetable")
 
 
 def test_dense_layout_build_side_is_a_join_of_deferred_size_under_an_aggregate(ctx, oracle, dense):

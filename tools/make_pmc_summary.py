@@ -32,7 +32,7 @@ def bench_line(src, tag):
 
 def main():
     src, out_path = sys.argv[1], sys.argv[2]
-    label = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    label = sys.argv[3] if len(sys.argv) > 3 else "r03"
     summary = {}
     for tag in ("q1_mini", "q1_full", "q3"):
         pmc_json = os.path.join(src, f"{tag}_pmc.json")
@@ -43,7 +43,7 @@ def main():
         wanted = []   # (kernel name, rows, bytes per row, operator)
         if tag == "q3":
             for k in line["records"]["q3"]["kernels"]:
-                if k["kernel"] in ("qk_join_probe", "qk_filter_agg"):
+                if k["kernel"].startswith("qk_join_probe") or k["kernel"] == "qk_filter_agg":
                     wanted.append((k["kernel"], k["rows_per_launch"], k.get("kernel_bytes_per_row"), k.get("operator")))
         else:
             r = line["roofline"]
