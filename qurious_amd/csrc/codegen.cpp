@@ -891,10 +891,18 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
   if (es.at(root).type.id != QHIP_BOOL)
     fail(QHIP_INVALID_ARGUMENT, "filter predicate must be Boolean, got " + dtype_name(es.at(root).type));
   ExprGen g(es, input);
+  // the mask kernel is software-pipelined over its tiles: a row's column loads (load(): branch-free, tile-relative
+  // addressing) are issued two tiles before the predicate is evaluated from them (pred())
+  g.set_indexing(" + tb", "o", "(tb + (i64)o)");
+  g.set_raw_mode(true);
   std::string code;
   g.emit(root, code);
   std::ostringstream s;
-  s << "struct P {\n  __device__ static __forceinline__ bool pred(const KArgs& a, const i64 i, u32& err) {\n" << code;
+  out.mask_r = std::max(1, std::min(16, env_int("QHIP_MASK_R", 4)));
+  s << "struct P {\n  static constexpr int MASK_R = " << out.mask_r << ";\n";
+  s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
+  s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
+  s << "  __device__ static __forceinline__ bool pred(const KArgs& a, const Raw& w, u32& err) {\n" << code;
   s << "    return " << g.ok(root) << " && " << g.val(root) << ";\n  }\n};\n";
   s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_pred_mask(KArgs a, u64* mask, u32* wave_count, u32* status) { "
        "qh_pred_mask_body<P>(a, mask, wave_count, status); }\n";

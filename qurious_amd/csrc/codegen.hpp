@@ -109,7 +109,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
 // (dev_rows: the input's row count lives on the device — KArgs::nrows_dev, a join output of deferred size; a separate
 // instantiation of the kernel bodies, so that kernels over ordinary tables keep their row count a plain kernel argument)
 
-struct MaskPlan { KernelBindings bind; std::string source; std::string kernel_name; };
+struct MaskPlan { KernelBindings bind; std::string source; std::string kernel_name; int mask_r = 4; /* mask words per tile (P::MASK_R) */ };
 void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, int predicate_root, MaskPlan& out);
 
 struct KeysPlan {

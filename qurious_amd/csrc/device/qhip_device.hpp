@@ -867,32 +867,78 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
 // Filter::execute (physical/plan/filter.rs:28-44): mask word j holds the keep bits of rows 64j..64j+63
 // (wavefront ballot), wave_count[j] their popcount; the exclusive scan of wave_count gives every
 // wavefront its output offset for the column compaction kernels (selection-vector compaction).
+// Software-pipelined like the join probe (round 3): a wavefront owns a run of consecutive TILES of 64 * MASK_R rows; every trip
+// evaluates tile t out of registers while the column loads of tiles t + 1 and t + 2 are in flight (three register sets that
+// rotate, the loop unrolled three trips, every load unconditional — the trips behind the last tile re-read the run's first
+// tile and store nothing). The one-trip-at-a-time loop before kept 1 KB per wavefront in flight — 8 MB over the chip, where
+// 8 TB/s x ~2 us of loaded latency wants 16 MB: a 4-byte predicate column streamed at 3.2 TB/s (60 M rows: 78 us).
+// The stores of a tile (lane r: mask word r and its popcount — two store instructions) are YOUNGER than the loads the
+// next trip waits for, so the in-order return of vector-memory operations never makes a trip wait for a store.
+template <class P>
+struct QhMaskTile {
+  typename P::Raw raw[P::MASK_R];
+  i64 tile;    // wave-uniform
+  bool live;   // wave-uniform: a tile of this wavefront's run (not a drain trip's)
+};
+template <class P>
+__device__ __forceinline__ void qh_mask_load(const KArgs& a, QhMaskTile<P>& x, i64 first, i64 mine, i64 j, int lane) {
+  constexpr int R = P::MASK_R, TILE = 64 * R;
+  x.live = j < mine;
+  x.tile = first + (x.live ? j : 0);
+  const i64 tb = x.tile * TILE;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32 o = (u32)r * 64u + (u32)lane;
+    P::load(a, tb, tb + (i64)o < a.nrows ? o : (u32)(a.nrows - 1 - tb), x.raw[r]);
+  }
+}
+template <class P>
+__device__ __forceinline__ void qh_mask_finish(const KArgs& a, const QhMaskTile<P>& x, u64* mask, u32* wave_count, i64 nwords, int lane, u32& err) {
+  constexpr int R = P::MASK_R, TILE = 64 * R;
+  u64 word = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool inb = x.tile * TILE + r * 64 + lane < a.nrows;
+    u32 e = 0;
+    const bool keep = P::pred(a, x.raw[r], e) && inb;
+    err |= (inb && x.live) ? e : 0u;
+    const u64 m = qh_ballot(keep);
+    word = lane == r ? m : word;
+  }
+  const i64 w = x.tile * R + lane;
+  if (x.live && lane < R && w < nwords) { mask[w] = word; wave_count[w] = (u32)__builtin_popcountll(word); }
+}
 template <class P>
 __device__ __forceinline__ void qh_pred_mask_body(const KArgs& a, u64* mask, u32* wave_count, u32* status) {
+  constexpr int R = P::MASK_R, TILE = 64 * R;
   const i64 nwords = (a.nrows + 63) / 64;
-  const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
-  const i64 nwaves = ((i64)gridDim.x * QH_BLOCK) >> 6;
+  const i64 ntiles = (a.nrows + TILE - 1) / TILE;
+  const i64 wave = (i64)blockIdx.x * (QH_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the loop is wave-uniform)
+  const i64 nwaves = (i64)gridDim.x * (QH_BLOCK / 64);
   const int lane = qh_lane();
+  const i64 per = (ntiles + nwaves - 1) / nwaves;
+  const i64 first = wave * per;
+  if (first >= ntiles) return;
+  const i64 mine = ntiles - first < per ? ntiles - first : per;
   u32 err = 0;
-  // U consecutive words (64 U rows) per trip, evaluated back to back: the predicate's column loads of the U rows a lane
-  // owns are independent, so they are in flight together (one word per trip streamed a 4-byte column at 2.9 TB/s)
-  constexpr int U = 4;
-  for (i64 j0 = wave_global * U; j0 < nwords; j0 += nwaves * U) {
-    bool keep[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const i64 i = (j0 + u) * 64 + lane;
-      const bool inb = i < a.nrows;
-      u32 e = 0;
-      keep[u] = P::pred(a, inb ? i : a.nrows - 1, e) && inb;
-      err |= inb ? e : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const u64 m = qh_ballot(keep[u]);
-      if (lane == 0 && j0 + u < nwords) { mask[j0 + u] = m; wave_count[j0 + u] = (u32)__builtin_popcountll(m); }
-    }
+  QhMaskTile<P> A, B, C;
+  qh_mask_load<P>(a, A, first, mine, 0, lane);
+  qh_mask_load<P>(a, B, first, mine, 1, lane);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // (the scheduling barrier ends every trip: without it the compares of the NEXT trip's tile were hoisted above this trip's
+  // loads — a wait for that tile with nothing else in flight; seen in the ISA)
+#define QH_MASK_TRIP(X3, X1, J)                                    \
+  qh_mask_finish<P>(a, X3, mask, wave_count, nwords, lane, err);   \
+  qh_mask_load<P>(a, X1, first, mine, (J), lane);                  \
+  asm volatile("" ::: "memory");                                   \
+  __builtin_amdgcn_sched_barrier(0);
+  for (i64 j = 0; j < mine; j += 3) {   // wave-uniform
+    QH_MASK_TRIP(A, C, j + 2)
+    QH_MASK_TRIP(B, A, j + 3)
+    QH_MASK_TRIP(C, B, j + 4)
   }
+#undef QH_MASK_TRIP
   qh_report(status, err);
 }
 

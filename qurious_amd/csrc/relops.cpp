@@ -32,8 +32,9 @@ void run_pred_mask(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std::
   void* wptr = wave_count.ptr;
   void* sptr = status_dev ? (void*)status_dev : ctx->status.ptr;
   void* args[] = {&ka, &mptr, &wptr, &sptr};
-  // (a wavefront takes 4 mask words per trip: 16 words per workgroup and trip)
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nwords + 15) / 16, (uint64_t)ctx->num_cus * 8));
+  // (a wavefront owns a run of tiles of mp.mask_r mask words; 8 workgroups of 4 wavefronts per CU are resident)
+  const uint64_t ntiles = (nwords + (uint64_t)mp.mask_r - 1) / (uint64_t)mp.mask_r;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((ntiles + 3) / 4, (uint64_t)ctx->num_cus * 8));
   QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
   if (status_dev) return;   // (the pooled literal buffer may be recycled: any later writer runs on the same stream, i.e. after this kernel)
   uint32_t status[QS_WORDS];
