@@ -119,6 +119,11 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
     }
     const DevColumn& c = resolved(ctx, c0);
     a.c[s].v = c.values ? c.values->ptr : nullptr;
+    if (s < b.narrow.size() && b.narrow[s]) {   // the kernel was generated for the column's narrow copy (InputCol::narrow_bytes)
+      if (!c.narrow || c.narrow->bytes != (int)b.narrow[s] || !c.values || c.narrow->src != c.values->ptr || c.narrow->rows != c.length)
+        fail(QHIP_HIP_ERROR, "a column planned with a narrow copy has none of that width (internal error)");
+      a.c[s].v = c.narrow->buf->ptr;
+    }
     a.c[s].n = c.validity ? (const uint8_t*)c.validity->ptr : nullptr;
     a.c[s].d = c.data ? (const uint8_t*)c.data->ptr : nullptr;
   }
@@ -185,7 +190,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   std::string key = "agg|";
   auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
   for (auto& ic : icols) {
-    const int v[7] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0};
+    const int v[8] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0, ic.narrow_bytes};
     put(&ic.value_maxabs, sizeof ic.value_maxabs);   // (a whole number of bits, see ensure_value_bounds)
     put(v, sizeof v);
   }
@@ -264,7 +269,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   for (int c : plan.bind.cols) {
     const DevColumn& dc = in->cols[(size_t)c];
     const int w = dtype_width(dc.type);
-    if (w > 0) bytes_per_row += w;
+    if (w > 0) bytes_per_row += icols[(size_t)c].narrow_bytes && !icols[(size_t)c].indirect ? icols[(size_t)c].narrow_bytes : w;
     else if (dc.type.id == QHIP_BOOL) bytes_per_row += 0.125;
     else if (dc.type.id == QHIP_UTF8) bytes_per_row += icols[(size_t)c].utf8_fixed1 ? 1.0 : 4.0 + (N > 0 ? (double)dc.data_bytes / (double)N : 0.0);
     if (dc.null_count > 0) bytes_per_row += 0.125;

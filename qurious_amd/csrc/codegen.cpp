@@ -100,6 +100,7 @@ int ExprGen::col_slot(int table_col) {
   if (bind.cols.size() >= 24) fail(QHIP_UNSUPPORTED, "expression references more than 24 distinct columns");
   bind.cols.push_back(table_col);
   bind.indirect.push_back(table_col >= 0 && table_col < (int)in_.size() && in_[(size_t)table_col].indirect ? 1 : 0);
+  bind.narrow.push_back(table_col >= 0 && table_col < (int)in_.size() && !in_[(size_t)table_col].indirect ? (char)in_[(size_t)table_col].narrow_bytes : (char)0);
   return (int)bind.cols.size() - 1;
 }
 
@@ -180,14 +181,17 @@ void ExprGen::emit(int k, std::string& out) {
       } else if (n.type.id == QHIP_NULL) {
         o << "    const int " << v << " = 0;\n";
       } else {
-        field(ctype(n.type), v);
+        // a Decimal128 column with a narrow copy (InputCol::narrow_bytes): the kernel loads 4 / 8 bytes per value and widens
+        const int nb = n.type.id == QHIP_DECIMAL128 && !in_[(size_t)n.column].indirect ? in_[(size_t)n.column].narrow_bytes : 0;
+        const std::string LT = nb == 4 ? "int" : nb == 8 ? "i64" : ctype(n.type);   // the type in memory
+        field(LT, v);
         {
           // streaming (non-temporal) loads when asked for: column values are read once; Decimal128 goes through a 4 x u32
           // vector (the builtin takes integer / float / vector types)
           // tile-relative indexing (uniform 64-bit tile base + 32-bit lane offset): the lane offset is turned into BYTES in 32
           // bits, so that the load is `global_load v, v_offset32, s[base]` — one VALU instruction for the address instead of a
           // 64-bit shift-add per column and row (a tile is far smaller than 4 GB / 16)
-          const std::string T = ctype(n.type);
+          const std::string T = LT;
           const bool ind = in_[(size_t)n.column].indirect;   // late materialisation: source[index[row]] (random access, no streaming hint)
           const std::string addr = ind ? "((const " + T + "*)a.c[" + S + "].v)[((const u32*)a.c[" + S + "].d)[" + row_ + "]]"
                                    : base_.empty() ? "((const " + T + "*)a.c[" + S + "].v)[" + idx_ + "]"
@@ -195,11 +199,12 @@ void ExprGen::emit(int k, std::string& out) {
                                                        ") * (u32)sizeof(" + T + "))))";
           std::string rhs = addr;
           if (ind) rhs = addr;
-          else if (nt_ && n.type.id == QHIP_DECIMAL128) rhs = "qh_nt_load_i128(&" + addr + ")";
+          else if (nt_ && n.type.id == QHIP_DECIMAL128 && nb == 0) rhs = "qh_nt_load_i128(&" + addr + ")";
           else if (nt_) rhs = "__builtin_nontemporal_load(&" + addr + ")";
+          if (nb && !raw_) rhs = "(" + ctype(n.type) + ")(" + rhs + ")";   // (sign-extending)
           ld << "    " << (raw_ ? "" : "const " + ctype(n.type) + " ") << W << v << " = " << rhs << ";\n";
         }
-        if (raw_) o << "    const " << ctype(n.type) << " " << v << " = w." << v << ";\n";
+        if (raw_) o << "    const " << ctype(n.type) << " " << v << " = (" << ctype(n.type) << ")w." << v << ";\n";
       }
       if (n.nullable) {
         if (n.type.id == QHIP_NULL) o << "    const bool " << nn << " = false;\n";
@@ -698,6 +703,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "struct P {\n";
   const int KC = P.KC;
   s << "  static constexpr int W = " << P.W << ";\n  static constexpr int R = " << P.R << ";\n  static constexpr int SLOT_WORDS = " << P.slot_words << ";\n";
+  s << "  static constexpr int PIPE = " << (env_int("QHIP_AGG_PIPE", 0) != 0 ? 1 : 0) << ";   // two register sets: the next tile's loads fly while a tile is evaluated\n";
   // rows per thread of the partitioned path's staged scatter (qh_agg_part_stage_body): what a 1 024-thread workgroup can stage
   // in LDS beside 4 096 bins' counters (160 KB per CU), at most 4; 0 = records too wide, per-lane stores
   P.part_pr = std::min(4, (int)((163840 - 4096 * 12 - 1024) / (1024 * ((P.slot_words - 1) * 8 + 2))));
@@ -872,7 +878,11 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "    slot_update<MemHbm>(gs, q);\n  }\n";
   s << "};\n";
   P.kernel_name = "qk_filter_agg";
-  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P" << dr << ">(a, L); }\n";
+  {
+    const int waves = env_int("QHIP_AGG_WAVES", 0);
+    const std::string wattr = waves > 0 ? "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "))) " : std::string();
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P" << dr << ">(a, L); }\n";
+  }
   if (P.W > 0) {
     // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_part_hist(KArgs a, PartLaunch L) { qh_agg_part_body<P, false" << dr << ">(a, L); }\n";

@@ -461,125 +461,72 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   const i64 nrows_dr = DEVROWS ? qh_rows(a) : 0;
 #define QH_NROWS (DEVROWS ? nrows_dr : a.nrows)
   const i64 ntiles = (QH_NROWS + tile_rows - 1) / tile_rows;
-  for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (the load is
-    // issued with the tile's loads and consumed at the end of the iteration, wave-uniform)
-    const u32 overflowed = W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    typename P::Row row[R];
-    const i64 tb = t * tile_rows;
-    typename P::Raw raw[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // phase 1: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
-      // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
-      const u32 o = (u32)r * QH_BLOCK + (u32)tid;
-      const bool inb = tb + (i64)o < QH_NROWS;
-      P::load(a, tb, inb ? o : (u32)(QH_NROWS - 1 - tb), raw[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // phase 2: predicate, key words and aggregate arguments of each row (may branch)
-      const bool inb = tb + (i64)((u32)r * QH_BLOCK + (u32)tid) < QH_NROWS;
-#undef QH_NROWS
-      u32 e = 0;
-      P::eval(a, raw[r], row[r], e);
-      row[r].pass = row[r].pass && inb;
-      err |= inb ? e : 0u;
-    }
-    if (W == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) P::template acc_add<true>(acc, row[r], row[r].pass);
-      continue;
-    }
-    // ---- wave-resident hot-key accumulators
-    bool pend[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) pend[r] = row[r].pass;
-    u32 tile_pass = 0, tile_hits = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) tile_pass += (u32)__builtin_popcountll(qh_ballot(pend[r]));
-    // (1) rows whose key is already cached: lane-private add under the EXEC mask, no cross-lane traffic, no table
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      if (k < nc && use_cache) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          bool m = pend[r];
-#pragma unroll
-          for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == ck[k][w]);
-          P::template acc_add<false>(cacc[k], row[r], m);
-          const u32 c = (u32)__builtin_popcountll(qh_ballot(m));
-          crows[k] += c;
-          tile_hits += c;
-          pend[r] = pend[r] && !m;
-        }
-      }
-    }
-    // (2) admit new keys while the cache has room and the data keeps showing duplicates inside a wave
-    if (cache_on && nc < KC) {
-      int tile_misses = 0;
-#pragma unroll
-      for (int r0 = 0; r0 < R; ++r0) {
-        u64 act = qh_ballot(pend[r0]);
-        while (act != 0 && cache_on && nc < KC && tile_misses < 4) {
-          const int leader = __builtin_ctzll(act);
-          u64 lk[W > 0 ? W : 1];
-#pragma unroll
-          for (int w = 0; w < W; ++w) lk[w] = qh_readlane64(row[r0].key[w], leader);
-          u32 cnt = 0;
-          bool mm[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            bool m = pend[r];
-#pragma unroll
-            for (int w = 0; w < W; ++w) m = m && (row[r].key[w] == lk[w]);
-            mm[r] = m;
-            cnt += (u32)__builtin_popcountll(qh_ballot(m));
-          }
-          if (cnt <= 1) {
-            // Nobody shares this key inside the wave. Uniform high-cardinality data shows nothing but such keys and the
-            // cache is given up after a few tiles; a skewed distribution (Zipf: a long tail AND a few heavy keys) shows
-            // them between its heavy keys, so a wave that has already admitted a key keeps looking 8x longer. At most 4
-            // such misses per tile bound the cost of looking.
-            act &= ~(1ULL << leader);
-            ++singles;
-            if (singles >= (nc > 0 ? 256 : 32)) cache_on = false;
-            if (++tile_misses >= 4) break;
-            continue;
-          }
-#pragma unroll
-          for (int k = 0; k < KC; ++k) {
-            if (k == nc) {
-#pragma unroll
-              for (int w = 0; w < W; ++w) ck[k][w] = lk[w];
-              P::acc_init(cacc[k]);
-              crows[k] = cnt;
-#pragma unroll
-              for (int r = 0; r < R; ++r) { P::template acc_add<false>(cacc[k], row[r], mm[r]); pend[r] = pend[r] && !mm[r]; }
-            }
-          }
-          ++nc;
-          tile_hits += cnt;
-          act = qh_ballot(pend[r0]);
-        }
-      }
-    }
-    // the cache must earn its compares: a full cache that serves < 1/4 of the rows is no longer consulted (what it
-    // holds is merged at the end of the kernel like any other cached group)
-    seen_pass += tile_pass; seen_hits += tile_hits;
-    if (nc == KC && seen_pass >= 4096 && seen_hits * 4 < seen_pass) { use_cache = false; cache_on = false; }
-    // (3) everything else: one lane per row straight to the LDS-staged table (contention is low when keys are many)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (pend[r]) {
-        typename P::Part part;
-        P::part_init(part);
-        P::template part_add<true>(part, row[r], true);
-        qh_update_group<P>(ltable, L, row[r].key, part, err);
-      }
-    }
-    if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
+  // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (QH_OVERFLOWED: the load is
+  // issued with a tile's loads and consumed at the end of the trip, wave-uniform)
+#define QH_OVERFLOWED() (W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u)
+  // phase 1 of a tile: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
+  // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
+#define QH_ISSUE(RAW, TB, NROWS)                                          \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) {                         \
+    const u32 o = (u32)r * QH_BLOCK + (u32)tid;                           \
+    const bool inb = (TB) + (i64)o < (NROWS);                             \
+    P::load(a, (TB), inb ? o : (u32)((NROWS) - 1 - (TB)), RAW[r]);        \
   }
+  if (P::PIPE == 0) {
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const u32 overflowed = QH_OVERFLOWED();
+      const i64 tb = t * tile_rows;
+      typename P::Raw raw[R];
+      QH_ISSUE(raw, tb, QH_NROWS)
+#define QH_TILE_RAW raw
+#define QH_TILE_TB tb
+#include "qhip_agg_tile.inc"
+#undef QH_TILE_RAW
+#undef QH_TILE_TB
+      if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
+    }
+  } else if ((i64)blockIdx.x < ntiles) {
+    // Two register sets of raw column values: while a tile is evaluated, the loads of the workgroup's NEXT tile are in flight
+    // (before: issue, wait, evaluate — a wavefront has nothing in flight while it computes). Every issue is unconditional —
+    // behind the last tile it reads row 0 with every lane (one line per column) — and the loop is unrolled over the two sets, so
+    // that the compiler waits with vmcnt(N > 0) for exactly the older set (qh_join_probe_dense_body, same discipline).
+    typename P::Raw rawA[R], rawB[R];
+    i64 t = blockIdx.x;
+    QH_ISSUE(rawA, t * tile_rows, QH_NROWS)
+    for (;;) {
+      u32 overflowed = QH_OVERFLOWED();
+      const i64 tbA = t * tile_rows;
+      const i64 t1 = t + gridDim.x;
+      const bool more1 = t1 < ntiles;
+      const i64 tbB = more1 ? t1 * tile_rows : 0;
+      QH_ISSUE(rawB, tbB, (more1 ? QH_NROWS : (i64)1))
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#define QH_TILE_RAW rawA
+#define QH_TILE_TB tbA
+#include "qhip_agg_tile.inc"
+#undef QH_TILE_RAW
+#undef QH_TILE_TB
+      if (!more1 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
+      overflowed = QH_OVERFLOWED();
+      const i64 t2 = t1 + gridDim.x;
+      const bool more2 = t2 < ntiles;
+      const i64 tbA2 = more2 ? t2 * tile_rows : 0;
+      QH_ISSUE(rawA, tbA2, (more2 ? QH_NROWS : (i64)1))
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#define QH_TILE_RAW rawB
+#define QH_TILE_TB tbB
+#include "qhip_agg_tile.inc"
+#undef QH_TILE_RAW
+#undef QH_TILE_TB
+      if (!more2 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
+      t = t2;
+    }
+  }
+#undef QH_ISSUE
+#undef QH_OVERFLOWED
+#undef QH_NROWS
 
   // hand the cached groups of this wave to the workgroup's table: one reduction + one update per (wave, key) per KERNEL
 #pragma unroll

@@ -32,6 +32,7 @@ struct InputCol {
   int utf8_max_len = -1;   // longest value of a Utf8 column in bytes when known (sizes packed join / group keys)
   bool utf8_fixed1 = false;   // every value of the Utf8 column is exactly 1 byte long: offsets[i] == i, nothing to load for them
   uint64_t value_maxabs = 0;  // DevColumn::value_maxabs (0 = unknown)
+  int narrow_bytes = 0;       // 4 / 8: the kernel reads the column's narrow copy (DevColumn::narrow) instead of its 16-byte values
   // the column is a deferred gather that the kernel reads THROUGH its index vector (value = source[index[row]]) instead of
   // a gathered copy: what an aggregate / a join build reads from a join output are a few short columns, each a gather launch
   // and a write + read of the copy otherwise (KCol::v = the source values, KCol::d = the u32 index vector)

@@ -17,7 +17,11 @@ static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_
   if (const char* e = getenv("QHIP_PLAN_VALUE_BITS")) {
     int col = 0, bits = 0, used = 0;
     while (*e && sscanf(e, "%d:%d%n", &col, &bits, &used) == 2) {
-      if (col >= 0 && col < n && bits >= 1 && bits <= 63) v[(size_t)col].value_maxabs = (1ULL << bits) - 1;
+      if (col >= 0 && col < n && bits >= 1 && bits <= 63) {
+        v[(size_t)col].value_maxabs = (1ULL << bits) - 1;
+        // (... and the narrow copy an execution makes of such a Decimal128 column, DevColumn::narrow)
+        if (v[(size_t)col].type.id == QHIP_DECIMAL128 && env_int("QHIP_NARROW_DECIMALS", 1) != 0) v[(size_t)col].narrow_bytes = bits <= 31 ? 4 : 8;
+      }
       e += used;
       if (*e == ',') ++e;
     }

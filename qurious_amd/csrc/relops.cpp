@@ -127,6 +127,7 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
 }
 
 void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
+  const bool narrow_ok = env_int("QHIP_NARROW_DECIMALS", 1) != 0;
   for (int k = 0; k < n_exprs; ++k) {
     const qhip_expr& e = exprs[k];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
@@ -146,6 +147,18 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
     uint64_t m = col.value_maxabs;
     if (m != 0 && m != ~0ULL) { int bits = 1; while (bits < 63 && (m >> bits)) ++bits; m = (1ULL << bits) - 1; }
     icols[(size_t)e.column].value_maxabs = m;
+    // every value fits 32 / 64 bits: the kernel reads the column's narrow copy (DevColumn::narrow), made here once per column
+    if (narrow_ok && m != 0 && m != ~0ULL && col.type.id == QHIP_DECIMAL128 && !icols[(size_t)e.column].indirect && col.values && col.length > 0) {
+      const int nb = m < (1ULL << 31) ? 4 : 8;
+      if (!col.narrow || col.narrow->bytes != nb || col.narrow->src != col.values->ptr || col.narrow->rows != col.length) {
+        auto nc = std::make_shared<DevColumn::NarrowCopy>();
+        nc->buf = std::make_shared<DevBuf>((size_t)col.length * (size_t)nb);
+        nc->bytes = nb; nc->src = col.values->ptr; nc->rows = col.length;
+        launch_narrow_decimal(col.values->ptr, (uint64_t)col.length, nb, nc->buf->ptr, ctx->stream);
+        col.narrow = nc;
+      }
+      icols[(size_t)e.column].narrow_bytes = nb;
+    }
   }
 }
 

@@ -233,3 +233,54 @@ def test_bounded_column_read_through_a_joins_index_vector(ctx, oracle, monkeypat
                     mk = m & keep
                     want = int((x_small[mk] * y_small[mk]).sum()) + sum(x_obj[r] * y_obj[r] for r in sp if m[r])
                     assert sums[k] == _wrap(want) and counts[k] == int(m.sum()), (extreme, no_bounds, grp)
+
+
+@pytest.mark.parametrize("extreme,width", [((1 << 31) - 1, 4), (1 << 31, 8), ((1 << 63) - 1, 8), (1 << 63, 16)])
+def test_narrow_copies_of_decimal_columns(ctx, monkeypatch, extreme, width):
+    """A Decimal128 column whose every value fits 32 / 64 bits gets a 4- / 8-byte copy that the aggregate kernel streams
+    instead of the 16-byte values (common.hpp DevColumn::narrow, relops.cpp ensure_value_bounds). Checked: the copy's width at
+    the thresholds (from the bytes per row the kernel reports), negative values and NULL slots, the same sums as with
+    QHIP_NARROW_DECIMALS=0 and as exact Python integers — and that the table's 16-byte values still serve every other operator
+    afterwards (a Filter over the same device table returns the original values)."""
+    rng = np.random.default_rng(extreme % 977)
+    g = rng.integers(0, 3, N).astype(np.int64)
+    small = rng.integers(-50000, 50000, N)
+    rows = rng.permutation(N)[:40]
+    ext = {int(r): (extreme if k % 2 == 0 else -extreme) for k, r in enumerate(rows)}
+    a = _dec_array(small, ext, 38)
+    valid = rng.random(N) > 0.01
+    valid[rows] = True
+    a_nulls = pa.Array.from_buffers(a.type, N, [pa.array(valid).buffers()[1], a.buffers()[1]])
+    schema = pa.schema([pa.field("g", I64, False), pa.field("a", a.type, True)])
+    cuts = list(range(0, N, 1 << 20)) + [N]
+    batches = [pa.RecordBatch.from_arrays([pa.array(g[s:e], I64), a_nulls.slice(s, e - s)], schema=schema) for s, e in zip(cuts[:-1], cuts[1:])]
+    scan = table_scan(schema, batches)
+    t = pa.decimal128(38, 0)
+    out_schema = pa.schema([pa.field("g", I64), pa.field("s", t), pa.field("c", I64)])
+    plan = q.HashAggregate(out_schema, scan, [col("g", 0)], [q.SumAggregateExpr(col("a", 1), t), q.CountAggregateExpr(col("a", 1))])
+
+    def run():
+        out = plan.execute_device()
+        st = ctx.last_stats()
+        b = out.to_batches()[0]
+        return sorted(zip(b.column(0).to_pylist(), _i128_of(b.column(1)), b.column(2).to_pylist())), st
+
+    got, st = run()
+    # 8 bytes of group key + the value column at its narrow width + its validity bits
+    assert abs(st["bytes_per_row_read"] - (8 + width + 0.125)) < 1e-9, st["bytes_per_row_read"]
+    a_obj = small.astype(object)
+    for r, v in ext.items():
+        a_obj[r] = v
+    for grp, s, c in got:
+        m = (g == grp) & valid
+        assert c == int(m.sum())
+        assert s == _wrap(sum(int(v) for v in a_obj[m])), (grp, width)
+    monkeypatch.setenv("QHIP_NARROW_DECIMALS", "0")
+    ctx.forget_plans()
+    wide, st_wide = run()
+    assert wide == got and abs(st_wide["bytes_per_row_read"] - (8 + 16 + 0.125)) < 1e-9
+    monkeypatch.delenv("QHIP_NARROW_DECIMALS")
+    # the canonical 16-byte values are untouched: a Filter over the same device table exports the original extremes
+    keep = q.Filter(scan, q.BinaryExpr(col("a", 1), Operator.Gt, q.CastExpr(q.Literal(S.Int64(60000)), a.type)))
+    kept = [v for b in keep.execute() for v in _i128_of(b.column(1))]
+    assert sorted(kept) == sorted(v for r, v in ext.items() if v > 60000)
