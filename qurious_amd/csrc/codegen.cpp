@@ -675,6 +675,13 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   bool all_narrow = P.W > 0 && !P.cells.empty();
   for (auto& c : P.cells) if (c.kind != CELL_ROWS && !cell_acc64(c)) all_narrow = false;
   if (all_narrow && part_regs > 0) P.KC = std::max(1, std::min(4, 24 / part_regs));
+  // ... and when the kernel streams NARROW COPIES of its decimal columns (InputCol::narrow_bytes: 22 instead of 70 bytes per row
+  // for Q1) it is no longer HBM that bounds it but the LDS: PMC on Q1 at KC = 2 — the quarter of the rows that miss the two
+  // cached keys keep the CU's LDS pipeline busy 76 % of the time (same-address DS atomics: SQ_LDS_BANK_CONFLICT = 26 % of the
+  // CU's cycles). Measured then, kernel + host per query: KC 2 0.522 ms, 3 0.409-0.422, 4 0.298 (R = 2; R = 1: 0.355, 3: 0.349).
+  bool narrow_copies = false;
+  for (auto& ic : input) if (ic.narrow_bytes > 0 && !ic.indirect) narrow_copies = true;
+  if (all_narrow && narrow_copies && part_regs > 0) P.KC = std::max(1, std::min(4, 48 / part_regs));
   if (const char* kc = getenv("QHIP_AGG_KC")) { if (*kc && P.W > 0) P.KC = atoi(kc); }   // tuning experiments only
   if (P.R <= 0) {
     // rows per thread per tile: all loads of a tile are in flight together, so more rows = more memory-level
