@@ -86,6 +86,13 @@ def catalog_sources():
         out.append(("q3 join-1 output dense build", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
         out.append(("q3 orders dense probe", planning.probe_source(ORDERS_SCHEMA, [j1.on[0][1]], j1.right.filter)))
         out.append(("q3 lineitem dense probe", planning.probe_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter)))
+        # ... with the key column read as its 4-byte narrow copy (TPC-H's keys fit 32 bits: relops.cpp ensure_narrow_int_columns)
+        for name, schema, join in (("q3 orders dense probe, narrow key", ORDERS_SCHEMA, j1), ("q3 lineitem dense probe, narrow key", LINEITEM_Q3_SCHEMA, j2)):
+            os.environ["QHIP_PLAN_NARROW_INTS"] = str(join.on[0][1].index)
+            try:
+                out.append((name, planning.probe_source(schema, [join.on[0][1]], join.right.filter)))
+            finally:
+                os.environ.pop("QHIP_PLAN_NARROW_INTS", None)
         os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
         out.append(("q3 join-1 output dense build, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
         # ... which reads its key through join 1's index vector (a deferred gather, InputCol::indirect)

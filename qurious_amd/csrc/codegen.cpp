@@ -182,7 +182,8 @@ void ExprGen::emit(int k, std::string& out) {
         o << "    const int " << v << " = 0;\n";
       } else {
         // a Decimal128 column with a narrow copy (InputCol::narrow_bytes): the kernel loads 4 / 8 bytes per value and widens
-        const int nb = n.type.id == QHIP_DECIMAL128 && !in_[(size_t)n.column].indirect ? in_[(size_t)n.column].narrow_bytes : 0;
+        const int nb = (n.type.id == QHIP_DECIMAL128 || (n.type.id == QHIP_INT64 && in_[(size_t)n.column].narrow_bytes == 4)) && !in_[(size_t)n.column].indirect
+                           ? in_[(size_t)n.column].narrow_bytes : 0;
         const std::string LT = nb == 4 ? "int" : nb == 8 ? "i64" : ctype(n.type);   // the type in memory
         field(LT, v);
         {
@@ -956,7 +957,11 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
   if (raw) {
-    out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", 2) : env_int("QHIP_PROBE_R", 4)));
+    // (dense probe: a lane owns R consecutive rows, 16 bytes of an 8-byte key column at R = 2 — and of its 4-byte narrow copy at
+    // R = 4: Q3's lineitem probe 112 -> 104 us)
+    bool narrow_key = false;
+    for (auto& ic : input) if (ic.narrow_bytes == 4 && ic.type.id == QHIP_INT64 && !ic.indirect) narrow_key = true;
+    out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", narrow_key ? 4 : 2) : env_int("QHIP_PROBE_R", 4)));
     s << "  static constexpr int PROBE_R = " << out.probe_r << ";\n";
     s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
     s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";

@@ -95,6 +95,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
   ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
   ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
+  ensure_narrow_int_columns(ctx, R, rex, nrex, rcols, (int64_t)1 << 22);   // (the probe side streams its key column: 4 bytes where they do)
   // both sides must pack a Utf8 key into the same number of words
   for (int k = 0; k < n_on; ++k) {
     if (on_l[k] < 0 || on_l[k] >= nlex || on_r[k] < 0 || on_r[k] >= nrex) fail(QHIP_INVALID_ARGUMENT, "join key index out of range");
@@ -154,7 +155,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     auto put = [&](const void* p, size_t n) { pkey.append((const char*)p, n); };
     for (const std::vector<InputCol>* cols : {&lcols, &rcols}) {
       for (auto& ic : *cols) {
-        const int v[7] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0};
+        const int v[8] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0, ic.narrow_bytes};
         put(v, sizeof v);
       }
       put("|", 1);
@@ -641,10 +642,11 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // bytes of column data the probe kernel / the build's key evaluation read per row (roofline figures)
   auto bytes_per_row = [&](const qhip_table* t, const KernelBindings& b) {
     double sum = 0;
-    for (int c : b.cols) {
+    for (size_t k = 0; k < b.cols.size(); ++k) {
+      const int c = b.cols[k];
       const DevColumn& dc = t->cols[(size_t)c];
       const int w = dtype_width(dc.type);
-      if (w > 0) sum += w;
+      if (w > 0) sum += k < b.narrow.size() && b.narrow[k] ? (int)b.narrow[k] : w;   // (a key column read as its 4-byte narrow copy)
       else if (dc.type.id == QHIP_BOOL) sum += 0.125;
       else if (dc.type.id == QHIP_UTF8) sum += 4.0 + (t->num_rows > 0 ? (double)dc.data_bytes / (double)t->num_rows : 0.0);
       if (dc.null_count > 0) sum += 0.125;

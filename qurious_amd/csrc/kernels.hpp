@@ -28,7 +28,8 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
 // out[0] = max |v| of the 63-bit values of an Int64 (words 1) / Decimal128 (words 2) column, out[1] != 0: some value is wider
 void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s);
 // out[i] = the low 4 / 8 bytes of the 16-byte value i (the narrow copy of a Decimal128 column whose values fit, DevColumn::narrow)
-void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s);
+// (src_words = 1: the source is an Int64 column, bytes = 4)
+void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words = 2);
 // out[0] / out[1] (zero-filled u64 words): order-preserving images of the max / the complement of the min of an integer column
 void launch_value_range(const void* values, uint64_t n, int width, bool is_signed, uint64_t* out, hipStream_t s);
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s);

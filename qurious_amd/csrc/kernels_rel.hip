@@ -372,9 +372,9 @@ __global__ __launch_bounds__(QH_BLOCK) void k_value_maxabs(const u64* v, u64 n, 
 }
 
 // the narrow copy of a Decimal128 column whose every value fits T (DevColumn::narrow): the low bytes of the two's complement value
-template <class T>
+template <class T, int WORDS>
 __global__ __launch_bounds__(QH_BLOCK) void k_narrow_decimal(const u64* v, u64 n, T* out) {
-  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (T)v[2 * i];
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) out[i] = (T)v[WORDS * i];
 }
 
 // Value range of an integer-like column (sign-extended to 64 bits): out[0] = max of (v ^ sign bit), out[1] = max of
@@ -962,11 +962,12 @@ void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* ou
   if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
   else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
 }
-void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s) {
+void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words) {
   if (!n) return;
   const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);
-  if (bytes == 4) hipLaunchKernelGGL(k_narrow_decimal<u32>, g, b, 0, s, (const u64*)values, (u64)n, (u32*)out);
-  else hipLaunchKernelGGL(k_narrow_decimal<u64>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
+  if (src_words == 1) hipLaunchKernelGGL((k_narrow_decimal<u32, 1>), g, b, 0, s, (const u64*)values, (u64)n, (u32*)out);   // Int64 -> 4 bytes
+  else if (bytes == 4) hipLaunchKernelGGL((k_narrow_decimal<u32, 2>), g, b, 0, s, (const u64*)values, (u64)n, (u32*)out);
+  else hipLaunchKernelGGL((k_narrow_decimal<u64, 2>), g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
 }
 void launch_value_range(const void* values, uint64_t n, int width, bool is_signed, uint64_t* out, hipStream_t s) {
   if (!n) return;

@@ -26,6 +26,16 @@ static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_
       if (*e == ',') ++e;
     }
   }
+  // QHIP_PLAN_NARROW_INTS="0,2": these Int64 columns are read through 4-byte narrow copies (what a big probe side's key columns
+  // get at run time when their value range fits, relops.cpp ensure_narrow_int_columns)
+  if (const char* e = getenv("QHIP_PLAN_NARROW_INTS")) {
+    int col = 0, used = 0;
+    while (*e && sscanf(e, "%d%n", &col, &used) == 1) {
+      if (col >= 0 && col < n && v[(size_t)col].type.id == QHIP_INT64) v[(size_t)col].narrow_bytes = 4;
+      e += used;
+      if (*e == ',') ++e;
+    }
+  }
   // QHIP_PLAN_UTF8_FIXED1="1,2": every value of these Utf8 columns is exactly one byte long (what an execution finds out on the
   // device for TPC-H's flag columns, relops.cpp ensure_utf8_key_lengths): the kernel addresses their bytes by row number
   if (const char* e = getenv("QHIP_PLAN_UTF8_FIXED1")) {

@@ -162,6 +162,31 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   }
 }
 
+// Int64 columns read by a big probe side (join keys: TPC-H's order and customer keys) whose values fit 32 bits get a 4-byte
+// narrow copy too (DevColumn::narrow), decided from the column's value RANGE (DevColumn::range: computed once per table column,
+// key_range_of) — Q3's lineitem probe then streams 8 instead of 12 bytes per row.
+void ensure_narrow_int_columns(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
+  if (env_int("QHIP_NARROW_INTS", 1) == 0 || t->num_rows < min_rows) return;
+  for (int k = 0; k < n_exprs; ++k) {
+    const qhip_expr& e = exprs[k];
+    if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
+    if (t->cols[(size_t)e.column].type.id != QHIP_INT64 || icols[(size_t)e.column].indirect) continue;
+    const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
+    if (!col.values || col.length < min_rows) continue;
+    int64_t mn = 0, mx = 0;
+    if (!key_range_of(ctx, col, mn, mx) || col.range_inherited) continue;   // (an inherited range is a superset's: still valid bounds, but only base columns are worth a copy)
+    if (mn < -(int64_t)0x7fffffff || mx > (int64_t)0x7fffffff) continue;
+    if (!col.narrow || col.narrow->bytes != 4 || col.narrow->src != col.values->ptr || col.narrow->rows != col.length) {
+      auto nc = std::make_shared<DevColumn::NarrowCopy>();
+      nc->buf = std::make_shared<DevBuf>((size_t)col.length * 4);
+      nc->bytes = 4; nc->src = col.values->ptr; nc->rows = col.length;
+      launch_narrow_decimal(col.values->ptr, (uint64_t)col.length, 4, nc->buf->ptr, ctx->stream, 1);
+      col.narrow = nc;
+    }
+    icols[(size_t)e.column].narrow_bytes = 4;
+  }
+}
+
 // Value range of an integer-like column (DevColumn::range): known, inherited from the column it was gathered from, or
 // computed now — one reduction + one read-back — over the base column's values: for a deferred gather that is its SOURCE
 // (the base table's column, whose ColRange object every query's gathers share), so a table's key range is found once.

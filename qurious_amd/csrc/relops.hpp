@@ -46,6 +46,8 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
 // |value| bounds of the Int64 / Decimal128 columns the expressions reference (DevColumn::value_maxabs -> icols): computed
 // (one reduction + one read-back per column, cached on the column) only for inputs of `min_rows` rows or more
 void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
+// 4-byte narrow copies of the Int64 columns (join keys) a big probe side's expressions reference, where the value range allows
+void ensure_narrow_int_columns(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 // [mn, mx] of an integer-like column's values (cached on the column and shared with its source table, DevColumn::range);
 // false when the column has no values to look at / is not integer-like
 bool key_range_of(Ctx* ctx, const DevColumn& col, int64_t& mn, int64_t& mx);
