@@ -89,7 +89,10 @@ typedef enum qhip_type_id {
   QHIP_FLOAT32 = 10, QHIP_FLOAT64 = 11,
   QHIP_DATE32 = 12, QHIP_DATE64 = 13,
   QHIP_DECIMAL128 = 14,
-  QHIP_UTF8 = 15
+  QHIP_UTF8 = 15,
+  /* Time32(Second | Millisecond) = i32, Time64(Microsecond | Nanosecond) = i64: key / comparison / MIN-MAX types of
+     create_hashes (utils/array.rs:199-202); no arithmetic and no casts are defined on them here */
+  QHIP_TIME32_S = 16, QHIP_TIME32_MS = 17, QHIP_TIME64_US = 18, QHIP_TIME64_NS = 19
 } qhip_type_id;
 
 typedef struct qhip_dtype {

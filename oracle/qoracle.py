@@ -126,7 +126,8 @@ def siphash13_chunks(chunks: Sequence[bytes]) -> int:
 
 _NP = {pa.int8(): np.int8, pa.int16(): np.int16, pa.int32(): np.int32, pa.int64(): np.int64, pa.uint8(): np.uint8,
        pa.uint16(): np.uint16, pa.uint32(): np.uint32, pa.uint64(): np.uint64, pa.float32(): np.float32,
-       pa.float64(): np.float64, pa.date32(): np.int32, pa.date64(): np.int64}
+       pa.float64(): np.float64, pa.date32(): np.int32, pa.date64(): np.int64, pa.time32("s"): np.int32, pa.time32("ms"): np.int32,
+       pa.time64("us"): np.int64, pa.time64("ns"): np.int64}
 
 
 class Col:
@@ -224,7 +225,8 @@ def _result_type(arr: pa.Array, c: qo_col) -> pa.DataType:
     table = {D.T_BOOL: pa.bool_(), D.T_INT8: pa.int8(), D.T_INT16: pa.int16(), D.T_INT32: pa.int32(), D.T_INT64: pa.int64(),
              D.T_UINT8: pa.uint8(), D.T_UINT16: pa.uint16(), D.T_UINT32: pa.uint32(), D.T_UINT64: pa.uint64(),
              D.T_FLOAT32: pa.float32(), D.T_FLOAT64: pa.float64(), D.T_DATE32: pa.date32(), D.T_DATE64: pa.date64(),
-             D.T_UTF8: pa.string(), D.T_NULL: pa.null()}
+             D.T_UTF8: pa.string(), D.T_NULL: pa.null(), D.T_TIME32_S: pa.time32("s"), D.T_TIME32_MS: pa.time32("ms"),
+             D.T_TIME64_US: pa.time64("us"), D.T_TIME64_NS: pa.time64("ns")}
     if tid == D.T_DECIMAL128:
         return pa.decimal128(c.type.precision, c.type.scale)
     return table[tid]
@@ -503,8 +505,8 @@ def _dense_rank(arr: pa.Array) -> np.ndarray:
         keys = np.array([(int(v.scaleb(sc)) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
     elif pa.types.is_boolean(t):
         keys = np.array([(int(v) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
-    elif pa.types.is_date(t):
-        keys = np.array([0 if v is None else v for v in arr.cast(pa.int32() if pa.types.is_date32(t) else pa.int64()).to_pylist()], dtype=object)
+    elif pa.types.is_date(t) or pa.types.is_time(t):
+        keys = np.array([0 if v is None else v for v in arr.cast(pa.int32() if (pa.types.is_date32(t) or pa.types.is_time32(t)) else pa.int64()).to_pylist()], dtype=object)
     elif pa.types.is_null(t):
         keys = np.zeros(n, dtype=object)
     else:
@@ -701,7 +703,7 @@ def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
             words.append(raw[:, 0].copy())
             words.append(raw[:, 1].copy())
         else:
-            v = np.array(a.cast(pa.int64() if not pa.types.is_date32(t) else pa.int32()).fill_null(0)).astype(np.int64)
+            v = np.array(a.cast(pa.int32() if (pa.types.is_date32(t) or pa.types.is_time32(t)) else pa.int64()).fill_null(0)).astype(np.int64)
             words.append(v.view(np.uint64).copy())
     h = np.zeros(n, dtype=np.uint64)
     with np.errstate(over="ignore"):

@@ -34,8 +34,8 @@ std::string ExprGen::ctype(const DType& t) {
     case QHIP_BOOL: return "bool";
     case QHIP_INT8: return "signed char";
     case QHIP_INT16: return "short";
-    case QHIP_INT32: case QHIP_DATE32: return "int";
-    case QHIP_INT64: case QHIP_DATE64: return "i64";
+    case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "int";
+    case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "i64";
     case QHIP_UINT8: return "u8";
     case QHIP_UINT16: return "u16";
     case QHIP_UINT32: return "u32";
@@ -54,16 +54,19 @@ std::string ExprGen::i128_const(i128 v) {
   return buf;
 }
 
+// (Time32 / Time64 are signed integers as far as key words, MIN / MAX images and sort keys go; the typing in expr.cpp keeps
+// arithmetic and casts away from them)
+static bool timelike(const DType& t) { return t.id >= QHIP_TIME32_S && t.id <= QHIP_TIME64_NS; }
 static bool intlike(const DType& t) {
-  return (t.id >= QHIP_INT8 && t.id <= QHIP_UINT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64;
+  return (t.id >= QHIP_INT8 && t.id <= QHIP_UINT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 || timelike(t);
 }
-static bool signed_intlike(const DType& t) { return (t.id >= QHIP_INT8 && t.id <= QHIP_INT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64; }
+static bool signed_intlike(const DType& t) { return (t.id >= QHIP_INT8 && t.id <= QHIP_INT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 || timelike(t); }
 static std::string int_min(const DType& t) {
   switch (t.id) {
     case QHIP_INT8: return "(-128)";
     case QHIP_INT16: return "(-32768)";
-    case QHIP_INT32: case QHIP_DATE32: return "(-2147483647-1)";
-    case QHIP_INT64: case QHIP_DATE64: return "(-9223372036854775807LL-1)";
+    case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "(-2147483647-1)";
+    case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "(-9223372036854775807LL-1)";
     default: return "0";
   }
 }
@@ -71,8 +74,8 @@ static std::string int_max(const DType& t) {
   switch (t.id) {
     case QHIP_INT8: return "127";
     case QHIP_INT16: return "32767";
-    case QHIP_INT32: case QHIP_DATE32: return "2147483647";
-    case QHIP_INT64: case QHIP_DATE64: return "9223372036854775807LL";
+    case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "2147483647";
+    case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "9223372036854775807LL";
     case QHIP_UINT8: return "255";
     case QHIP_UINT16: return "65535";
     case QHIP_UINT32: return "4294967295U";
@@ -478,11 +481,12 @@ void ExprGen::emit(int k, std::string& out) {
 // ---------------------------------------------------------------- key packing shared by aggregate / join / partition kernels
 // Key types: the reference's create_hashes (utils/array.rs:190-210) hashes Int64, UInt8, Int32, Utf8, Date32 / Date64,
 // Time32 / Time64, Decimal128 and Decimal256 and raises an InternalError for anything else. The HIP path takes the same list
-// MINUS Time32 / Time64 (no such type id crosses the C ABI: qhip_type_id) and Decimal256 (out of scope): a plan with
-// such a key gets the reference's own error text here and the shim keeps the CPU node — a documented gap, not a drop-in.
+// MINUS Decimal256 (out of scope, DESIGN §8: no such type id crosses the C ABI): a plan with such a key gets the reference's
+// own error text here and the shim keeps the CPU node — a documented gap, not a drop-in.
 static void check_key_type(const DType& t) {
   switch (t.id) {
     case QHIP_INT64: case QHIP_UINT8: case QHIP_INT32: case QHIP_UTF8: case QHIP_DATE32: case QHIP_DATE64: case QHIP_DECIMAL128:
+    case QHIP_TIME32_S: case QHIP_TIME32_MS: case QHIP_TIME64_US: case QHIP_TIME64_NS:
       return;
     default:
       fail(QHIP_INVALID_ARGUMENT, "Internal error: Unsupported data type in hasher: " + dtype_name(t));

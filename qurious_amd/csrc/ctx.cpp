@@ -112,6 +112,10 @@ std::string dtype_name(const DType& t) {
     case QHIP_FLOAT64: return "Float64";
     case QHIP_DATE32: return "Date32";
     case QHIP_DATE64: return "Date64";
+    case QHIP_TIME32_S: return "Time32(Second)";
+    case QHIP_TIME32_MS: return "Time32(Millisecond)";
+    case QHIP_TIME64_US: return "Time64(Microsecond)";
+    case QHIP_TIME64_NS: return "Time64(Nanosecond)";
     case QHIP_DECIMAL128: return "Decimal128(" + std::to_string(t.precision) + ", " + std::to_string(t.scale) + ")";
     case QHIP_UTF8: return "Utf8";
   }
@@ -122,8 +126,8 @@ int dtype_width(const DType& t) {
   switch (t.id) {
     case QHIP_INT8: case QHIP_UINT8: return 1;
     case QHIP_INT16: case QHIP_UINT16: return 2;
-    case QHIP_INT32: case QHIP_UINT32: case QHIP_FLOAT32: case QHIP_DATE32: return 4;
-    case QHIP_INT64: case QHIP_UINT64: case QHIP_FLOAT64: case QHIP_DATE64: return 8;
+    case QHIP_INT32: case QHIP_UINT32: case QHIP_FLOAT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return 4;
+    case QHIP_INT64: case QHIP_UINT64: case QHIP_FLOAT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return 8;
     case QHIP_DECIMAL128: return 16;
     default: return 0;
   }
@@ -148,6 +152,10 @@ std::string dtype_to_format(const DType& t) {
     case QHIP_FLOAT64: return "g";
     case QHIP_DATE32: return "tdD";
     case QHIP_DATE64: return "tdm";
+    case QHIP_TIME32_S: return "tts";
+    case QHIP_TIME32_MS: return "ttm";
+    case QHIP_TIME64_US: return "ttu";
+    case QHIP_TIME64_NS: return "ttn";
     case QHIP_DECIMAL128: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
     case QHIP_UTF8: return "u";
   }
@@ -170,6 +178,10 @@ DType dtype_from_format(const char* f) {
   if (s == "g") return DType(QHIP_FLOAT64);
   if (s == "tdD") return DType(QHIP_DATE32);
   if (s == "tdm") return DType(QHIP_DATE64);
+  if (s == "tts") return DType(QHIP_TIME32_S);
+  if (s == "ttm") return DType(QHIP_TIME32_MS);
+  if (s == "ttu") return DType(QHIP_TIME64_US);
+  if (s == "ttn") return DType(QHIP_TIME64_NS);
   if (s == "u") return DType(QHIP_UTF8);
   if (s.rfind("d:", 0) == 0) {
     int p = 0, sc = 0, bits = 128;

@@ -81,7 +81,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       lex[on_l[0]].column < (int)L->cols.size()) {
     const DevColumn& kc = L->cols[(size_t)lex[on_l[0]].column];
     const int id = kc.type.id;
-    if ((id == QHIP_INT64 || id == QHIP_INT32 || id == QHIP_UINT8 || id == QHIP_DATE32 || id == QHIP_DATE64) && key_range_of(ctx, kc, kmin, kmax)) {
+    if ((id == QHIP_INT64 || id == QHIP_INT32 || id == QHIP_UINT8 || id == QHIP_DATE32 || id == QHIP_DATE64 || (id >= QHIP_TIME32_S && id <= QHIP_TIME64_NS)) &&
+        key_range_of(ctx, kc, kmin, kmax)) {
       const uint64_t span = (uint64_t)kmax - (uint64_t)kmin;   // (kmax >= kmin; the difference fits 64 unsigned bits)
       if (span < (1ULL << 30) && (dense_mode == 2 || span < 256 * B + 65536)) { dense_candidate = true; dense_n = span + 1; }
     }

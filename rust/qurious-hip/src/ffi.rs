@@ -36,6 +36,10 @@ pub const QHIP_DATE32: i32 = 12;
 pub const QHIP_DATE64: i32 = 13;
 pub const QHIP_DECIMAL128: i32 = 14;
 pub const QHIP_UTF8: i32 = 15;
+pub const QHIP_TIME32_S: i32 = 16;
+pub const QHIP_TIME32_MS: i32 = 17;
+pub const QHIP_TIME64_US: i32 = 18;
+pub const QHIP_TIME64_NS: i32 = 19;
 
 // ---------------------------------------------------------------- qhip_expr_kind
 pub const QHIP_EXPR_COLUMN: i32 = 0;

@@ -9,7 +9,7 @@ use std::ffi::CString;
 use std::os::raw::c_char;
 use std::sync::Arc;
 
-use arrow::datatypes::{DataType, Schema, SchemaRef};
+use arrow::datatypes::{DataType, Schema, SchemaRef, TimeUnit};
 use qurious::common::table_schema::FIELD_QUALIFIERS_META_KEY;
 use qurious::datatypes::operator::Operator;
 use qurious::datatypes::scalar::ScalarValue;
@@ -62,6 +62,10 @@ pub fn dtype_of(t: &DataType) -> HipResult<qhip_dtype> {
         DataType::Date32 => QHIP_DATE32,
         DataType::Date64 => QHIP_DATE64,
         DataType::Utf8 => QHIP_UTF8,
+        DataType::Time32(TimeUnit::Second) => QHIP_TIME32_S,
+        DataType::Time32(TimeUnit::Millisecond) => QHIP_TIME32_MS,
+        DataType::Time64(TimeUnit::Microsecond) => QHIP_TIME64_US,
+        DataType::Time64(TimeUnit::Nanosecond) => QHIP_TIME64_NS,
         DataType::Decimal128(p, s) => {
             return Ok(qhip_dtype { id: QHIP_DECIMAL128, precision: *p as i32, scale: *s as i32 });
         }

@@ -1,0 +1,122 @@
+"""Time32(Second | Millisecond) and Time64(Microsecond | Nanosecond) as hash keys, comparison operands and MIN / MAX arguments.
+
+The reference's `create_hashes` hashes them (utils/array.rs:199-202: group keys of hash.rs:46-69, join keys of
+hash_join.rs:161), arrow's comparison kernels order them as their i32 / i64 storage, and the MIN / MAX accumulators take
+them (aggregate/mod.rs:104-107). Every test runs on the `engine` fixture — the CPU oracle under -m "not gpu" (pins the
+restatement) and the HIP path through the C ABI under -m gpu — against results computed here with numpy / pyarrow on the
+storage integers. No arithmetic and no casts are defined on these types (include/qhip.h)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import qurious_amd as q
+from qurious_amd import JoinType, Operator
+
+from .helpers import col, table_scan
+
+TYPES = [(pa.time32("s"), pa.int32(), 86400), (pa.time32("ms"), pa.int32(), 86400 * 1000), (pa.time64("us"), pa.int64(), 86400 * 10**6),
+         (pa.time64("ns"), pa.int64(), 86400 * 10**9)]
+
+
+def _time_array(storage_values, valid, ttype, stype):
+    return pa.array(np.asarray(storage_values), type=stype, mask=~np.asarray(valid)).cast(ttype)
+
+
+def _storage(arr, stype):
+    return arr.cast(stype).to_pylist()
+
+
+@pytest.mark.parametrize("ttype,stype,day", TYPES, ids=[str(t[0]) for t in TYPES])
+def test_group_by_time_key_with_min_max(engine, ttype, stype, day):
+    rng = np.random.default_rng(day % 97)
+    n = 5000
+    keys = rng.integers(0, 40, n) * (day // 48)            # 40 distinct times of day
+    valid = rng.random(n) > 0.05
+    vals = rng.integers(0, day, n)
+    t = _time_array(keys, valid, ttype, stype)
+    v = _time_array(vals, np.ones(n, bool), ttype, stype)
+    x = pa.array(rng.integers(-1000, 1000, n), pa.int64())
+    schema = pa.schema([pa.field("t", ttype), pa.field("v", ttype), pa.field("x", pa.int64())])
+    cuts = [0, 1700, 1700, 3900, n]                        # ragged batches, one of them empty
+    batches = [pa.RecordBatch.from_arrays([t.slice(s, e - s), v.slice(s, e - s), x.slice(s, e - s)], schema=schema) for s, e in zip(cuts[:-1], cuts[1:])]
+    out_schema = pa.schema([pa.field("t", ttype), pa.field("s", pa.int64()), pa.field("c", pa.int64()), pa.field("lo", ttype), pa.field("hi", ttype)])
+    plan = q.HashAggregate(out_schema, table_scan(schema, batches), [col("t", 0)],
+                           [q.SumAggregateExpr(col("x", 2), pa.int64()), q.CountAggregateExpr(col("x", 2)), q.MinAggregateExpr(col("v", 1), ttype),
+                            q.MaxAggregateExpr(col("v", 1), ttype)])
+    got = engine.execute(plan)
+    assert all(b.schema.field(0).type == ttype and b.schema.field(3).type == ttype for b in got)
+    rows = {}
+    for b in got:
+        for k, s, c, lo, hi in zip(_storage(b.column(0), stype), b.column(1).to_pylist(), b.column(2).to_pylist(), _storage(b.column(3), stype),
+                                   _storage(b.column(4), stype)):
+            assert k not in rows
+            rows[k] = (s, c, lo, hi)
+    xs = np.asarray(x.to_pylist())
+    want = {}
+    for k in set(int(a) if ok else None for a, ok in zip(keys, valid)):
+        m = (~valid) if k is None else (valid & (keys == k))
+        want[k] = (int(xs[m].sum()), int(m.sum()), int(vals[m].min()), int(vals[m].max()))
+    assert rows == want
+
+
+@pytest.mark.parametrize("ttype,stype,day", TYPES, ids=[str(t[0]) for t in TYPES])
+@pytest.mark.parametrize("join_type", [JoinType.Inner, JoinType.Left, JoinType.Full, JoinType.LeftAnti])
+def test_join_on_time_key(engine, ttype, stype, day, join_type):
+    rng = np.random.default_rng(day % 89 + int(join_type))
+    nb, npr = 300, 2000
+    step = day // 1000
+    bkeys = rng.permutation(1000)[:nb] * step              # unique build keys (a small range: the dense layout applies on the GPU)
+    pkeys = rng.integers(0, 1000, npr) * step
+    bvalid = rng.random(nb) > 0.03
+    pvalid = rng.random(npr) > 0.03
+    ls = pa.schema([pa.field("lt", ttype), pa.field("lv", pa.int64())])
+    rs = pa.schema([pa.field("rt", ttype), pa.field("rv", pa.int64())])
+    lb = pa.RecordBatch.from_arrays([_time_array(bkeys, bvalid, ttype, stype), pa.array(np.arange(nb), pa.int64())], schema=ls)
+    rb = [pa.RecordBatch.from_arrays([_time_array(pkeys[s:e], pvalid[s:e], ttype, stype), pa.array(np.arange(s, e), pa.int64())], schema=rs)
+          for s, e in ((0, 900), (900, npr))]
+    plan = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, rb), join_type, [(col("lt", 0), col("rt", 0))])
+    got = engine.execute(plan)
+    got_rows = sorted((tuple(r) for b in got for r in zip(*[(_storage(c, stype) if pa.types.is_time(c.type) else c.to_pylist()) for c in b.columns])),
+                      key=lambda r: tuple((x is None, x) for x in r))
+    index = {int(k): i for i, (k, ok) in enumerate(zip(bkeys, bvalid)) if ok}
+    want, hit = [], set()
+    for j in range(npr):
+        i = index.get(int(pkeys[j])) if pvalid[j] else None
+        if i is not None:
+            hit.add(i)
+            if join_type not in (JoinType.LeftAnti,):
+                want.append((int(bkeys[i]), i, int(pkeys[j]), j))
+        elif join_type == JoinType.Full:
+            want.append((None, None, int(pkeys[j]) if pvalid[j] else None, j))
+    if join_type in (JoinType.Left, JoinType.Full):
+        want += [((int(bkeys[i]) if bvalid[i] else None), i, None, None) for i in range(nb) if i not in hit]
+    if join_type == JoinType.LeftAnti:
+        want = [((int(bkeys[i]) if bvalid[i] else None), i) for i in range(nb) if i not in hit]
+    assert got_rows == sorted(want, key=lambda r: tuple((x is None, x) for x in r))
+
+
+@pytest.mark.parametrize("ttype,stype,day", TYPES, ids=[str(t[0]) for t in TYPES])
+def test_filter_and_sort_on_time_columns(engine, ttype, stype, day):
+    rng = np.random.default_rng(day % 83)
+    n = 3000
+    a = rng.integers(0, day, n)
+    b = rng.integers(0, day, n)
+    av, bv = rng.random(n) > 0.04, rng.random(n) > 0.04
+    schema = pa.schema([pa.field("a", ttype), pa.field("b", ttype), pa.field("i", pa.int64())])
+    batch = pa.RecordBatch.from_arrays([_time_array(a, av, ttype, stype), _time_array(b, bv, ttype, stype), pa.array(np.arange(n), pa.int64())], schema=schema)
+    kept = engine.execute(q.Filter(table_scan(schema, [batch.slice(0, 1000), batch.slice(1000)]), q.BinaryExpr(col("a", 0), Operator.Lt, col("b", 1))))
+    assert [i for bt in kept for i in bt.column(2).to_pylist()] == [i for i in range(n) if av[i] and bv[i] and a[i] < b[i]]
+    top = q.DefaultQueryPlanner().physical_plan_sort(table_scan(schema, [batch]), [(col("a", 0), True), (col("i", 2), False)])
+    out = engine.execute(top)
+    order = [i for bt in out for i in bt.column(2).to_pylist()]
+    want = sorted(range(n), key=lambda i: ((0, 0) if not av[i] else (1, int(a[i])), -i))   # NULLs first, ascending a; ties by i descending
+    assert order == want
+
+
+def test_unsupported_operations_on_time_types_are_errors(engine):
+    ttype = pa.time32("s")
+    schema = pa.schema([pa.field("a", ttype), pa.field("b", ttype)])
+    batch = pa.RecordBatch.from_arrays([pa.array([1, 2], pa.int32()).cast(ttype)] * 2, schema=schema)
+    plan = q.Projection(None, table_scan(schema, [batch]), [q.BinaryExpr(col("a", 0), Operator.Add, col("b", 1))])
+    with pytest.raises(Exception):
+        engine.execute(plan)
