@@ -164,17 +164,19 @@ def pmc_traffic(workload, kernel, rows, bytes_per_row):
 
 
 def roofline(kernel, kernel_ms, bytes_per_launch, traffic=None, traffic_source=None, algorithmic_bytes_per_launch=None, **extra):
-    """`achieved` = ALGORITHMIC bytes per launch / the kernel's mean duration (the contract's definition; SURVEY §8d's bytes per
-    row x rows when given, else the bytes the kernel reads); `bytes_read_per_launch` = what the kernel actually reads from its
-    column buffers, with the rate and fraction on THOSE bytes beside it. The two differ where the kernel streams narrow copies
-    of Decimal128 columns (4- / 8-byte copies of columns whose values fit): less traffic than the algorithm's
-    Arrow layout implies, so `frac` can exceed what HBM could deliver for the algorithmic bytes."""
+    """`achieved` / `frac` = the bytes the kernel READS per launch (qhip_exec_stats.bytes_per_row_read x rows: what it must pull
+    from HBM in the layout it streams, checked against the PMC `traffic`) / its mean duration — a physical rate, never above
+    the peak, the same convention as rounds 1-2. Where the kernel streams narrow copies of Decimal128 / Int64 columns (DESIGN
+    §2) those bytes are fewer than the ALGORITHMIC bytes of the Arrow layout (SURVEY §8d's figure x rows): that figure, and the
+    rate and fraction it would imply, are reported beside it as `algorithmic_*` — they can exceed the HBM peak, which is the
+    point of the narrow layout, not a measurement of the memory system."""
     per_s = 1.0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    alg = bytes_per_launch if algorithmic_bytes_per_launch is None else algorithmic_bytes_per_launch
-    r = {"bound": "hbm", "achieved": alg * per_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg * per_s / HBM_PEAK_GBS,
+    r = {"bound": "hbm", "achieved": bytes_per_launch * per_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch * per_s / HBM_PEAK_GBS,
          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": kernel_ms,
-         "algorithmic_bytes_per_launch": alg, "bytes_read_per_launch": bytes_per_launch,
-         "achieved_on_bytes_read": bytes_per_launch * per_s, "frac_on_bytes_read": bytes_per_launch * per_s / HBM_PEAK_GBS}
+         "bytes_read_per_launch": bytes_per_launch}
+    if algorithmic_bytes_per_launch is not None:
+        r.update({"algorithmic_bytes_per_launch": algorithmic_bytes_per_launch, "algorithmic_achieved": algorithmic_bytes_per_launch * per_s,
+                  "algorithmic_frac": algorithmic_bytes_per_launch * per_s / HBM_PEAK_GBS})
     r.update(extra)
     return r
 
