@@ -277,6 +277,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const int slot_bytes = plan.slot_words * 8;
   // LDS-staged table: as many slots as fit the per-workgroup LDS budget
   uint32_t l_nslots = 0;
+  bool wide = false;
   if (plan.W > 0) {
     // Many groups (the plan's previous run says so) on a mid-sized input: every workgroup's LDS table ends up full and is
     // merged slot by slot into the HBM table at the end, the heavy keys by EVERY workgroup — same-slot atomic traffic that
@@ -286,13 +287,21 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // 1 M groups, tools/highcard_timing.py) the rows that miss the LDS table dominate and more workgroups hide their
     // latency better (4.7 vs 5.3 ms), so the default shape stays.
     const bool merge_heavy = plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
-    const int lds_budget = env_int("QHIP_AGG_LDS_BYTES", merge_heavy ? 64 * 1024 : 32 * 1024);
+    // ... and since round 3 that one workgroup per CU has 1024 threads (qk_filter_agg_wide) and a table of up to 128 KB: PMC
+    // on configs[4]'s slice showed the four wavefronts per CU of the 256-thread shape waiting 77 % of their time (1.6 M HBM
+    // atomics and 0.4 GB of random reads in 0.35 ms: neither a throughput limit) — a latency chain per row with too few rows in
+    // flight; more 256-thread workgroups hide it but multiply the end-of-kernel merges (1 / 2 / 4 / 8 per CU: 352 / 399 / 557 /
+    // 683 us), sixteen wavefronts on ONE table do not
+    wide = merge_heavy && env_int("QHIP_AGG_WIDE", 1) != 0;
+    const int lds_budget = env_int("QHIP_AGG_LDS_BYTES", wide ? 128 * 1024 : merge_heavy ? 64 * 1024 : 32 * 1024);
     l_nslots = 16;
     while ((uint64_t)l_nslots * 2 * slot_bytes <= (uint64_t)lds_budget) l_nslots *= 2;
-    if ((uint64_t)l_nslots * slot_bytes > 64 * 1024) l_nslots = 0;   // slot too wide for LDS staging
+    if ((uint64_t)l_nslots * slot_bytes > (wide ? 128 : 64) * 1024) l_nslots = 0;   // slot too wide for LDS staging
+    if (l_nslots == 0) wide = false;
   }
   const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
-  const int64_t tile_rows = (int64_t)256 * plan.R;
+  const int block = wide ? 1024 : 256;
+  const int64_t tile_rows = (int64_t)block * plan.R;
   const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
   const bool merge_heavy_grid = plan.W > 0 && plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
   const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : merge_heavy_grid ? 1 : 4);
@@ -632,8 +641,14 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       }
       }
 
-    } else if (N > 0)
-      QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+    } else if (N > 0) {
+      if (wide) {
+        std::shared_ptr<Module> wmod = get_module(ctx, plan.source, "qk_filter_agg_wide");
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(wmod->fn, grid, 1, 1, 1024, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+      } else {
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+      }
+    }
     time_mark(ctx, 1);
     uint32_t* const counter_dev = status_dev + 16;   // (page-locked mirror: status_pinned = pinned + 0, pre_host[0] = pinned + 64)
     pre_copied = 0;

@@ -894,6 +894,10 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     const int waves = env_int("QHIP_AGG_WAVES", 0);
     const std::string wattr = waves > 0 ? "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "))) " : std::string();
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_filter_agg(KArgs a, AggLaunch L) { qh_filter_agg_body<P" << dr << ">(a, L); }\n";
+    // 1024-thread workgroups, one per CU, sharing one LDS table of up to 128 KB (mid-sized many-group inputs, agg.cpp)
+    if (P.W > 0)
+      s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_wide(KArgs a, AggLaunch L) { qh_filter_agg_body<P, " << (dev_rows ? "true" : "false")
+        << ", 1024>(a, L); }\n";
   }
   if (P.W > 0) {
     // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)

@@ -428,7 +428,10 @@ __device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& 
 // DEVROWS: the input is a join output whose row count lives on the device (KArgs::nrows_dev) — a separate instantiation, so
 // that the kernels over ordinary tables keep a.nrows a plain kernel argument (two more live scalars cost the TPC-H Q1 kernel,
 // which spills SGPRs, 8 % of its time)
-template <class P, bool DEVROWS = false>
+// TB: threads per workgroup — 256 (QH_BLOCK), or 1024 for the one-workgroup-per-CU shape of mid-sized many-group inputs
+// (qk_filter_agg_wide: sixteen wavefronts share ONE LDS table of up to 128 KB, so the chains of dependent loads and table
+// updates of four times as many rows overlap while the number of end-of-kernel merges stays that of one table per CU)
+template <class P, bool DEVROWS = false, int TB = QH_BLOCK>
 __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
   constexpr int R = P::R;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   if (W > 0) {
     // LDS table: zero = empty slots and identity cells
     const u32 lwords = L.l_nslots * (u32)P::SLOT_WORDS;
-    for (u32 k = tid; k < lwords; k += QH_BLOCK) ltable[k] = 0;
+    for (u32 k = tid; k < lwords; k += TB) ltable[k] = 0;
     __syncthreads();
   }
 
@@ -457,7 +460,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   bool cache_on = KC > 0, use_cache = true;
   u64 seen_pass = 0, seen_hits = 0;
 
-  const i64 tile_rows = (i64)QH_BLOCK * R;
+  const i64 tile_rows = (i64)TB * R;
   const i64 nrows_dr = DEVROWS ? qh_rows(a) : 0;
 #define QH_NROWS (DEVROWS ? nrows_dr : a.nrows)
   const i64 ntiles = (QH_NROWS + tile_rows - 1) / tile_rows;
@@ -466,11 +469,11 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
 #define QH_OVERFLOWED() (W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u)
   // phase 1 of a tile: issue the loads of all R rows (branch-free). Out-of-range lanes re-read the table's last row and are
   // masked out afterwards; addressing is (uniform 64-bit tile base) + (32-bit lane offset)
-#define QH_ISSUE(RAW, TB, NROWS)                                          \
-  _Pragma("unroll") for (int r = 0; r < R; ++r) {                         \
-    const u32 o = (u32)r * QH_BLOCK + (u32)tid;                           \
-    const bool inb = (TB) + (i64)o < (NROWS);                             \
-    P::load(a, (TB), inb ? o : (u32)((NROWS) - 1 - (TB)), RAW[r]);        \
+#define QH_ISSUE(RAW, TBASE, NROWS)                                         \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) {                           \
+    const u32 o = (u32)r * TB + (u32)tid;                                   \
+    const bool inb = (TBASE) + (i64)o < (NROWS);                            \
+    P::load(a, (TBASE), inb ? o : (u32)((NROWS) - 1 - (TBASE)), RAW[r]);    \
   }
   if (P::PIPE == 0) {
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -549,7 +552,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   }
   // ---- merge this workgroup's LDS table into the HBM table
   __syncthreads();
-  u32 used = qh_merge_lds_table<P>(ltable, L);
+  u32 used = qh_merge_lds_table<P, TB>(ltable, L);
   if (L.collect_stats && L.l_nslots) {
     // LDS-table occupancy (statistics runs only): one global atomic per workgroup
     __syncthreads();
