@@ -184,7 +184,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   ensure_utf8_key_lengths(ctx, in, exprs, n_exprs, group_roots, n_groups, icols);
   // |value| bounds of the Int64 / Decimal128 columns (cached per column; computed only on inputs big enough to pay for the
   // reduction): the generated code multiplies and accumulates in 32 / 64 bits where the bounds allow
-  if (env_int("QHIP_AGG_NO_BOUNDS", 0) == 0) ensure_value_bounds(ctx, in, exprs, n_exprs, icols, (int64_t)1 << 22);
+  if (env_int("QHIP_AGG_NO_BOUNDS", 0) == 0) ensure_value_bounds(ctx, in, exprs, n_exprs, icols, (int64_t)env_int("QHIP_STATS_MIN_ROWS", 1 << 22));   // (the switch: tests / the fuzzer run the statistics paths on small tables)
   // lowered plans are cached per context: a repeated query (same expression PODs over the same column signature) skips
   // typing and code generation; literal VALUES are part of the key because they are bound into the plan's KernelBindings
   std::string key = "agg|";

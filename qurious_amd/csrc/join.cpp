@@ -96,7 +96,7 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   std::vector<InputCol> lcols = input_cols_of(L, late_build), rcols = input_cols_of(R);
   ensure_utf8_key_lengths(ctx, L, lex, nlex, on_l, n_on, lcols);
   ensure_utf8_key_lengths(ctx, R, rex, nrex, on_r, n_on, rcols);
-  ensure_narrow_int_columns(ctx, R, rex, nrex, rcols, (int64_t)1 << 22);   // (the probe side streams its key column: 4 bytes where they do)
+  ensure_narrow_int_columns(ctx, R, rex, nrex, rcols, (int64_t)env_int("QHIP_STATS_MIN_ROWS", 1 << 22));   // (the probe side streams its key column: 4 bytes where they do)
   // both sides must pack a Utf8 key into the same number of words
   for (int k = 0; k < n_on; ++k) {
     if (on_l[k] < 0 || on_l[k] >= nlex || on_r[k] < 0 || on_r[k] >= nrex) fail(QHIP_INVALID_ARGUMENT, "join key index out of range");
