@@ -32,12 +32,19 @@ def catalog_sources():
     os.environ["QHIP_PLAN_VALUE_BITS"] = "3:13,4:24,5:4,6:4"
     os.environ["QHIP_PLAN_UTF8_FIXED1"] = "1,2"   # l_returnflag / l_linestatus: one byte each, addressed by row number
     try:
-        for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table))):
+        for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table)), ("q1_partial", queries.q1_partial(table))):
             scan = plan.input
             out.append((name + " filter+aggregate, bounded values", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
+        # ... over the 16-byte Arrow layout: what the FIRST execution over a table runs (its decimal columns get their narrow
+        # copies at the second big read, common.hpp DevColumn::big_reads)
+        os.environ["QHIP_NARROW_DECIMALS"] = "0"
+        for name, plan in (("q1_mini", queries.q1_mini(table)), ("q1_full", queries.q1_full(table)), ("q1_partial", queries.q1_partial(table))):
+            scan = plan.input
+            out.append((name + " filter+aggregate, bounded values, Arrow layout", planning.aggregate_source(LINEITEM_SCHEMA, scan.filter, plan.group_exprs, plan.aggregate_exprs)))
     finally:
         os.environ.pop("QHIP_PLAN_VALUE_BITS", None)
         os.environ.pop("QHIP_PLAN_UTF8_FIXED1", None)
+        os.environ.pop("QHIP_NARROW_DECIMALS", None)
     # Q3: build-side key words (+ fused scan filter), fused probe kernels, the aggregate over the second join's output
     tabs = (MemoryTable.try_new(CUSTOMER_SCHEMA, []), MemoryTable.try_new(ORDERS_SCHEMA, []), MemoryTable.try_new(LINEITEM_Q3_SCHEMA, []))
     agg = queries.q3(*tabs)

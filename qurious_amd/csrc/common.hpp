@@ -115,6 +115,10 @@ struct DevColumn {
   // it was made from (src / rows are checked before use).
   struct NarrowCopy { std::shared_ptr<DevBuf> buf; int bytes = 0; const void* src = nullptr; int64_t rows = 0; };
   mutable std::shared_ptr<NarrowCopy> narrow;
+  // ... made the SECOND time a big operator streams the column (big_reads): a copy costs a pass over the column, which only a
+  // column that lives on — a resident table's — earns back; the columns of an intermediate result (an exchange's received
+  // part, a materialised join output) are read once and never get one. QHIP_NARROW_FIRST_USE=1: at the first read (tests).
+  mutable int big_reads = 0;
   // Value range [min, max] of an integer-like column, computed on first use as a hash join's build key (one reduction +
   // one read-back; decides whether the join addresses its table by the key itself: join.cpp, dense layout). The object is
   // SHARED by every copy of the column (a base table's column and the `src` of the deferred gathers made from it), so the

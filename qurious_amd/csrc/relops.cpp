@@ -128,10 +128,14 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
 
 void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
   const bool narrow_ok = env_int("QHIP_NARROW_DECIMALS", 1) != 0;
+  const bool narrow_first = env_int("QHIP_NARROW_FIRST_USE", 0) != 0;
+  std::vector<char> seen(t->cols.size(), 0);   // (a column referenced by several expression nodes counts as ONE read)
   for (int k = 0; k < n_exprs; ++k) {
     const qhip_expr& e = exprs[k];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
     if (t->cols[(size_t)e.column].type.id != QHIP_DECIMAL128 && t->cols[(size_t)e.column].type.id != QHIP_INT64) continue;
+    if (seen[(size_t)e.column]) continue;
+    seen[(size_t)e.column] = 1;
     // (a deferred gather the kernel reads through its index vector is not gathered for the statistic: it carries its source's)
     const DevColumn& col = icols[(size_t)e.column].indirect ? t->cols[(size_t)e.column] : resolved(ctx, t->cols[(size_t)e.column]);
     if (col.value_maxabs == 0 && col.length >= min_rows && col.values) {
@@ -148,7 +152,8 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
     if (m != 0 && m != ~0ULL) { int bits = 1; while (bits < 63 && (m >> bits)) ++bits; m = (1ULL << bits) - 1; }
     icols[(size_t)e.column].value_maxabs = m;
     // every value fits 32 / 64 bits: the kernel reads the column's narrow copy (DevColumn::narrow), made here once per column
-    if (narrow_ok && m != 0 && m != ~0ULL && col.type.id == QHIP_DECIMAL128 && !icols[(size_t)e.column].indirect && col.values && col.length > 0) {
+    if (narrow_ok && m != 0 && m != ~0ULL && col.type.id == QHIP_DECIMAL128 && !icols[(size_t)e.column].indirect && col.values && col.length > 0 &&
+        (++col.big_reads >= 2 || col.narrow || narrow_first)) {
       const int nb = m < (1ULL << 31) ? 4 : 8;
       if (!col.narrow || col.narrow->bytes != nb || col.narrow->src != col.values->ptr || col.narrow->rows != col.length) {
         auto nc = std::make_shared<DevColumn::NarrowCopy>();
@@ -167,15 +172,19 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
 // key_range_of) — Q3's lineitem probe then streams 8 instead of 12 bytes per row.
 void ensure_narrow_int_columns(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
   if (env_int("QHIP_NARROW_INTS", 1) == 0 || t->num_rows < min_rows) return;
+  std::vector<char> seen(t->cols.size(), 0);
   for (int k = 0; k < n_exprs; ++k) {
     const qhip_expr& e = exprs[k];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
     if (t->cols[(size_t)e.column].type.id != QHIP_INT64 || icols[(size_t)e.column].indirect) continue;
+    if (seen[(size_t)e.column]) continue;
+    seen[(size_t)e.column] = 1;
     const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
     if (!col.values || col.length < min_rows) continue;
     int64_t mn = 0, mx = 0;
     if (!key_range_of(ctx, col, mn, mx) || col.range_inherited) continue;   // (an inherited range is a superset's: still valid bounds, but only base columns are worth a copy)
     if (mn < -(int64_t)0x7fffffff || mx > (int64_t)0x7fffffff) continue;
+    if (++col.big_reads < 2 && !col.narrow && env_int("QHIP_NARROW_FIRST_USE", 0) == 0) continue;   // (DevColumn::big_reads: the second read earns the copy)
     if (!col.narrow || col.narrow->bytes != 4 || col.narrow->src != col.values->ptr || col.narrow->rows != col.length) {
       auto nc = std::make_shared<DevColumn::NarrowCopy>();
       nc->buf = std::make_shared<DevBuf>((size_t)col.length * 4);

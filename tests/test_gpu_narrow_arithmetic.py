@@ -71,6 +71,8 @@ THRESHOLDS = [
 def test_sum_avg_and_products_at_the_narrow_arithmetic_thresholds(ctx, monkeypatch, name, extreme, no_bounds):
     if no_bounds:
         monkeypatch.setenv("QHIP_AGG_NO_BOUNDS", "1")
+    else:
+        monkeypatch.setenv("QHIP_NARROW_FIRST_USE", "1")   # (narrow copies at the first read: these tests execute a plan once)
     rng = np.random.default_rng(extreme % 1000 + (7 if no_bounds else 0))
     g = rng.integers(0, 4, N).astype(np.int64)
     a_small = rng.integers(-1000, 1000, N)
@@ -141,6 +143,8 @@ def test_truncating_decimal_avg_at_the_thresholds(ctx, monkeypatch, extreme, no_
     SUM behind it accumulated in 64-bit lanes below 2^39 and in 128 bits from there"""
     if no_bounds:
         monkeypatch.setenv("QHIP_AGG_NO_BOUNDS", "1")
+    else:
+        monkeypatch.setenv("QHIP_NARROW_FIRST_USE", "1")   # (narrow copies at the first read: these tests execute a plan once)
     rng = np.random.default_rng(extreme % 997)
     # EVERY row big, in (+x, -x + d) pairs of one group: a group's SUM stays small enough for AVG's checked sum * 10^4
     # (Decimal128(19, 6), avg.rs:105-116) while the LANE sums grow — a lane always sees rows of one parity, i.e. one sign
@@ -265,7 +269,10 @@ def test_narrow_copies_of_decimal_columns(ctx, monkeypatch, extreme, width):
         b = out.to_batches()[0]
         return sorted(zip(b.column(0).to_pylist(), _i128_of(b.column(1)), b.column(2).to_pylist())), st
 
-    got, st = run()
+    first, st_first = run()
+    assert abs(st_first["bytes_per_row_read"] - (8 + 16 + 0.125)) < 1e-9   # the first big read streams the Arrow layout ...
+    got, st = run()                                                        # ... the second one finds / makes the narrow copy
+    assert got == first
     # 8 bytes of group key + the value column at its narrow width + its validity bits
     assert abs(st["bytes_per_row_read"] - (8 + width + 0.125)) < 1e-9, st["bytes_per_row_read"]
     a_obj = small.astype(object)
