@@ -165,18 +165,16 @@ def pmc_traffic(workload, kernel, rows, bytes_per_row):
 
 def roofline(kernel, kernel_ms, bytes_per_launch, traffic=None, traffic_source=None, algorithmic_bytes_per_launch=None, **extra):
     """`achieved` / `frac` = the bytes the kernel READS per launch (qhip_exec_stats.bytes_per_row_read x rows: what it must pull
-    from HBM in the layout it streams, checked against the PMC `traffic`) / its mean duration — a physical rate, never above
-    the peak, the same convention as rounds 1-2. Where the kernel streams narrow copies of Decimal128 / Int64 columns (DESIGN
-    §2) those bytes are fewer than the ALGORITHMIC bytes of the Arrow layout (SURVEY §8d's figure x rows): that figure, and the
-    rate and fraction it would imply, are reported beside it as `algorithmic_*` — they can exceed the HBM peak, which is the
-    point of the narrow layout, not a measurement of the memory system."""
+    from HBM in the layout that is resident and streamed, checked against the PMC `traffic`) / its mean duration. Where the
+    kernel streams narrow copies of Decimal128 / Int64 columns this is SURVEY §8(d)'s rule for a narrower device
+    layout: the algorithmic bytes are recomputed from the bytes actually resident — Arrow-layout bytes are never divided by a
+    narrowed kernel's time. The Arrow layout's figure is reported beside it for reference only (`arrow_layout_bytes_per_launch`)."""
     per_s = 1.0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     r = {"bound": "hbm", "achieved": bytes_per_launch * per_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_launch * per_s / HBM_PEAK_GBS,
          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel, "kernel_ms": kernel_ms,
          "bytes_read_per_launch": bytes_per_launch}
     if algorithmic_bytes_per_launch is not None:
-        r.update({"algorithmic_bytes_per_launch": algorithmic_bytes_per_launch, "algorithmic_achieved": algorithmic_bytes_per_launch * per_s,
-                  "algorithmic_frac": algorithmic_bytes_per_launch * per_s / HBM_PEAK_GBS})
+        r["arrow_layout_bytes_per_launch"] = algorithmic_bytes_per_launch
     r.update(extra)
     return r
 
@@ -294,7 +292,7 @@ class Q1:
                "rows": self.rows_total, "groups": st["groups"], "resident_bytes_per_gpu": self.resident,
                "roofline": roofline(st["main_kernel_name"], st["main_kernel_ms"], kbytes, traffic, src,
                                     algorithmic_bytes_per_launch=self.rows * SURVEY_BYTES_PER_ROW[self.workload],
-                                    algorithmic_bytes_per_row=SURVEY_BYTES_PER_ROW[self.workload], kernel_bytes_per_row=bpr,
+                                    arrow_layout_bytes_per_row=SURVEY_BYTES_PER_ROW[self.workload], kernel_bytes_per_row=bpr,
                                     rows_per_launch=self.rows,
                                     layout=("narrow copies of the Decimal128 columns (4 / 8 bytes per value)" if bpr < 0.75 * SURVEY_BYTES_PER_ROW[self.workload]
                                             else "Arrow layout")),

@@ -222,9 +222,9 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
             assert rec["q1_sf10"]["rows"] == 59986052 and rec["q1_sf10"]["groups"] == 4
             assert rec["q3_sf10"]["groups"] == rec["q3_sf10_repartition"]["groups"] > 100000
             assert rec["q3_sf10"]["exchange"]["exchanges_per_query"] > 0 and line["exchange"]["bytes_sent_per_query"] >= 0
-            # (`frac` is on the bytes the kernel reads — a physical rate; `algorithmic_frac`, on the Arrow layout's bytes, may
-            # exceed 1 where the kernel streams narrow copies of the decimal columns)
-            assert line["roofline"]["kernel"] == "qk_filter_agg" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["algorithmic_frac"] >= line["roofline"]["frac"]
+            # (`frac` is on the bytes the kernel reads from the resident layout — SURVEY §8d's rule for narrowed layouts)
+            assert line["roofline"]["kernel"] == "qk_filter_agg" and 0 < line["roofline"]["frac"] < 1
+            assert line["roofline"]["arrow_layout_bytes_per_launch"] >= line["roofline"]["bytes_read_per_launch"]
             # configs[4] in the N > 1 line: Zipf(1.1) keys, both strategies, LDS-table occupancy, exchange rate against xGMI, host waits
             z = rec["q3_sf100_zipf"]
             assert "configs[4]" in z["workload"] and z["groups"] > 100 and z["other_strategy"]["groups"] == z["groups"]
