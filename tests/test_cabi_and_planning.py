@@ -175,6 +175,18 @@ def test_catalog_holds_the_kernel_variants_a_repeated_q3_launches():
     # Q1's catalog variant knows what an execution finds out about the data: narrow values, one-byte flag columns
     q1 = srcs["q1_full filter+aggregate, bounded values"]
     assert q1 != srcs["q1_full filter+aggregate"]
+    # ... and, from a column's second big read on, streams the NARROW COPIES of the decimal columns: 4-byte loads
+    # that are sign-extended, every group of the query in the wave-resident cache (KC = 4), the wide entry point beside the
+    # 256-thread one; the Arrow-layout variant (first read) keeps the 16-byte loads and two cached keys
+    q1_arrow = srcs["q1_full filter+aggregate, bounded values, Arrow layout"]
+    assert "(const int*)((const char*)((const int*)a.c[" in q1 and "qh_nt_load_i128" not in q1
+    assert "qh_nt_load_i128" in q1_arrow and "(const int*)((const char*)((const int*)a.c[3]" not in q1_arrow
+    assert "static constexpr int KC = 4;" in q1 and "static constexpr int KC = 2;" in q1_arrow
+    assert "qk_filter_agg_wide(" in q1 and "qh_filter_agg_body<P, false, 1024>" in q1
+    assert "q1_partial filter+aggregate, bounded values" in srcs            # what every rank of an N > 1 run launches
+    # the probe side's Int64 key as its 4-byte narrow copy, four rows per lane (16-byte loads)
+    dpn = srcs["q3 lineitem dense probe, narrow key"]
+    assert dpn != dp and "static constexpr int PROBE_R = 4;" in dpn and "static constexpr int PROBE_R = 2;" in dp
 
 
 def test_retry_protocol_of_the_host_mirror():
