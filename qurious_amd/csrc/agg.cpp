@@ -709,6 +709,11 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       QHIP_HIP_CHECK(sync_stream(ctx->stream));
     }
     memcpy(status, status_pinned, sizeof(status));
+    if (env_int("QHIP_AGG_PROF", 0)) {   // phase timers of the fused kernel (P::PROF): mean cycles per wavefront, in units of 256
+      const double waves = (double)grid * (block / 64);
+      fprintf(stderr, "[qhip agg prof] rows %lld grid %u x %d: loads+eval %.0f  cache %.0f  table updates %.0f  cached keys -> table %.0f  merge %.0f  (x256 cycles per wavefront)\n",
+              (long long)N, grid, block, status_pinned[8] / waves, status_pinned[9] / waves, status_pinned[10] / waves, status_pinned[11] / waves, status_pinned[12] / waves);
+    }
     mark("synchronised");
     trace_point("aggregate: back from its wait");
     verify_pending_sizes(ctx);   // (an input of deferred size: did the joins below have room? — else QHIP_RETRY)

@@ -715,6 +715,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   s << "struct P {\n";
   const int KC = P.KC;
   s << "  static constexpr int W = " << P.W << ";\n  static constexpr int R = " << P.R << ";\n  static constexpr int SLOT_WORDS = " << P.slot_words << ";\n";
+  s << "  static constexpr int PROF = " << (env_int("QHIP_AGG_PROF", 0) != 0 ? 1 : 0) << ";   // phase timers (s_memtime) summed into status words 8..12 (measurements only)\n";
   s << "  static constexpr int PIPE = " << (env_int("QHIP_AGG_PIPE", 0) != 0 ? 1 : 0) << ";   // two register sets: the next tile's loads fly while a tile is evaluated\n";
   // rows per thread of the partitioned path's staged scatter (qh_agg_part_stage_body): what a 1 024-thread workgroup can stage
   // in LDS beside 4 096 bins' counters (160 KB per CU), at most 4; 0 = records too wide, per-lane stores

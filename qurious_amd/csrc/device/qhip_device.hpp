@@ -464,6 +464,11 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   const i64 nrows_dr = DEVROWS ? qh_rows(a) : 0;
 #define QH_NROWS (DEVROWS ? nrows_dr : a.nrows)
   const i64 ntiles = (QH_NROWS + tile_rows - 1) / tile_rows;
+  // phase timers (P::PROF, measurements only): cycles per wavefront in [0] loads + evaluation, [1] hot-key cache, [2] table
+  // updates of a tile, [3] cached keys -> table at the end, [4] LDS table -> HBM table; summed into status words 8..12
+  u64 prof[5] = {0, 0, 0, 0, 0};
+  u64 tmark = P::PROF ? __builtin_readcyclecounter() : 0;
+#define QH_PROF_MARK(K) if (P::PROF) { const u64 now_ = __builtin_readcyclecounter(); prof[K] += now_ - tmark; tmark = now_; }
   // the HBM table overflowed somewhere: the host will retry with a larger one, stop streaming (QH_OVERFLOWED: the load is
   // issued with a tile's loads and consumed at the end of the trip, wave-uniform)
 #define QH_OVERFLOWED() (W > 0 ? __hip_atomic_load(&L.status[QS_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u)
@@ -542,6 +547,7 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       if (lane == 0) qh_update_group<P>(ltable, L, ck[k], part, err);
     }
   }
+  QH_PROF_MARK(3)
   qh_report(L.status, err);
   if (W == 0) {
     typename P::Part part;
@@ -553,6 +559,12 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   // ---- merge this workgroup's LDS table into the HBM table
   __syncthreads();
   u32 used = qh_merge_lds_table<P, TB>(ltable, L);
+  QH_PROF_MARK(4)
+  if (P::PROF && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) atomicAdd(&L.status[8 + k], (u32)(prof[k] >> 8));
+  }
+#undef QH_PROF_MARK
   if (L.collect_stats && L.l_nslots) {
     // LDS-table occupancy (statistics runs only): one global atomic per workgroup
     __syncthreads();
