@@ -499,6 +499,22 @@ class FilterBench:
         return {"workload": f"standalone Filter (filter.rs:28-44) over {self.rows} lineitem rows x 7 columns, HBM-resident", "cases": out}
 
 
+def cpp_host_step(args):
+    """The SAME step (Q1 at SF10 + Q3 at SF10) driven by the compiled host — tools/bench_host: the C++ mirror of the reference's
+    operator API (include/qhip_plan.hpp) over the C ABI — in a child process with its own context and tables: what the host
+    language costs the metric (the timed region of this file goes through the Python mirror)."""
+    exe = os.path.join(ROOT, "tools", "bench_host")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/bench_host is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    import subprocess
+    r = subprocess.run([exe, str(args.steps), str(args.warmup + SETTLE_STEPS)], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": r.stderr[-400:]}
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    rec["note"] = "child process: own context, own copy of the tables; one 60 M-row batch per table instead of 2^20-row batches"
+    return rec
+
+
 # ---------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -655,6 +671,7 @@ def main():
             records["q1_mini"], _ = mini.record(args, clock, with_cpu)
             if rank == 0:
                 records["q1_mini"]["roofline"]["stream_read_GBps"] = ctx.measure_stream_read(4 << 30, 5)
+            records["cpp_host"] = cpp_host_step(args)
         except Exception as e:   # the headline line must not depend on the extras
             records["extras_error"] = f"{type(e).__name__}: {e}"
     finish()

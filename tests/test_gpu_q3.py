@@ -290,3 +290,21 @@ def test_q3_over_1024_row_batches_like_the_reference_csv_loader(ctx, oracle):
     assert [b.num_rows for b in gf] == [b.num_rows for b in wf] and len(gf) == 300
     assert rows_of(gf) == rows_of(wf)
     assert rows_of(table_scan(schema, small).execute()) == rows_of([big])
+
+
+def test_compiled_host_runs_the_metrics_step(ctx):
+    """tools/bench_host — the metric's step through the C++ mirror of the reference's operator API (include/qhip_plan.hpp),
+    no Python between the plan nodes and the C ABI — produces the groups the Python mirror produces on the same synthetic tables."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bench_host")
+    assert os.path.exists(exe), "tools/bench_host is not built: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([exe, "3", "3", "0.5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    from qurious_amd import queries, synth
+    c, o, l = synth.q3_tables(0.5, 0, 1)
+    tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o), q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
+    want = queries.q3(*tabs).execute_device().num_rows
+    assert line["q1_groups"] == 4 and line["q3_groups"] == want > 1000 and line["ms_per_step"] > 0
+    assert line["q3_lineitem_rows"] == sum(b.num_rows for b in l)
