@@ -297,8 +297,8 @@ def test_compiled_host_runs_the_metrics_step(ctx):
     no Python between the plan nodes and the C ABI — produces the groups the Python mirror produces on the same synthetic tables."""
     import json
     import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "bench_host"])   # (g++ over the C ABI: no GPU needed to build)
     exe = os.path.join(ROOT, "tools", "bench_host")
-    assert os.path.exists(exe), "tools/bench_host is not built: python -c 'import __graft_entry__ as g; g.build()'"
     r = subprocess.run([exe, "3", "3", "0.5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
