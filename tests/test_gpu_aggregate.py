@@ -258,3 +258,67 @@ def test_partitioned_path_for_many_groups(ctx, oracle, monkeypatch):
     assert first == second and len(first) == len(np.unique(kk))
     sums = np.bincount(kk, weights=None, minlength=400_000)
     assert [r[2] for r in first] == [int(c) for c in sums[sums > 0]]
+
+
+def test_wide_workgroups_for_mid_sized_many_group_inputs(ctx, monkeypatch):
+    """A plan that produced many groups (> 4096) from a mid-sized input (1-4 M rows) runs its NEXT execution with one 1024-thread
+    workgroup per CU on one LDS table of up to 128 KB (qk_filter_agg_wide, csrc/agg.cpp `wide`). Every cell kind — 128-bit and
+    narrow SUMs, COUNT, 64-bit and 128-bit MIN / MAX (the per-cell lock), Float64 SUM — two key columns incl. Utf8, NULL keys and
+    values, a fused filter, heavy keys next to a long tail; compared with the 256-thread shape (QHIP_AGG_WIDE=0), with the first
+    execution (which does not know the group count yet) and with exact numpy results for the integer columns."""
+    import decimal
+    rng = np.random.default_rng(77)
+    n = 1_300_000
+    heavy = rng.random(n) < 0.25
+    k = np.where(heavy, rng.integers(0, 6, n), rng.integers(0, 90_000, n))
+    kn = rng.random(n) < 0.01
+    v = rng.integers(-10**9, 10**9, n)
+    vn = rng.random(n) < 0.05
+    d_raw = rng.integers(-10**12, 10**12, n)
+    dn = rng.random(n) < 0.05
+    D = pa.decimal128(20, 2)
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("v", I64), pa.field("d", D), pa.field("f", pa.float64())])
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(k, type=I64, mask=kn),
+        pa.array(["s%d" % x for x in rng.integers(0, 3, n)], type=pa.string()),
+        pa.array(v, type=I64, mask=vn),
+        pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in d_raw], type=D, mask=dn),
+        pa.array(rng.integers(-100, 100, n).astype(np.float64), type=pa.float64())], schema=schema)
+    cuts = [0, 400_000, 400_000, 900_001, n]
+    scan = q.Scan(schema, q.MemoryTable.try_new(schema, [batch.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]), None,
+                  q.BinaryExpr(col("f", 4), Operator.GtEq, q.Literal(q.ScalarValue.Float64(-90.0))))
+    aggs = [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(col("v", 2)), q.CountAggregateExpr(lit_i64(1)), q.MinAggregateExpr(col("v", 2), I64),
+            q.MaxAggregateExpr(col("d", 3), D), q.MinAggregateExpr(col("d", 3), D), q.SumAggregateExpr(col("d", 3), D), q.SumAggregateExpr(col("f", 4), pa.float64())]
+    plan = q.HashAggregate(None, scan, [col("k", 0), col("s", 1)], aggs)
+
+    def run():
+        out = sorted(rows_of(plan.execute()), key=lambda r: tuple((x is None, x) for x in r[:2]))
+        return out, ctx.last_stats()
+
+    first, st1 = run()
+    assert st1["workgroups"] > 256 and st1["groups"] > 90_000          # the default shape: the group count is not known yet
+    second, st2 = run()
+    assert st2["workgroups"] <= 256 and st2["lds_table_slots"] >= 256    # one workgroup per CU, the big table (128 KB / slot bytes)
+    monkeypatch.setenv("QHIP_AGG_WIDE", "0")
+    third, st3 = run()
+    assert st3["workgroups"] <= 256 and st3["lds_table_slots"] < st2["lds_table_slots"]
+    close = lambda a, b: len(a) == len(b) and all(x[:9] == y[:9] and abs(x[9] - y[9]) <= 1e-6 * max(1.0, abs(y[9])) for x, y in zip(a, b))   # noqa: E731
+    assert close(first, second) and close(third, second)
+    # exact integers of one heavy and a few light groups
+    keep = np.asarray(batch.column(4).to_pylist()) >= -90.0
+    s_col = np.asarray(batch.column(1).to_pylist())
+    for key in (0, 3, int(k[~heavy][0]), int(k[~heavy][5])):
+        for sv in ("s0", "s2"):
+            m = keep & ~kn & (k == key) & (s_col == sv)
+            row = [r for r in second if r[0] == key and r[1] == sv]
+            if not m.any():
+                assert not row
+                continue
+            assert len(row) == 1
+            mv = m & ~vn
+            assert row[0][2] == (int(v[mv].sum()) if mv.any() else None) and row[0][3] == int(mv.sum()) and row[0][4] == int(m.sum())
+            assert row[0][5] == (int(v[mv].min()) if mv.any() else None)
+            md = m & ~dn
+            assert row[0][6] == (decimal.Decimal(int(d_raw[md].max())).scaleb(-2) if md.any() else None)
+            assert row[0][7] == (decimal.Decimal(int(d_raw[md].min())).scaleb(-2) if md.any() else None)
+            assert row[0][8] == (decimal.Decimal(int(d_raw[md].sum())).scaleb(-2) if md.any() else None)
