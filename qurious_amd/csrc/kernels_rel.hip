@@ -599,6 +599,32 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, con
     const u32 n = chunk_nent[ch];
     u32 base = chunk_off[ch];
     const u64 e0 = ch * chunk_rows;
+    if (!start && !pair_off && !visited) {
+      // unique build keys, nothing but the pairs wanted (every Inner FK -> PK join): entry j of the chunk IS pair base + j, so
+      // there is no scan and no dependence between the trips — four of them in flight (Q3's join 1: 1 640 entries per chunk
+      // were 26 dependent trips of two chained loads each, 20 us for 3 M pairs)
+      for (u32 j0 = 0; j0 < n; j0 += 256) {
+        u32 sid[4], p[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const u32 j = j0 + (u32)u * 64u + (u32)lane;
+          live[u] = j < n;
+          sid[u] = live[u] ? ent_slot[e0 + j] : 0u;
+          p[u] = live[u] ? ent_row[e0 + j] : 0u;
+        }
+        if (row_of) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sid[u] = live[u] ? row_of[sid[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const u32 o = base + j0 + (u32)u * 64u + (u32)lane;
+          if (live[u] && o < cap) { b_idx[o] = sid[u]; p_idx[o] = p[u]; }
+        }
+      }
+      continue;
+    }
     for (u32 j0 = 0; j0 < n; j0 += 64) {
       const u32 j = j0 + lane;
       const bool live = j < n;
