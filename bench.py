@@ -499,6 +499,73 @@ class FilterBench:
         return {"workload": f"standalone Filter (filter.rs:28-44) over {self.rows} lineitem rows x 7 columns, HBM-resident", "cases": out}
 
 
+class PartitionBench:
+    """The exchange's first step on one rank (qhip_partition_filtered): Q3's lineitem side — scan filter
+    l_shipdate > 1995-03-15, key l_orderkey, the three columns the plan above the exchange reads — split into 8 parts, over the
+    whole SF10 table (what one rank of one holds) and over rank 0's 1/8 slice (what one rank of eight holds)."""
+
+    def __init__(self, ctx, tabs_full=None):
+        self.ctx = ctx
+        self.tabs = {}
+        if tabs_full is not None:
+            self.tabs["sf10"] = tabs_full
+        else:
+            self.tabs["sf10"] = q3_memory_tables(10.0, 0.0, 0, 1)
+        self.tabs["sf10_slice_1_of_8"] = q3_memory_tables(10.0, 0.0, 0, 8)
+
+    def record(self, args, clock, n_parts=8):
+        from qurious_amd import exchange
+        out = {}
+        for name, tabs in self.tabs.items():
+            plan = queries.q3(*tabs)
+            j2 = plan.input
+            scan, key = j2.right, j2.on[0][1]
+            schema = scan.schema()
+            need = exchange.referenced_columns(list(plan.group_exprs) + [a.expression() for a in plan.aggregate_exprs])
+            nl = len(j2.left.schema())
+            keep = [(nl + c) in need or c == key.index for c in range(len(schema))]
+            dev = tabs[2].device_table()
+            rows = dev.num_rows
+            run = lambda: exchange.partition_filtered(dev, [key], n_parts, predicate=scan.filter, keep=keep)   # noqa: E731
+            steps = max(5, args.steps)
+            elapsed = clock.run(run, steps, 2)
+            self.ctx.set_timing(True)
+            try:
+                p1, p2, tot = [], [], []
+                for _ in range(5):
+                    parts = run()
+                    st = self.ctx.last_stats()
+                    p1.append(st["build_ms"]); p2.append(st["main_kernel_ms"]); tot.append(st["total_device_ms"])
+            finally:
+                self.ctx.set_timing(False)
+            kept = sum(p.num_rows for p in parts)
+            widths = [pa_width(f.type) for f in schema]
+            pred_cols = exchange.referenced_columns([scan.filter, key])
+            w_kept = sum(w for w, k in zip(widths, keep) if k)
+            w_read_once = sum(w for c, w in enumerate(widths) if keep[c] or c in pred_cols)
+            algorithmic = rows * w_read_once + kept * w_kept           # every referenced column read once + the kept rows written once
+            moved = rows * (st["build_bytes_per_row"] + 1) + rows * (1 + w_kept) + kept * w_kept   # incl. the part byte written and re-read, key read twice
+            k1, k2 = statistics.median(p1), statistics.median(p2)
+            out[name] = {"rows_in": rows, "rows_out": kept, "parts": n_parts, "part_rows": [p.num_rows for p in parts],
+                         "columns_moved": [f.name for f, k in zip(schema, keep) if k],
+                         "ms_per_call": elapsed / steps * 1e3, "rows_per_s": rows * steps / elapsed,
+                         "pass1_ms": k1, "pass2_ms": k2, "device_ms": statistics.median(tot), "host_waits_per_call": 1,
+                         "device_ms_is": "first launch .. last launch of a call: the two kernels + the one-workgroup scan of the (part, unit) counters "
+                                         "+ the host wait that sizes the parts (~30 us)",
+                         "roofline": roofline("qk_part_ids + k_scan_small + k_part_scatter", k1 + k2, algorithmic, None, "not profiled per launch",
+                                              bytes_are="every referenced column read once + the kept rows' kept columns written once",
+                                              bytes_moved_per_launch=moved, frac_on_bytes_moved=moved / ((k1 + k2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              pass1=roofline("qk_part_ids", k1, rows * (st["build_bytes_per_row"] + 1)),
+                                              pass2=roofline("k_part_scatter", k2, rows * (1 + w_kept) + kept * w_kept))}
+        return {"workload": f"exchange step 1 (SURVEY §8e): Q3's lineitem side, scan filter + partition by mix64(l_orderkey) into {n_parts} parts, "
+                            "HBM-resident; no reference counterpart (single process)", "cases": out}
+
+
+def pa_width(t):
+    import pyarrow as pa
+    return 16 if pa.types.is_decimal128(t) else t.bit_width // 8
+
+
 def cpp_host_step(args):
     """The SAME step (Q1 at SF10 + Q3 at SF10) driven by the compiled host — tools/bench_host: the C++ mirror of the reference's
     operator API (include/qhip_plan.hpp) over the C ABI — in a child process with its own context and tables: what the host
@@ -521,7 +588,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="metric", choices=["metric", "q1_mini", "q1_full", "q3", "filter"],
+    ap.add_argument("--workload", default="metric", choices=["metric", "q1_mini", "q1_full", "q3", "filter", "partition"],
                     help="metric (default): a step = Q1 at SF10 + Q3 at SF10; the others run one configuration as the step")
     ap.add_argument("--rows", type=int, default=0, help="lineitem rows of the q1_* / filter workloads (whole job; default: 100 M for q1_mini, SF10's for q1_full)")
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
@@ -593,6 +660,12 @@ def main():
         first = next(iter(rec["cases"].values()))
         line.update(value=first["rows_per_s"], ms_per_step=first["ms_per_call"], scaling="strong", roofline=first["roofline"], cpu_baseline=None,
                     config={"workload": rec["workload"]}, records={"filter_lineitem": rec})
+        return finish()
+    if args.workload == "partition":
+        rec = PartitionBench(ctx).record(args, clock)
+        first = rec["cases"]["sf10"]
+        line.update(value=first["rows_per_s"], ms_per_step=first["ms_per_call"], scaling="strong", roofline=first["roofline"], cpu_baseline=None,
+                    config={"workload": rec["workload"]}, records={"partition": rec})
         return finish()
     if args.workload == "q3":
         slice_of = tuple(int(x) for x in args.slice.split("/")) if args.slice else None
@@ -666,6 +739,7 @@ def main():
         line["exchange"] = records["q3_sf10"]["exchange"]
     if world == 1 and not USE_DIST and not args.no_extra:
         try:
+            records["partition"] = PartitionBench(ctx, q3.tabs).record(args, clock)
             records["filter_lineitem"] = FilterBench(args, ctx, q1.table).record(args, clock)
             mini = Q1(args, ctx, "q1_mini", 100_000_000, rank, world)
             records["q1_mini"], _ = mini.record(args, clock, with_cpu)

@@ -310,6 +310,18 @@ int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input,
                           const qhip_expr* exprs, int32_t n_exprs,
                           const int32_t* key_roots, int32_t n_keys,
                           int32_t n_parts, qhip_table** out_parts /* n_parts entries */);
+/* The same split FUSED with what surrounds it in a repartitioned join (round 4; SURVEY §8e "scan+filter, radix-partition
+ * surviving rows into n send buffers"): predicate_root >= 0 is the scan filter of the join side (MemoryTable::scan's,
+ * datasource/memory.rs:90-93 — a row whose predicate is false or NULL is in no part), keep_columns (one int32 per input
+ * column, NULL = all) names the columns the plan above the exchange reads: only those are moved, the others become
+ * QHIP_NULL placeholders exactly as qhip_table_keep_columns makes them. Two streaming passes, one host wait (the parts'
+ * sizes); every kept plain column lands in ONE allocation over all parts and a part's column is a slice of it. n_parts <= 255
+ * (more: the generic path of qhip_partition_by_key, which takes no filter). */
+int qhip_partition_filtered(qhip_ctx* ctx, const qhip_table* input,
+                            const qhip_expr* exprs, int32_t n_exprs,
+                            const int32_t* key_roots, int32_t n_keys,
+                            int32_t predicate_root, const int32_t* keep_columns,
+                            int32_t n_parts, qhip_table** out_parts /* n_parts entries */);
 /* Concatenate tables with identical schemas (batches appended in order). */
 int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n, qhip_table** out);
 
@@ -413,6 +425,14 @@ int qhip_plan_probe_source(const qhip_dtype* col_types, const int32_t* col_has_n
 int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
                              const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
                              int32_t predicate_root, char* buf, size_t buflen, size_t* needed);
+/* Pass 1 of qhip_partition_filtered (scan filter + key -> part of every row + per-wavefront histogram) for n_parts parts. */
+int qhip_plan_partition_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,
+                               const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots, int32_t n_keys,
+                               int32_t predicate_root, int32_t n_parts, char* buf, size_t buflen, size_t* needed);
+/* Pass 2 of qhip_partition_filtered for one group of columns: widths[c] = bytes per value (1, 2, 4, 8, 16; 0 = the row number
+ * as u32), indirect[c] != 0 = read through an index vector (a deferred gather). */
+int qhip_plan_part_scatter_source(const int32_t* widths, const int32_t* indirect, int32_t n_cols, int32_t n_parts,
+                                  char* buf, size_t buflen, size_t* needed);
 /* The image kernel of qhip_sort_execute for the key expressions, and the kernel of qhip_projection_execute for the
  * computed (non-Column) expressions among `roots`. */
 int qhip_plan_sort_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols,

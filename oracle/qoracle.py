@@ -674,7 +674,7 @@ def _mix64(x: np.ndarray) -> np.ndarray:
 
 
 def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
-    """numpy restatement of qhip_partition_by_key's row -> part mapping (csrc/kernels_rel.hip k_partition_ids over the key
+    """numpy restatement of qhip_partition_by_key's row -> part mapping (csrc/device/qhip_device.hpp qh_part_hash over the key
     words of csrc/codegen.cpp emit_key_words): ints/dates sign-extended to 64 bits, Decimal128 as (lo, hi), Utf8 <= 31 bytes
     packed into 4 words; a row with any NULL key has all its key words zeroed."""
     n = len(key_arrays[0])
@@ -705,9 +705,13 @@ def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
         else:
             v = np.array(a.cast(pa.int32() if (pa.types.is_date32(t) or pa.types.is_time32(t)) else pa.int64()).fill_null(0)).astype(np.int64)
             words.append(v.view(np.uint64).copy())
-    h = np.zeros(n, dtype=np.uint64)
+    def fold_mul(x):   # qh_fold_mul: one 64-bit multiply, the high half folded into the low one
+        x = x * np.uint64(0x9E3779B97F4A7C15)
+        return x ^ (x >> np.uint64(32))
     with np.errstate(over="ignore"):
-        for w in words:
-            h = _mix64(h ^ np.where(valid, w, np.uint64(0)))
+        z = [np.where(valid, w, np.uint64(0)) for w in words]
+        h = fold_mul(z[0])
+        for k, w in enumerate(z[1:], start=1):   # qh_key_hash
+            h = fold_mul(h ^ w) + np.uint64(k)
         pid = ((h >> np.uint64(32)) * np.uint64(n_parts)) >> np.uint64(32)
     return pid.astype(np.int64)

@@ -158,6 +158,7 @@ def load_library() -> C.CDLL:
             "qhip_sort_execute": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), P(i32), P(i32), i32, i64, P(vp)]),
             "qhip_limit_execute": (C.c_int, [vp, vp, i64, i64, P(vp)]),
             "qhip_partition_by_key": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(vp)]),
+            "qhip_partition_filtered": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
             "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
             "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),
             "qhip_table_wire_meta": (C.c_int, [vp, vp, P(i64), i32]),

@@ -111,6 +111,25 @@ def catalog_sources():
         os.environ.pop("QHIP_PLAN_DENSE", None)
         os.environ.pop("QHIP_PLAN_DEV_ROWS", None)
         os.environ.pop("QHIP_PLAN_INDIRECT", None)
+    # the exchange of a repartitioned Q3 at 2 / 4 / 8 ranks (qhip_partition_filtered, pass 1): scan filter + key -> part
+    for world in (2, 4, 8):
+        out.append((f"q3 customer partition x{world}", planning.partition_source(CUSTOMER_SCHEMA, [j1.on[0][0]], j1.left.filter, world)))
+        out.append((f"q3 orders partition x{world}", planning.partition_source(ORDERS_SCHEMA, [j1.on[0][1]], j1.right.filter, world)))
+        out.append((f"q3 lineitem partition x{world}", planning.partition_source(LINEITEM_Q3_SCHEMA, [j2.on[0][1]], j2.right.filter, world)))
+    # ... with the Int64 key read as its 4-byte narrow copy (resident tables whose keys fit 32 bits: TPC-H's)
+    for name, schema, join in (("q3 orders partition x8, narrow key", ORDERS_SCHEMA, j1), ("q3 lineitem partition x8, narrow key", LINEITEM_Q3_SCHEMA, j2)):
+        os.environ["QHIP_PLAN_NARROW_INTS"] = str(join.on[0][1].index)
+        try:
+            out.append((name, planning.partition_source(schema, [join.on[0][1]], join.right.filter, 8)))
+        finally:
+            os.environ.pop("QHIP_PLAN_NARROW_INTS", None)
+    # ... pass 2 for the column shapes of Q3's four exchanges (the ranking variant for <= 8 parts serves 2 / 4 / 8 ranks):
+    # customer: c_custkey; orders: o_orderkey, o_custkey, o_orderdate, o_shippriority; lineitem: l_orderkey, price, discount;
+    # join 1's output: the three columns the plan reads, through join 1's index vectors
+    out.append(("partition scatter: customer (8)", planning.part_scatter_source([8], 8)))
+    out.append(("partition scatter: orders (8, 8, 4, 8)", planning.part_scatter_source([8, 8, 4, 8], 8)))
+    out.append(("partition scatter: lineitem (8, 16, 16)", planning.part_scatter_source([8, 16, 16], 8)))
+    out.append(("partition scatter: join-1 output (8, 4, 8), indirect", planning.part_scatter_source([8, 4, 8], 8, [True, True, True])))
     top = queries.q3_top10(*tabs)
     out.append(("q3 order-by keys", planning.sort_keys_source(agg.schema(), [e.expr for e in top.input.exprs])))
     # a Filter node's mask kernel and a Projection with CASE / LIKE (Q12 / Q14 shapes)

@@ -939,12 +939,13 @@ void plan_predicate_mask(const ExprSet& es, const std::vector<InputCol>& input, 
 }
 
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root,
-               int kernel, bool dev_rows) {
+               int kernel, bool dev_rows, int n_parts) {
   out = KeysPlan();
   layout_keys(es, input, roots, n, false, out.keys, out.W, out.null_mask_word);
   if (out.W > 8) fail(QHIP_UNSUPPORTED, "join key wider than 8 words");
   ExprGen g(es, input);
-  const bool raw = kernel == KEYS_KERNEL_PROBE || kernel == KEYS_KERNEL_DENSE_PROBE;
+  const bool raw = kernel == KEYS_KERNEL_PROBE || kernel == KEYS_KERNEL_DENSE_PROBE || kernel == KEYS_KERNEL_PARTITION;
+  if (kernel == KEYS_KERNEL_PARTITION && (n_parts < 1 || n_parts > 255)) fail(QHIP_INVALID_ARGUMENT, "partition kernel: 1 .. 255 parts");
   if (raw) {
     // the probe kernel is software-pipelined over its tiles: a row's column loads are issued one stage (load(), branch-free,
     // tile-relative addressing) before its filter / key words are computed from them (keys())
@@ -962,6 +963,11 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     g.emit(predicate_root, code);
   }
   emit_key_words(g, es, out.keys, false, "k", code, &all);
+  // (the exchange's partition kernel tells "rejected by the filter" (the row is dropped) from "NULL key" (the row travels, hashed
+  // as all-zero key words): bit 1 / bit 0 of what keys() returns)
+  if (kernel == KEYS_KERNEL_PARTITION)
+    all = "(" + (predicate_root >= 0 ? "(" + g.ok(predicate_root) + " && " + g.val(predicate_root) + ")" : std::string("true")) + " ? 2u : 0u) | ((" + all + ") ? 1u : 0u)";
+  else
   if (predicate_root >= 0) all = "(" + g.ok(predicate_root) + " && " + g.val(predicate_root) + ") && " + all;
   std::ostringstream s;
   s << "struct P {\n  static constexpr int W = " << out.W << ";\n";
@@ -972,9 +978,11 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     for (auto& ic : input) if (ic.narrow_bytes == 4 && ic.type.id == QHIP_INT64 && !ic.indirect) narrow_key = true;
     out.probe_r = std::max(1, std::min(8, kernel == KEYS_KERNEL_DENSE_PROBE ? env_int("QHIP_DENSE_PROBE_R", narrow_key ? 4 : 2) : env_int("QHIP_PROBE_R", 4)));
     s << "  static constexpr int PROBE_R = " << out.probe_r << ";\n";
+    if (kernel == KEYS_KERNEL_PARTITION)
+      s << "  static constexpr int NP = " << n_parts << ";\n  static constexpr int PART_R = " << std::max(1, std::min(8, env_int("QHIP_PART_R", 4))) << ";\n";
     s << "  struct Raw {\n" << g.raw_fields << "    int unused_;\n  };\n";
     s << "  __device__ static __forceinline__ void load(const KArgs& a, const i64 tb, const u32 o, Raw& w) {\n" << g.load_code << "    w.unused_ = 0;\n  }\n";
-    s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const Raw& w, u64* k, u32& err) {\n" << code;
+    s << "  __device__ static __forceinline__ " << (kernel == KEYS_KERNEL_PARTITION ? "u32" : "bool") << " keys(const KArgs& a, const Raw& w, u64* k, u32& err) {\n" << code;
   } else {
     s << "  __device__ static __forceinline__ bool keys(const KArgs& a, const i64 i, u64* k, u32& err) {\n" << code;
   }
@@ -996,6 +1004,10 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_join_probe_dense_wide(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 0, true>(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_lds(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 1, false>(a, L); }\n";
     s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_join_probe_dense_hybrid(KArgs a, ProbeLaunch L) { qh_join_probe_dense_body<P, 2, false>(a, L); }\n";
+  } else if (kernel == KEYS_KERNEL_PARTITION) {
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_part_ids(KArgs a, PartIdsLaunch L) { qh_part_ids_body<P, " << (dev_rows ? "true" : "false") << ", false>(a, L); }\n";
+    // (tables of at least one tile: a lane owns PART_R consecutive rows — 16-byte column loads, one 4-byte store of its part bytes)
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_part_ids_wide(KArgs a, PartIdsLaunch L) { qh_part_ids_body<P, " << (dev_rows ? "true" : "false") << ", true>(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_DENSE_BUILD) {
     s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_join_dense_build(KArgs a, DenseBuildLaunch L) { qh_join_dense_build_body<P" << (dev_rows ? ", true" : "") << ">(a, L); }\n";
   } else if (kernel == KEYS_KERNEL_SCATTER)
@@ -1005,8 +1017,90 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
          "qh_eval_keys_body<P>(a, keys, keyvalid, status); }\n";
   out.source = s.str();
   out.kernel_name = kernel == KEYS_KERNEL_PROBE ? "qk_join_probe" : kernel == KEYS_KERNEL_SCATTER ? "qk_join_scatter" :
-                    kernel == KEYS_KERNEL_DENSE_PROBE ? "qk_join_probe_dense" : kernel == KEYS_KERNEL_DENSE_BUILD ? "qk_join_dense_build" : "qk_eval_keys";
+                    kernel == KEYS_KERNEL_DENSE_PROBE ? "qk_join_probe_dense" : kernel == KEYS_KERNEL_DENSE_BUILD ? "qk_join_dense_build" :
+                    kernel == KEYS_KERNEL_PARTITION ? "qk_part_ids" : "qk_eval_keys";
   out.bind = g.bind;
+}
+
+// ---------------------------------------------------------------- exchange, pass 2
+void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out) {
+  out = PartScatterPlan();
+  if (widths.empty() || widths.size() > 8) fail(QHIP_INVALID_ARGUMENT, "partition scatter: 1 .. 8 columns per launch");
+  auto T = [](int w) { return w == 1 ? "u8" : w == 2 ? "u16" : (w == 4 || w == 0) ? "u32" : w == 8 ? "u64" : "qh_v4u"; };
+  int maxw = 4;
+  for (int w : widths) maxw = std::max(maxw, w);
+  const int R = std::max(1, std::min(8, env_int("QHIP_PART_SCATTER_R", 4)));
+  out.rows_per_lane = R;
+  std::ostringstream s;
+  // measurement switches: stores straight from the registers (no LDS staging: every lane writes its own value to its place in
+  // the part's run), one tile at a time instead of the two-stage loop, the stores left out altogether (results wrong)
+  const bool direct = env_int("QHIP_PART_SCATTER_DIRECT", 0) != 0, no_stores = env_int("QHIP_PART_SCATTER_NOSTORE", 0) != 0;
+  const bool nt_store = env_int("QHIP_PART_SCATTER_NT", 0) != 0;
+  const int tb = std::max(256, std::min(1024, env_int("QHIP_PART_SCATTER_TB", 512))) / 64 * 64;
+  s << "struct P {\n  static constexpr int TB = " << tb << ";\n  static constexpr int NC = " << widths.size() << ", R = " << R << ", NPT = " << (n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0)
+    << ", MAXW = " << maxw << ", DIRECT = " << (direct ? 1 : 0) << ", PIPE = " << (env_int("QHIP_PART_SCATTER_PIPE", 1) != 0 ? 1 : 0) << ";\n";
+  s << "  struct Vals {\n";
+  for (size_t c = 0; c < widths.size(); ++c) s << "    " << T(widths[c]) << " c" << c << "[R];\n";
+  s << "  };\n";
+  s << "  __device__ static __forceinline__ void load(const PartScatterLaunch& L, const i64 tb, const i64 last, const int lane, Vals& v) {\n";
+  s << "#pragma unroll\n    for (int r = 0; r < R; ++r) {\n      i64 row = tb + r * 64 + lane;\n      row = row < last ? row : last - 1;\n";
+  for (size_t c = 0; c < widths.size(); ++c) {
+    const std::string t = T(widths[c]);
+    if (widths[c] == 0) s << "      v.c" << c << "[r] = (u32)row;\n";
+    else if (indirect[c]) s << "      v.c" << c << "[r] = ((const " << t << "*)L.src[" << c << "])[L.idx[" << c << "][row]];\n";
+    else s << "      v.c" << c << "[r] = __builtin_nontemporal_load((const " << t << "*)L.src[" << c << "] + row);\n";
+  }
+  s << "    }\n  }\n";
+  s << "  __device__ static __forceinline__ void move(const PartScatterLaunch& L, const Vals& v, const i64 tb, const u32* id, const u32* pos, const u32* dst,\n"
+       "                                              const u32 total, u8* sval, const u32* sdst, const int lane) {\n";
+  // every store is UNCONDITIONAL (a lane beyond the tile's rows stores the tile's last row again — same value, same address — and a
+  // tile without rows stores into the launch's scratch line): a store behind a branch is one the compiler cannot count, and it
+  // then waits for ALL older stores' acknowledgements before the next tile's loads (s_waitcnt vmcnt(loads only))
+  if (!direct) s << "    u32 d[R], jj[R];\n#pragma unroll\n    for (int k = 0; k < R; ++k) { const u32 j = (u32)k * 64u + (u32)lane; jj[k] = j < total ? j : (total ? total - 1u : 0u); d[k] = total ? sdst[jj[k]] : (u32)lane; }\n";
+  for (size_t c = 0; c < widths.size(); ++c) {
+    const std::string t = T(widths[c]);
+    if (direct) {
+      if (!no_stores && nt_store) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) if (id[r] != 0xFFu) __builtin_nontemporal_store(v.c" << c << "[r], (" << t << "*)L.out[" << c << "] + dst[r]);\n";
+      else if (!no_stores) s << "#pragma unroll\n    for (int r = 0; r < R; ++r) if (id[r] != 0xFFu) ((" << t << "*)L.out[" << c << "])[dst[r]] = v.c" << c << "[r];\n";
+      else s << "#pragma unroll\n    for (int r = 0; r < R; ++r) if (id[r] == 0xFEu) ((" << t << "*)L.out[" << c << "])[dst[r]] = v.c" << c << "[r];\n";
+      continue;
+    }
+    s << "#pragma unroll\n    for (int r = 0; r < R; ++r) if (id[r] != 0xFFu) ((" << t << "*)sval)[pos[r]] = v.c" << c << "[r];\n";
+    s << "    asm volatile(\"\" ::: \"memory\");\n";
+    if (env_int("QHIP_PART_SCATTER_TRASH", 0))   // (measurement: every store lands in the 1 KB scratch line — the store path without HBM writes)
+      s << "    { " << t << "* const o = (" << t << "*)L.trash;\n#pragma unroll\n    for (int k = 0; k < R; ++k) d[k] &= 63u;\n";
+    else
+    s << "    { " << t << "* const o = total ? (" << t << "*)L.out[" << c << "] : (" << t << "*)L.trash;\n";
+    s << "#pragma unroll\n    for (int k = 0; k < R; ++k) { const " << t << " x = ((const " << t << "*)sval)[jj[k]]; "
+      << (no_stores ? "if (lane > 64) " : "") << (nt_store ? "__builtin_nontemporal_store(x, o + d[k])" : "o[d[k]] = x") << "; } }\n";
+    s << "    asm volatile(\"\" ::: \"memory\");\n";
+  }
+  s << "  }\n";
+  // workgroup form: the tile of TB * R rows is laid out in LDS column by column and written out by all threads; every store is
+  // unconditional here too (see above)
+  s << "  __device__ static __forceinline__ void move_wg(const PartScatterLaunch& L, const Vals& v, const u32* id, const u32* pos, u8* sval, const u32* sdst,\n"
+       "                                                 const u32* stotal, const int tid) {\n";
+  s << "    u32 d[R], jj[R];\n    u32 total = 0;\n";
+  for (size_t c = 0; c < widths.size(); ++c) {
+    const std::string t = T(widths[c]);
+    s << "#pragma unroll\n    for (int r = 0; r < R; ++r) if (id[r] != 0xFFu) ((" << t << "*)sval)[pos[r]] = v.c" << c << "[r];\n";
+    s << "    __syncthreads();\n";
+    if (c == 0)
+      s << "    total = *stotal;\n#pragma unroll\n    for (int k = 0; k < R; ++k) { const u32 j = (u32)k * (u32)TB + (u32)tid; jj[k] = j < total ? j : (total ? total - 1u : 0u); "
+           "d[k] = total ? sdst[jj[k]] : (u32)(tid & 63); }\n";
+    s << "    { " << t << "* const o = total ? (" << t << "*)L.out[" << c << "] : (" << t << "*)L.trash;\n";
+    s << "#pragma unroll\n    for (int k = 0; k < R; ++k) { const " << t << " x = ((const " << t << "*)sval)[jj[k]]; "
+      << (no_stores ? "if (tid > 4096) " : "") << (nt_store ? "__builtin_nontemporal_store(x, o + d[k])" : "o[d[k]] = x") << "; } }\n";
+    s << "    __syncthreads();\n";
+  }
+  s << "  }\n};\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_part_scatter(PartScatterLaunch L) { qh_part_scatter_body<P" << (dev_rows ? ", true" : "")
+    << ">(L); }\n";
+  s << "extern \"C\" __global__ __launch_bounds__(" << tb << ") void qk_part_scatter_wg(PartScatterLaunch L) { qh_part_scatter_wg_body<P" << (dev_rows ? ", true" : "")
+    << ">(L); }\n";
+  out.wg_threads = tb;
+  out.source = s.str();
+  out.kernel_name = "qk_part_scatter";
 }
 
 // ---------------------------------------------------------------- projection

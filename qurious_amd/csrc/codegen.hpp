@@ -123,9 +123,16 @@ struct KeysPlan {
 // qh_join_probe_body) or qk_join_scatter (build rows -> region entries of the LDS-staged join build, qh_join_scatter_body)
 // ... or the two kernels of the dense (direct-address) join layout: qk_join_dense_build (qh_join_dense_build_body) and
 // qk_join_probe_dense / qk_join_probe_dense_lds (qh_join_probe_dense_body)
-enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2, KEYS_KERNEL_DENSE_BUILD = 3, KEYS_KERNEL_DENSE_PROBE = 4 };
+// ... or pass 1 of the exchange's fused filter + partition: qk_part_ids (qh_part_ids_body; n_parts is a compile-time constant of it)
+enum { KEYS_KERNEL_EVAL = 0, KEYS_KERNEL_PROBE = 1, KEYS_KERNEL_SCATTER = 2, KEYS_KERNEL_DENSE_BUILD = 3, KEYS_KERNEL_DENSE_PROBE = 4, KEYS_KERNEL_PARTITION = 5 };
 void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int32_t* roots, int n, KeysPlan& out, int predicate_root = -1,
-               int kernel = KEYS_KERNEL_EVAL, bool dev_rows = false);   // (dev_rows: the build kernels only)
+               int kernel = KEYS_KERNEL_EVAL, bool dev_rows = false, int n_parts = 0);   // (dev_rows: the build kernels and the partition kernel)
+
+// ---------------------------------------------------------------- exchange, pass 2 (qh_part_scatter_body)
+// widths[c]: bytes per value of column c (1, 2, 4, 8, 16), 0 = the row number itself as u32 (the parts' selection vector);
+// indirect[c]: the column is read through an index vector; n_parts picks the ranking variant (<= 8, <= 16, more)
+struct PartScatterPlan { std::string source; std::string kernel_name; int rows_per_lane = 4; int wg_threads = 512; /* qk_part_scatter_wg's workgroup */ };
+void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out);
 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };

@@ -62,13 +62,17 @@ struct DevBuf {
   size_t bytes = 0;
   size_t cap = 0;     // size class actually allocated (caching allocator, ctx.cpp)
   int device = 0;
+  // a VIEW of `bytes` bytes inside another buffer (the parts of a partitioned column are slices of one allocation, exchange.cpp):
+  // the view keeps the owner alive and returns nothing to the pool itself
+  std::shared_ptr<DevBuf> owner;
   DevBuf() {}
   explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const std::shared_ptr<DevBuf>& whole, size_t offset, size_t n) : ptr((uint8_t*)whole->ptr + offset), bytes(n), cap(0), device(whole->device), owner(whole) {}
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes), cap(o.cap), device(o.device) { o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
+  DevBuf(DevBuf&& o) noexcept : ptr(o.ptr), bytes(o.bytes), cap(o.cap), device(o.device), owner(std::move(o.owner)) { o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; cap = o.cap; device = o.device; o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; cap = o.cap; device = o.device; owner = std::move(o.owner); o.ptr = nullptr; o.bytes = 0; o.cap = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
@@ -217,7 +221,7 @@ struct Module;  // jit.cpp
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // call begin / end, dominant kernel begin / end
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // call begin / end, dominant kernel begin / end, end of the first phase (partition: pass 1)
   std::string last_error;
   std::string device_name;
   int num_cus = 256;
@@ -225,7 +229,7 @@ struct Ctx {
   // HIP events around an operator's phases (qhip_exec_stats timings). OFF by default: every event record is a packet of its
   // own on the stream (~5 us of stream time; Q3 recorded 10 per query) — qhip_ctx_set_timing / QHIP_TIMING=1 switch them on
   bool timing = false;
-  mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 — read when the stats are asked for
+  mutable int stats_timing_pending = 0;   // 1: total = ev0..ev1; 2: also main kernel = ev2..ev3 (3: and build_ms = ev0..ev4) — read when the stats are asked for
   std::unordered_map<std::string, std::shared_ptr<Module>> modules;  // kernel cache keyed by generated source
   DevBuf status;       // QS_WORDS u32 status words
   // 128-byte blocks of zeros for status words / counters of ONE operator call (zeroed_block): handed out in turn from a ring

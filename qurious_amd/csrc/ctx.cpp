@@ -255,6 +255,7 @@ void DevBuf::alloc(size_t n) {
   device = dev;
 }
 void DevBuf::release() {
+  if (owner) { owner.reset(); ptr = nullptr; bytes = 0; cap = 0; return; }   // a view: the owner's last reference frees the memory
   if (!ptr) return;
   if (g_live_contexts[device & 31].load(std::memory_order_relaxed) > 1) (void)hipDeviceSynchronize();
   Pool& pool = g_pools[device & 31];
@@ -398,7 +399,8 @@ int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
     qhip_ctx* c = const_cast<qhip_ctx*>(ctx);
     float ms = 0;
     if (sync_event(c->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.total_device_ms = ms;
-    if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.main_kernel_ms = ms;
+    if (c->stats_timing_pending >= 2 && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.main_kernel_ms = ms;
+    if (c->stats_timing_pending == 3 && hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) c->stats.build_ms = ms;   // (partition: pass 1 + scan)
     if (c->stats_timing_pending == 2 && hipEventElapsedTime(&ms, c->ev[0], c->ev[2]) == hipSuccess) c->stats.build_ms = ms;   // (hash join)
     else if (c->stats_timing_pending == 1) c->stats.main_kernel_ms = c->stats.total_device_ms;
     c->stats_timing_pending = 0;

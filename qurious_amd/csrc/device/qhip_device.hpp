@@ -825,6 +825,446 @@ __device__ __forceinline__ void qh_agg_reduce_body(const ReduceLaunch& R, const 
   qh_report(L.status, err);
 }
 
+// Hash of a join key: ONE 64-bit multiply and a fold per key word. The probe kernel hashes every probing row, and a 64-bit
+// multiply is four quarter-rate 32-bit ones — the two multiplies of qh_mix64 were about a third of that kernel's VALU time.
+// The high half of the product depends on every key bit (it picks the region / the legacy filter word); folding it into
+// the low half does the same for the slot and filter-bit fields taken from there (a bare product's low bits would only
+// depend on the key's low bits: TPC-H order keys use 8 of every 32 values).
+__device__ __forceinline__ u64 qh_fold_mul(u64 x) { x *= 0x9E3779B97F4A7C15ULL; return x ^ (x >> 32); }
+template <int W> __device__ __forceinline__ u64 qh_key_hash(const u64* k) {
+  u64 h = qh_fold_mul(k[0]);
+#pragma unroll
+  for (int w = 1; w < W; ++w) h = qh_fold_mul(h ^ k[w]) + (u64)w;
+  return h;
+}
+
+// ------------------------------------------------------------------ exchange, pass 1: fused scan filter + key -> part of every row
+// The multi-GPU hash-join exchange (the reference is a single process and has no counterpart) splits a rank's
+// slice of a join input by mix64(key words) into one part per rank. Round 3 did that as five generic steps (Filter operator,
+// key words to a buffer, part ids, a stable radix sort of (part, row) pairs, per-part per-column gathers: 0.12 of the HBM
+// peak); since round 4 it is two streaming passes:
+//   pass 1  qh_part_ids_body (here, generated per plan): the scan filter and the key expressions are evaluated straight from
+//           the table's columns; every row gets ONE BYTE — its part, or 0xFF when the filter rejects it — and every wavefront
+//           counts its rows per part (ballots; the counts never leave the SGPRs until the wavefront is done);
+//           an exclusive scan of hist[part][wavefront] (part-major) then gives every (part, wavefront) run its place;
+//   pass 2  k_part_scatter (kernels_rel.hip, plan-independent): the same wavefront re-reads its row range — the part bytes and
+//           ONLY the columns the plan above the exchange reads — ranks the rows of a tile per part (ballots again: stable, so a
+//           part keeps the input's row order), orders the tile by part in LDS and stores it: consecutive lanes write
+//           consecutive values of a part's run.
+// A unit of work is a WAVEFRONT with a static, contiguous row range: no workgroup barrier anywhere, no atomics at all.
+// Policy P (generated, KEYS_KERNEL_PARTITION): NP parts (compile time: the per-part counters are an unrolled SGPR array),
+// W key words, Raw / load() as for the probe kernels, keys() returns bit 0 = every key column is non-null, bit 1 = the row
+// passes the scan filter. A row with a NULL key hashes as all-zero key words (like k_partition_ids).
+struct PartIdsLaunch {
+  u8* ids;            // out: part of row i, 0xFF = rejected by the filter
+  u32* hist;          // out: [NP][n_units] rows per (part, unit)
+  u32* status;
+  u32 n_units;        // units that own rows; unit u owns rows [u * rows_per_unit, (u + 1) * rows_per_unit)
+  u32 rows_per_unit;  // a multiple of 4 tiles (a tile = 64 * PART_R rows)
+  u32 wg_units;       // 0: a unit is a WAVEFRONT (pass 2's wavefront form needs every wavefront's runs); 1: a unit is a WORKGROUP
+  u32 pad_;           //    whose four wavefronts take a quarter of its rows each (big inputs: a quarter of the counters to scan)
+};
+template <class P>
+struct QhPartTile {
+  typename P::Raw raw[P::PART_R];
+  i64 tb;      // wave-uniform: first row the tile's loads read (WIDE: shifted back for a partial last tile)
+  i64 nominal; // wave-uniform: first row of the tile (rows in front of it belong to the previous tile)
+  bool live;   // wave-uniform
+};
+// WIDE: a lane owns R CONSECUTIVE rows of the tile (row = tile base + lane * R + r): the R loads of a column are adjacent and
+// merge into 16-byte loads, and the lane's R part bytes are ONE 4-byte store (per-row byte stores wrote 64-byte half lines).
+// Needs a table of at least one tile: a partial last tile is shifted back to end at the range's last row and the rows in
+// front of its nominal start are masked. Pass 1 only COUNTS per part, so the row order inside a tile is free.
+template <class P, bool WIDE>
+__device__ __forceinline__ u32 qh_part_row_off(int r, int lane) { return WIDE ? (u32)lane * P::PART_R + (u32)r : (u32)r * 64u + (u32)lane; }
+template <class P, bool WIDE>
+__device__ __forceinline__ void qh_part_load(const KArgs& a, QhPartTile<P>& x, i64 first, i64 last, i64 j, int lane) {
+  constexpr int R = P::PART_R, TILE = 64 * R;
+  const i64 tb = first + j * TILE;
+  x.live = tb < last;
+  x.nominal = x.live ? tb : first;
+  x.tb = WIDE ? (x.nominal + TILE <= last ? x.nominal : last - TILE) : x.nominal;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const u32 o = qh_part_row_off<P, WIDE>(r, lane);
+    if (WIDE) P::load(a, x.tb, o, x.raw[r]);
+    else P::load(a, x.tb, x.tb + (i64)o < last ? o : (u32)(last - 1 - x.tb), x.raw[r]);
+  }
+}
+// THE partition function of the exchange: both join sides and every rank must agree on it (k_partition_ids computes the same
+// from key-word arrays, oracle/ holds the numpy mirror the tests check against). One 64-bit multiply + fold per key word
+// (qh_key_hash, the join's hash; the murmur finaliser of rounds 1-3 — two 64-bit multiplies per word, four quarter-rate
+// 32-bit multiplies each — was 60 % of pass 1's time), the high half picks the part. A NULL key hashes as all-zero words.
+template <int W> __device__ __forceinline__ u32 qh_part_hash(const u64* k, const bool valid, const u32 n_parts) {
+  u64 z[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) z[w] = valid ? k[w] : 0ULL;
+  const u64 h = qh_key_hash<W>(z);
+  return (u32)(((h >> 32) * (u64)n_parts) >> 32);
+}
+template <class P>
+__device__ __forceinline__ u32 qh_part_of(const u64* k, bool valid) { return qh_part_hash<P::W>(k, valid, (u32)P::NP); }
+template <class P, bool DEVROWS = false, bool WIDE = false>
+__device__ __forceinline__ void qh_part_ids_body(const KArgs& a, const PartIdsLaunch& L) {
+  constexpr int R = P::PART_R, TILE = 64 * R, NP = P::NP;
+  constexpr bool SMALL = NP <= 16;   // counters in SGPRs (unrolled); more parts: a per-wavefront LDS histogram
+  __shared__ u32 lh[SMALL ? 1 : QH_BLOCK / 64][SMALL ? 1 : 256];
+  __shared__ u32 wg_cnt[SMALL ? 16 : 256];
+  const int lane = qh_lane();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool wgu = L.wg_units != 0;   // (uniform over the grid)
+  const u32 unit = wgu ? blockIdx.x : blockIdx.x * (QH_BLOCK / 64) + (u32)wv;
+  if (unit >= L.n_units) return;
+  if (wgu) { for (int p = (int)threadIdx.x; p < (SMALL ? 16 : 256); p += QH_BLOCK) wg_cnt[p] = 0; __syncthreads(); }
+  const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
+  const i64 quarter = (i64)(L.rows_per_unit / (QH_BLOCK / 64));
+  const i64 ufirst = (i64)unit * L.rows_per_unit;
+  const i64 first = wgu ? ufirst + (i64)wv * quarter : ufirst;
+  const i64 uend = wgu ? first + quarter : ufirst + L.rows_per_unit;
+  const i64 last = uend < nrows ? uend : nrows;
+  u32 cnt[SMALL ? NP : 1];
+#pragma unroll
+  for (int p = 0; p < (SMALL ? NP : 1); ++p) cnt[p] = 0;
+  if (!SMALL) { for (int p = lane; p < 256; p += 64) lh[wv][p] = 0; }
+  u32 err = 0;
+  if (first < last) {
+    const i64 mine = (last - first + TILE - 1) / TILE;
+    QhPartTile<P> A, B;
+    qh_part_load<P, WIDE>(a, A, first, last, 0, lane);
+    // one trip: the next tile's column loads are issued, then the current tile is evaluated out of registers (two register
+    // sets, the loop unrolled over them; the scheduling barrier keeps the evaluation behind the issue, qh_pred_mask_body)
+#define QH_PART_TRIP(X, Y, J)                                                          \
+    qh_part_load<P, WIDE>(a, Y, first, last, (J) + 1, lane);                           \
+    asm volatile("" ::: "memory");                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (X.live) {                                                                      \
+      u32 idr[R];                                                                      \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) {                                  \
+        const i64 row = X.tb + (i64)qh_part_row_off<P, WIDE>(r, lane);                 \
+        const bool inb = row < last && row >= X.nominal;                               \
+        u64 k[P::W];                                                                   \
+        u32 e = 0;                                                                     \
+        const u32 code = P::keys(a, X.raw[r], k, e);                                   \
+        err |= inb ? e : 0u;                                                           \
+        const u32 id = (inb && (code & 2u)) ? qh_part_of<P>(k, (code & 1u) != 0) : 0xFFu;   \
+        idr[r] = id;                                                                   \
+        if (!WIDE && inb) L.ids[row] = (u8)id;                                         \
+        if (SMALL) {                                                                   \
+          _Pragma("unroll") for (int p = 0; p < (SMALL ? NP : 1); ++p) cnt[p] += (u32)__builtin_popcountll(qh_ballot(id == (u32)p)); \
+        } else if (id != 0xFFu) atomicAdd(&lh[wv][id], 1u);                            \
+      }                                                                                \
+      if (WIDE) {                                                                      \
+        const i64 row0 = X.tb + (i64)lane * R;                                         \
+        if (R == 4 && X.tb == X.nominal && X.tb + TILE <= last) {   /* wave-uniform: a whole, aligned tile */ \
+          *(u32*)(L.ids + row0) = idr[0] | (idr[1] << 8) | (idr[2] << 16) | (idr[3] << 24);  \
+        } else {                                                                       \
+          _Pragma("unroll") for (int r = 0; r < R; ++r) if (row0 + r < last && row0 + r >= X.nominal) L.ids[row0 + r] = (u8)idr[r]; \
+        }                                                                              \
+      }                                                                                \
+    }
+    for (i64 j = 0; j < mine; j += 2) {   // wave-uniform
+      QH_PART_TRIP(A, B, j)
+      QH_PART_TRIP(B, A, j + 1)
+    }
+#undef QH_PART_TRIP
+  }
+  if (SMALL) {
+    u32 mine_cnt = 0;
+#pragma unroll
+    for (int p = 0; p < (SMALL ? NP : 1); ++p) mine_cnt = lane == p ? cnt[p] : mine_cnt;
+    if (wgu) { if (lane < NP && mine_cnt) atomicAdd(&wg_cnt[lane], mine_cnt); }
+    else if (lane < NP) L.hist[(size_t)lane * L.n_units + unit] = mine_cnt;
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int p = lane; p < NP; p += 64) {
+      if (wgu) { if (lh[wv][p]) atomicAdd(&wg_cnt[p], lh[wv][p]); }
+      else L.hist[(size_t)p * L.n_units + unit] = lh[wv][p];
+    }
+  }
+  if (wgu) {
+    __syncthreads();
+    for (int p = (int)threadIdx.x; p < NP; p += QH_BLOCK) L.hist[(size_t)p * L.n_units + unit] = wg_cnt[p];
+  }
+  qh_report(L.status, err);
+}
+
+// ------------------------------------------------------------------ exchange, pass 2: rows -> per-part runs
+// The wavefront that counted a row range in pass 1 reads it again: the part bytes and the columns that travel. A tile of
+// 64 * R rows is ranked per part with ballots (stable: a part keeps the input's row order), ordered by part in the wavefront's
+// OWN LDS area and written out so that consecutive lanes store consecutive values of a part's run. Every column is ONE buffer
+// over all parts (part p = positions [runs[p * n_units], runs[(p + 1) * n_units]) of it): a part's column is a slice, never a
+// copy. No workgroup barrier, no atomic; a wavefront's DS operations execute in order, so its LDS traffic needs no waits
+// beyond the register dependencies (the empty asm statements only keep the COMPILER from reordering them).
+// The kernel is generated per column shape (policy P: Vals = the registers of one tile's values, load() = all column loads of
+// a tile, move() = LDS staging + stores, column by column) because everything about it must be static: the loads of tile
+// t + 1 are issued before tile t is ranked and stored, and vector-memory operations return in order — only with a known
+// number of loads and stores per trip can the compiler wait with s_waitcnt vmcnt(N > 0) for exactly the older tile's loads
+// while this tile's stores are still in flight. (The first version, a plan-independent kernel with a run-time loop over
+// column descriptors, drained the queue at every column: 3.1 TB/s on Q3's lineitem side.)
+// NPT = 8 / 16: the parts' counters are unrolled SGPR arrays; NPT = 0: up to 255 parts, the distinct parts of a tile row are
+// walked with readfirstlane + ballot and the counters live in LDS.
+#define QH_PART_MAXC 8
+struct PartScatterLaunch {
+  const u8* ids;         // pass 1: part of every row, 0xFF = dropped
+  const u32* runs;       // exclusive scan of pass 1's hist[part][unit] (part-major)
+  i64 nrows;
+  const u32* nrows_dev;  // the input's row count lives on the device (a join output of deferred size), nrows = capacity
+  u32 n_units, rows_per_unit, n_parts;
+  u32 sub;               // workgroup form: a workgroup owns the rows of `sub` consecutive pass-1 units (wavefront form: 1)
+  void* trash;           // 1 KB nobody reads: where the (unconditional) stores of a tile without rows go
+  const void* src[QH_PART_MAXC];   // the columns' values ...
+  const u32* idx[QH_PART_MAXC];    // ... read through this index vector where the policy says so (a deferred gather never materialised)
+  void* out[QH_PART_MAXC];
+};
+__device__ __forceinline__ u32 qh_wave_incl_scan_u32(u32 v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)v, d, 64); if (lane >= d) v += t; }
+  return v;
+}
+// ranks of a tile's rows inside their parts (q), the tile's first position per part (s_tf), rows in the tile (total) and the
+// count this lane is responsible for when the running positions advance (cnt4: NPT > 0: part `lane`; NPT = 0: parts 4 lane ..)
+template <int NPT, int R>
+__device__ __forceinline__ void qh_part_rank(const u32 (&id)[R], u32 (&q)[R], u32& total, u32 (&cnt4)[4], u32* s_tf, const u32 np, const int lane) {
+  total = 0;
+  cnt4[0] = cnt4[1] = cnt4[2] = cnt4[3] = 0;
+  if (NPT > 0) {
+    u32 run[NPT > 0 ? NPT : 1];
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) run[p] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      q[r] = 0;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const u64 m = qh_ballot(id[r] == (u32)p);
+        q[r] = id[r] == (u32)p ? run[p] + (u32)qh_rank(m) : q[r];
+        run[p] += (u32)__builtin_popcountll(m);
+      }
+    }
+    u32 my_tf = 0;
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) { my_tf = lane == p ? total : my_tf; cnt4[0] = lane == p ? run[p] : cnt4[0]; total += run[p]; }
+    if (lane < NPT) s_tf[lane] = my_tf;
+  } else {
+    for (u32 p = (u32)lane; p < np; p += 64) s_tf[p] = 0;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      q[r] = 0;
+      u64 todo = qh_ballot(id[r] != 0xFFu);
+      while (todo) {   // wave-uniform
+        const int l = __builtin_ctzll(todo);
+        const u32 p = qh_readlane32(id[r], l);
+        const u64 m = qh_ballot(id[r] == p);
+        const u32 base = s_tf[p];
+        if (id[r] == p) q[r] = base + (u32)qh_rank(m);
+        asm volatile("" ::: "memory");
+        if (lane == l) s_tf[p] = base + (u32)__builtin_popcountll(m);
+        asm volatile("" ::: "memory");
+        todo &= ~m;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; cnt4[k] = p < np ? s_tf[p] : 0u; }
+    const u32 mine = cnt4[0] + cnt4[1] + cnt4[2] + cnt4[3];
+    const u32 incl = qh_wave_incl_scan_u32(mine, lane);
+    total = qh_readlane32(incl, 63);
+    u32 at = incl - mine;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_tf[p] = at; at += cnt4[k]; }
+  }
+  asm volatile("" ::: "memory");
+}
+template <class P>
+struct QhScatterTile {
+  u32 id[P::R];
+  typename P::Vals v;
+  i64 tb;      // wave-uniform
+  bool live;   // wave-uniform
+};
+template <class P>
+__device__ __forceinline__ void qh_scatter_load(const PartScatterLaunch& L, QhScatterTile<P>& x, const i64 first, const i64 last, const i64 j, const int lane) {
+  constexpr int R = P::R, TILE = 64 * R;
+  const i64 tb = first + j * TILE;
+  x.live = tb < last;
+  x.tb = x.live ? tb : first;
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const i64 row = x.tb + r * 64 + lane; x.id[r] = (u32)L.ids[row < last ? row : last - 1]; }
+  P::load(L, x.tb, last, lane, x.v);
+}
+template <class P, bool DEVROWS = false>
+__device__ __forceinline__ void qh_part_scatter_body(const PartScatterLaunch& L) {
+  constexpr int R = P::R, TILE = 64 * R, NW = QH_BLOCK / 64, NPT = P::NPT, NPL = NPT > 0 ? NPT : 256;
+  __shared__ __attribute__((aligned(16))) u8 s_val[NW][TILE * P::MAXW];
+  __shared__ u32 s_dst[NW][TILE];
+  __shared__ u32 s_cur[NW][NPL];   // per part: position (in the column buffers) of this wavefront's next row of the part
+  __shared__ u32 s_tf[NW][NPL];    // per part: first position of the part inside the ordered tile
+  const int lane = qh_lane();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32 unit = blockIdx.x * NW + (u32)wv;
+  if (unit >= L.n_units) return;
+  i64 nrows = L.nrows;
+  if (DEVROWS) { const i64 d = (i64)*L.nrows_dev; nrows = d < nrows ? d : nrows; }
+  const i64 first = (i64)unit * L.rows_per_unit;
+  const i64 last = first + L.rows_per_unit < nrows ? first + L.rows_per_unit : nrows;
+  if (first >= last) return;
+  const u32 np = L.n_parts;
+  for (u32 p = (u32)lane; p < np; p += 64) s_cur[wv][p] = L.runs[(size_t)p * L.n_units + unit];
+  const i64 mine = (last - first + TILE - 1) / TILE;
+  QhScatterTile<P> A, B;
+  qh_scatter_load<P>(L, A, first, last, 0, lane);
+#define QH_SCATTER_TRIP(X, Y, J)                                                                          \
+  qh_scatter_load<P>(L, Y, first, last, (J) + 1, lane);                                                    \
+  asm volatile("" ::: "memory");                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                       \
+  {   /* unconditional on every path (a trip behind the last tile moves nothing: every id is 0xFF): the number of   */  \
+      /* memory operations per trip is then static, which is what lets the compiler wait with vmcnt(N > 0)         */  \
+    u32 id[R], q[R], pos[R], cnt4[4], total;                                                               \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) id[r] = (X.live && X.tb + r * 64 + lane < last) ? X.id[r] : 0xFFu;  \
+    qh_part_rank<NPT, R>(id, q, total, cnt4, s_tf[wv], np, lane);                                          \
+    u32 dst[R];                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                        \
+      pos[r] = 0; dst[r] = 0;                                                                              \
+      if (id[r] != 0xFFu) { pos[r] = s_tf[wv][id[r]] + q[r]; dst[r] = s_cur[wv][id[r]] + q[r]; if (!P::DIRECT) s_dst[wv][pos[r]] = dst[r]; } \
+    }                                                                                                      \
+    asm volatile("" ::: "memory");                                                                         \
+    if (NPT > 0) { if (lane < NPT) s_cur[wv][lane] += cnt4[0]; }                                           \
+    else { _Pragma("unroll") for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_cur[wv][p] += cnt4[k]; } } \
+    asm volatile("" ::: "memory");                                                                         \
+    P::move(L, X.v, X.tb, id, pos, dst, total, s_val[wv], s_dst[wv], lane);                                \
+  }                                                                                                        \
+  asm volatile("" ::: "memory");                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+  if (P::PIPE) {
+    for (i64 j = 0; j < mine; j += 2) {   // wave-uniform
+      QH_SCATTER_TRIP(A, B, j)
+      QH_SCATTER_TRIP(B, A, j + 1)
+    }
+  } else {   // (measurements: one tile at a time, one register set)
+    for (i64 j = 0; j < mine; ++j) {
+      if (j) qh_scatter_load<P>(L, A, first, last, j, lane);
+      u32 id[R], q[R], pos[R], dst[R], cnt4[4], total;
+#pragma unroll
+      for (int r = 0; r < R; ++r) id[r] = A.tb + r * 64 + lane < last ? A.id[r] : 0xFFu;
+      qh_part_rank<NPT, R>(id, q, total, cnt4, s_tf[wv], np, lane);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        pos[r] = 0; dst[r] = 0;
+        if (id[r] != 0xFFu) { pos[r] = s_tf[wv][id[r]] + q[r]; dst[r] = s_cur[wv][id[r]] + q[r]; if (!P::DIRECT) s_dst[wv][pos[r]] = dst[r]; }
+      }
+      asm volatile("" ::: "memory");
+      if (NPT > 0) { if (lane < NPT) s_cur[wv][lane] += cnt4[0]; }
+      else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_cur[wv][p] += cnt4[k]; }
+      }
+      asm volatile("" ::: "memory");
+      P::move(L, A.v, A.tb, id, pos, dst, total, s_val[wv], s_dst[wv], lane);
+      asm volatile("" ::: "memory");
+    }
+  }
+#undef QH_SCATTER_TRIP
+}
+
+// Pass 2, WORKGROUP-cooperative form (the default for big inputs). What bounds the wavefront form above is not its instruction
+// count or its loads (with the stores switched off it moves Q3's lineitem side at 5.8 TB/s) but the WRITES: every wavefront
+// keeps parts x columns output streams open and feeds each a few hundred bytes per tile — ~100 k concurrent streams of
+// ~270-byte bursts over the chip, which HBM serves at ~2 TB/s (fewer, fatter units were faster although they leave most of
+// the chip idle: the measured evidence that the stream count, not the parallelism, is the limit). Here a unit is a WORKGROUP
+// of P::TB threads that owns the row range of `sub` consecutive pass-1 units and moves it in tiles of TB * R rows: the
+// wavefronts rank their rows with ballots as before, their per-part counts meet in LDS, ONE barrier later every wavefront
+// knows where its rows go inside the tile and inside the parts' runs; then column by column the tile is laid out in LDS
+// ordered by part and written out by all threads — bursts of kilobytes per part and column, parts x columns streams per
+// WORKGROUP. Same policy P as the wavefront form (+ TB), same stable order, same runs.
+template <class P, bool DEVROWS = false>
+__device__ __forceinline__ void qh_part_scatter_wg_body(const PartScatterLaunch& L) {
+  constexpr int R = P::R, TB = P::TB, NW = TB / 64, TILE = TB * R, NPT = P::NPT, NPL = NPT > 0 ? NPT : 256;
+  __shared__ __attribute__((aligned(16))) u8 s_val[TILE * P::MAXW];
+  __shared__ u32 s_dst[TILE];
+  __shared__ u32 s_wcnt[NW][NPL];   // rows of the tile per (wavefront, part)
+  __shared__ u32 s_pos[NW][NPL];    // first position inside the ordered tile of the wavefront's rows of the part
+  __shared__ u32 s_out[NW][NPL];    // ... and inside the column buffers
+  __shared__ u32 s_tf[NW][NPL];     // (scratch of qh_part_rank: per-wavefront first positions, unused here)
+  __shared__ u32 s_cur[NPL];        // per part: position in the column buffers of the workgroup's next row of the part
+  __shared__ u32 s_total;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const u32 unit = blockIdx.x;
+  i64 nrows = L.nrows;
+  if (DEVROWS) { const i64 d = (i64)*L.nrows_dev; nrows = d < nrows ? d : nrows; }
+  const i64 rows_per_wg = (i64)L.rows_per_unit * L.sub;
+  const i64 first = (i64)unit * rows_per_wg;
+  const i64 last = first + rows_per_wg < nrows ? first + rows_per_wg : nrows;
+  if (first >= last) return;   // (workgroup-uniform)
+  const u32 np = L.n_parts;
+  for (u32 p = (u32)tid; p < np; p += TB) s_cur[p] = L.runs[(size_t)p * L.n_units + (size_t)unit * L.sub];
+  const i64 ntiles = (last - first + TILE - 1) / TILE;
+  // the wavefront's rows of tile j: [first + j * TILE + wv * 64 * R, + 64 * R) — row order = (wavefront, r, lane)
+  QhScatterTile<P> A, B;
+  const i64 wfirst = first + (i64)wv * 64 * R;
+  auto load = [&](QhScatterTile<P>& x, const i64 j) {
+    const i64 tb = wfirst + j * TILE;
+    x.live = j < ntiles;
+    x.tb = x.live ? tb : wfirst;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const i64 row = x.tb + r * 64 + lane; x.id[r] = (u32)L.ids[row < last ? row : last - 1]; }
+    P::load(L, x.tb, last, lane, x.v);
+  };
+  load(A, 0);
+#define QH_SCATTER_WG_TRIP(X, Y, J)                                                                        \
+  load(Y, (J) + 1);                                                                                        \
+  asm volatile("" ::: "memory");                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                       \
+  {                                                                                                        \
+    u32 id[R], q[R], pos[R], cnt4[4], wtotal;                                                              \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) id[r] = (X.live && X.tb + r * 64 + lane < last) ? X.id[r] : 0xFFu;  \
+    qh_part_rank<NPT, R>(id, q, wtotal, cnt4, s_tf[wv], np, lane);                                         \
+    if (NPT > 0) { if (lane < NPT) s_wcnt[wv][lane] = cnt4[0]; }                                           \
+    else { _Pragma("unroll") for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_wcnt[wv][p] = cnt4[k]; } } \
+    __syncthreads();                                                                                       \
+    /* every wavefront, for its own row of the tables: rows of earlier wavefronts per part, the tile's rows per part */ \
+    {                                                                                                      \
+      u32 before[4] = {0, 0, 0, 0}, all[4] = {0, 0, 0, 0};                                                 \
+      _Pragma("unroll") for (int k = 0; k < (NPT > 0 ? 1 : 4); ++k) {                                      \
+        const u32 p = NPT > 0 ? (u32)lane : (u32)lane * 4u + (u32)k;                                       \
+        if (p < np && p < (u32)NPL) {                                                                      \
+          for (int w2 = 0; w2 < NW; ++w2) { const u32 c = s_wcnt[w2][p]; all[k] += c; before[k] += w2 < wv ? c : 0u; } \
+        }                                                                                                  \
+      }                                                                                                    \
+      const u32 mine = all[0] + all[1] + all[2] + all[3];                                                  \
+      const u32 incl = qh_wave_incl_scan_u32(mine, lane);                                                  \
+      u32 at = incl - mine;                                                                                \
+      _Pragma("unroll") for (int k = 0; k < (NPT > 0 ? 1 : 4); ++k) {                                      \
+        const u32 p = NPT > 0 ? (u32)lane : (u32)lane * 4u + (u32)k;                                       \
+        if (p < np && p < (u32)NPL) { s_pos[wv][p] = at + before[k]; s_out[wv][p] = s_cur[p] + before[k]; } \
+        at += all[k];                                                                                      \
+      }                                                                                                    \
+      if (tid == TB - 1) s_total = incl;   /* (lane 63 of the last wavefront: the tile's rows) */          \
+      asm volatile("" ::: "memory");                                                                       \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                      \
+        pos[r] = 0;                                                                                        \
+        if (id[r] != 0xFFu) { pos[r] = s_pos[wv][id[r]] + q[r]; s_dst[pos[r]] = s_out[wv][id[r]] + q[r]; } \
+      }                                                                                                    \
+      P::move_wg(L, X.v, id, pos, s_val, s_dst, &s_total, tid);                                            \
+      /* (move_wg ends behind a barrier: everybody has read s_cur / s_wcnt) */                             \
+      if (wv == 0) {                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < (NPT > 0 ? 1 : 4); ++k) {                                    \
+          const u32 p = NPT > 0 ? (u32)lane : (u32)lane * 4u + (u32)k;                                     \
+          if (p < np && p < (u32)NPL) s_cur[p] += all[k];                                                  \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }                                                                                                        \
+  asm volatile("" ::: "memory");                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+  for (i64 j = 0; j < ntiles; j += 2) {   // workgroup-uniform
+    QH_SCATTER_WG_TRIP(A, B, j)
+    QH_SCATTER_WG_TRIP(B, A, j + 1)
+  }
+#undef QH_SCATTER_WG_TRIP
+}
+
 // ------------------------------------------------------------------ predicate -> selection mask kernel
 // Filter::execute (physical/plan/filter.rs:28-44): mask word j holds the keep bits of rows 64j..64j+63
 // (wavefront ballot), wave_count[j] their popcount; the exclusive scan of wave_count gives every
@@ -926,19 +1366,6 @@ __device__ __forceinline__ u32 qh_join_find(const u64* table, u32 base, u32 mask
   }
   return 0xFFFFFFFFu;
 }
-// Hash of a join key: ONE 64-bit multiply and a fold per key word. The probe kernel hashes every probing row, and a 64-bit
-// multiply is four quarter-rate 32-bit ones — the two multiplies of qh_mix64 were about a third of that kernel's VALU time.
-// The high half of the product depends on every key bit (it picks the region / the legacy filter word); folding it into
-// the low half does the same for the slot and filter-bit fields taken from there (a bare product's low bits would only
-// depend on the key's low bits: TPC-H order keys use 8 of every 32 values).
-__device__ __forceinline__ u64 qh_fold_mul(u64 x) { x *= 0x9E3779B97F4A7C15ULL; return x ^ (x >> 32); }
-template <int W> __device__ __forceinline__ u64 qh_key_hash(const u64* k) {
-  u64 h = qh_fold_mul(k[0]);
-#pragma unroll
-  for (int w = 1; w < W; ++w) h = qh_fold_mul(h ^ k[w]) + (u64)w;
-  return h;
-}
-
 struct ProbeLaunch {
   const u64* table;      // distinct build keys
   const u64* bloom;      // hash filter of 64-bit words: qh_filter_mask() of the key all set in its word, else the key is not in

@@ -10,6 +10,8 @@
 
 #include "common.hpp"
 #include "device/qhip_status.h"
+#include "jit.hpp"
+#include "kargs_host.hpp"
 #include "kernels.hpp"
 #include "relops.hpp"
 
@@ -87,6 +89,281 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
     out_parts[p] = t.release();
   }
   flush();
+}
+
+// ---- the fused path (round 4): scan filter + key -> part byte per row + per-wavefront histogram (qk_part_ids, generated) ->
+// scan -> ONE host wait (the parts' sizes + the status words) -> k_part_scatter moves only the columns `keep` names, each into
+// ONE buffer over all parts; a part's column is a slice (view) of it. Columns the scatter kernel cannot move itself
+// (validity bitmaps, Booleans, strings) are gathered per part through the selection vector the same kernel leaves behind.
+// A deferred gather whose source is plain is read THROUGH its index vector in both passes (never materialised).
+struct PartitionPlan { KeysPlan kp; std::shared_ptr<Module> mod, mod_wide; DevBuf strlit; };
+
+// pass 2 runs its workgroup-cooperative form (few output streams, bursts of kilobytes) from 2^20 rows on
+bool scatter_wg_form(int64_t rows) {
+  const int wg_mode = env_int("QHIP_PART_SCATTER_WG", 1);   // 0 never, 1 big inputs, 2 always (tests)
+  return env_int("QHIP_PART_SCATTER_JIT", 1) != 0 && (wg_mode == 2 || (wg_mode == 1 && rows >= (1 << 20)));
+}
+
+struct PartitionWork {       // what pass 1 leaves on the device for pass 2
+  DevBuf trash{2048};        // where pass 2's unconditional stores of a tile without rows go
+  DevBuf ids, runs, starts;  // part byte per row | scanned hist [n_parts * n_units] + total | the parts' first positions (n_parts + 1)
+  uint32_t n_units = 0, rows_per_unit = 0;
+  bool wg_units = false;     // a unit is a workgroup of pass 1 (pass 2 then runs its workgroup form)
+  uint32_t* dstat = nullptr;
+  double pass1_bytes_per_row = 0;   // column bytes the filter + key expressions read per row
+};
+
+void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
+                     int n_parts, PartitionWork& w) {
+  hipStream_t s = ctx->stream;
+  const uint64_t N = (uint64_t)in->num_rows;
+  resolve_referenced(ctx, in, exprs, n_exprs, true);
+  std::vector<InputCol> icols = input_cols_of(in, true);
+  // partition ids must agree across ranks and across the two join sides: Utf8 keys always hash as 4 words (<= 31 bytes)
+  for (int k = 0; k < n_keys; ++k)
+    if (roots[k] >= 0 && roots[k] < n_exprs && exprs[roots[k]].kind == QHIP_EXPR_COLUMN && exprs[roots[k]].column >= 0 &&
+        exprs[roots[k]].column < (int)icols.size() && icols[(size_t)exprs[roots[k]].column].type.id == QHIP_UTF8)
+      icols[(size_t)exprs[roots[k]].column].utf8_max_len = 31;
+  // a resident table's Int64 key column whose values fit 32 bits is read through its 4-byte narrow copy (made at the second big
+  // read of the column, relops.cpp ensure_narrow_int_columns — TPC-H's order and customer keys)
+  ensure_narrow_int_columns(ctx, in, exprs, n_exprs, icols, (int64_t)env_int("QHIP_STATS_MIN_ROWS", 1 << 22));
+  std::string pkey = "partition|";
+  {
+    auto put = [&](const void* p, size_t n) { pkey.append((const char*)p, n); };
+    for (auto& ic : icols) {
+      const int v[8] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0, ic.narrow_bytes};
+      put(v, sizeof v);
+    }
+    put("|", 1);
+    for (int k = 0; k < n_exprs; ++k) {
+      qhip_expr e = exprs[k];
+      const char* str = e.lit_str; const int64_t len = e.lit_len;
+      e.lit_str = nullptr;
+      put(&e, sizeof e);
+      if (str && len > 0 && e.kind == QHIP_EXPR_LITERAL) put(str, (size_t)len);
+    }
+    put("|", 1);
+    put(roots, sizeof(int32_t) * (size_t)n_keys);
+    const int v[3] = {pred_root, n_parts, in->rows_dev ? 1 : 0};
+    put(v, sizeof v);
+  }
+  std::shared_ptr<PartitionPlan> pp;
+  {
+    auto cached = ctx->plan_cache.find(pkey);
+    if (cached != ctx->plan_cache.end()) pp = std::static_pointer_cast<PartitionPlan>(cached->second);
+    else {
+      pp = std::make_shared<PartitionPlan>();
+      ExprSet es;
+      es.build(exprs, n_exprs, icols);
+      if (pred_root >= n_exprs) fail(QHIP_INVALID_ARGUMENT, "qhip_partition_filtered: predicate index out of range");
+      plan_keys(es, icols, roots, n_keys, pp->kp, pred_root, KEYS_KERNEL_PARTITION, in->rows_dev != nullptr, n_parts);
+      if (ctx->plan_cache.size() > 4096) ctx->plan_cache.clear();
+      ctx->plan_cache[pkey] = pp;
+    }
+  }
+  if (!pp->mod) pp->mod = get_module(ctx, pp->kp.source, pp->kp.kernel_name);
+  for (size_t k = 0; k < pp->kp.bind.cols.size(); ++k) {
+    const int c = pp->kp.bind.cols[k];
+    const int wd = dtype_width(icols[(size_t)c].type);
+    w.pass1_bytes_per_row += icols[(size_t)c].indirect ? wd + 4 : icols[(size_t)c].narrow_bytes ? icols[(size_t)c].narrow_bytes : wd > 0 ? wd : 8;
+  }
+  // units of work = wavefronts with a static row range of whole tiles (256 rows in both passes); enough of them for ~8 rounds
+  // of the chip's resident wavefronts, few enough that the histogram is scanned by ONE launch (<= 64 k counters) when the
+  // table is not huge
+  // Big inputs (pass 2 runs its workgroup form): a unit is a WORKGROUP of pass 1 whose four wavefronts count a quarter of its
+  // rows each — a quarter of the counters to scan (k_scan_small: one workgroup, ~20 us for 64 k counters).
+  w.wg_units = scatter_wg_form(in->num_rows);
+  const uint64_t tile = w.wg_units ? 4 * (uint64_t)std::max(64, env_int("QHIP_PART_UNIT_QUANTUM", 256)) : 256;   // (a workgroup unit: four wavefronts x whole tiles)
+  uint64_t want = std::max<uint64_t>(1, (uint64_t)ctx->num_cus * (w.wg_units ? 8 : 32));
+  if ((uint64_t)n_parts * want > 65536 && 65536 / (uint64_t)n_parts >= (uint64_t)ctx->num_cus * 4) want = 65536 / (uint64_t)n_parts;
+  uint64_t rpu = std::max<uint64_t>(w.wg_units ? tile : tile * 4, ((N + want - 1) / want + tile - 1) / tile * tile);
+  if (env_int("QHIP_PART_ROWS_PER_UNIT", 0) > 0) rpu = (uint64_t)(env_int("QHIP_PART_ROWS_PER_UNIT", 0) + (int)tile - 1) / tile * tile;
+  w.rows_per_unit = (uint32_t)rpu;
+  w.n_units = (uint32_t)std::max<uint64_t>(1, (N + rpu - 1) / rpu);
+  const size_t nh = (size_t)n_parts * w.n_units;
+  DevBuf hist((nh + 4) * 4);
+  w.ids.alloc(N + 64);
+  w.runs.alloc((nh + 4) * 4);
+  w.starts.alloc(((size_t)n_parts + 1) * 4);
+  w.dstat = zeroed_block(ctx);
+  HKArgs ka;
+  fill_kargs(ctx, in, pp->kp.bind, ka, pp->strlit);
+  HPartIdsLaunch pl = {w.ids.as<uint8_t>(), hist.as<uint32_t>(), w.dstat, w.n_units, w.rows_per_unit, w.wg_units ? 1u : 0u, 0u};
+  void* args[] = {&ka, &pl};
+  time_mark(ctx, 0);
+  // (the wide form needs whole tiles to shift a partial last tile back over: an exact row count of at least one tile)
+  const bool wide = env_int("QHIP_PART_WIDE", 1) != 0 && !in->rows_dev && N >= 256 * 8;
+  if (wide && !pp->mod_wide) pp->mod_wide = get_module(ctx, pp->kp.source, "qk_part_ids_wide");
+  QHIP_HIP_CHECK(hipModuleLaunchKernel((wide ? pp->mod_wide : pp->mod)->fn, w.wg_units ? w.n_units : (w.n_units + 3) / 4, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+  time_mark(ctx, 4);
+  exclusive_scan_u32(hist.as<uint32_t>(), w.runs.as<uint32_t>(), nh, w.runs.as<uint32_t>() + nh, s);
+  launch_gather_stride_u32(w.runs.as<uint32_t>(), w.n_units, (uint32_t)n_parts + 1, w.starts.as<uint32_t>(), s);   // (entry n_parts = the scan's total)
+}
+
+// the parts' tables from the parts' first positions (host copy of PartitionWork::starts): pass 2 + the gathers of the odd columns
+void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, const uint32_t* starts,
+                     qhip_table** out_parts) {
+  hipStream_t s = ctx->stream;
+  const uint64_t total = starts[n_parts];
+  struct Moved { size_t col; std::shared_ptr<DevBuf> out; int width; };
+  std::vector<Moved> moved;
+  std::vector<size_t> odd;   // columns gathered per part through the selection vector
+  // one generated kernel per group of columns (qh_part_scatter_body: the registers of two tiles' values bound the group: <= 48
+  // bytes per row, <= 8 columns); the AOT kernel k_part_scatter (any shape, QHIP_PART_SCATTER_JIT=0) is the plan-independent form
+  const bool jit = env_int("QHIP_PART_SCATTER_JIT", 1) != 0;
+  const int budget = std::max(16, env_int("QHIP_PART_SCATTER_BYTES", 48));
+  struct Pending { const void* src; const uint32_t* idx; void* out; int width; };
+  std::vector<Pending> group;
+  int group_bytes = 0;
+  bool marked = false;
+  auto flush = [&] {
+    if (group.empty()) return;
+    if (total) {
+      if (!marked) { time_mark(ctx, 2); marked = true; }
+      if (jit) {
+        std::vector<int> widths; std::vector<char> ind;
+        for (auto& g : group) { widths.push_back(g.src || g.width != 4 ? g.width : 0); ind.push_back(g.idx ? 1 : 0); }
+        std::string key = "part_scatter|" + std::to_string(n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0) + (in->rows_dev ? "|d" : "|h");
+        for (size_t k = 0; k < widths.size(); ++k) key += "|" + std::to_string(widths[k]) + (ind[k] ? "i" : "");
+        struct ScatterPlan { PartScatterPlan sp; std::shared_ptr<Module> mod, mod_wg; };
+        std::shared_ptr<ScatterPlan> sp;
+        auto cached = ctx->plan_cache.find(key);
+        if (cached != ctx->plan_cache.end()) sp = std::static_pointer_cast<ScatterPlan>(cached->second);
+        else {
+          sp = std::make_shared<ScatterPlan>();
+          plan_part_scatter(widths, ind, n_parts, in->rows_dev != nullptr, sp->sp);
+          sp->mod = get_module(ctx, sp->sp.source, sp->sp.kernel_name);
+          ctx->plan_cache[key] = sp;
+        }
+        HPartScatterLaunch L;
+        memset(&L, 0, sizeof L);
+        L.ids = w.ids.as<uint8_t>(); L.runs = w.runs.as<uint32_t>();
+        L.nrows = in->num_rows; L.nrows_dev = in->rows_dev;
+        L.n_units = w.n_units; L.rows_per_unit = w.rows_per_unit; L.n_parts = (uint32_t)n_parts; L.sub = 1;
+        L.trash = w.trash.ptr;
+        for (size_t k = 0; k < group.size(); ++k) { L.src[k] = group[k].src; L.idx[k] = group[k].idx; L.out[k] = group[k].out; }
+        void* args[] = {&L};
+        // the workgroup-cooperative form: a workgroup takes `sub` consecutive pass-1 units: ~3 workgroups per CU over the
+        // table (measured: 2-3 best, 6 / 12 cost 7-9 % — more streams), at least 4 tiles each
+        if (w.wg_units) {
+          if (!sp->mod_wg) sp->mod_wg = get_module(ctx, sp->sp.source, "qk_part_scatter_wg");
+          const uint64_t tile = (uint64_t)sp->sp.wg_threads * (uint64_t)sp->sp.rows_per_lane;
+          const uint64_t want_wgs = (uint64_t)std::max(1, env_int("QHIP_PART_SCATTER_WGS_PER_CU", 3)) * (uint64_t)ctx->num_cus;
+          uint64_t rows_wg = std::max<uint64_t>(4 * tile, ((uint64_t)in->num_rows + want_wgs - 1) / want_wgs);
+          const uint32_t sub = (uint32_t)std::max<uint64_t>(1, (rows_wg + w.rows_per_unit - 1) / w.rows_per_unit);
+          L.sub = sub;
+          const unsigned wgs = (w.n_units + sub - 1) / sub;
+          QHIP_HIP_CHECK(hipModuleLaunchKernel(sp->mod_wg->fn, wgs, 1, 1, (unsigned)sp->sp.wg_threads, 1, 1, 0, s, args, nullptr));
+        } else
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(sp->mod->fn, (w.n_units + 3) / 4, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+      } else {
+        PartScatterArgs A;
+        memset(&A, 0, sizeof A);
+        A.ids = w.ids.as<uint8_t>(); A.runs = w.runs.as<uint32_t>();
+        A.nrows = (uint64_t)in->num_rows; A.nrows_dev = in->rows_dev;
+        A.n_units = w.n_units; A.rows_per_unit = w.rows_per_unit; A.n_parts = (uint32_t)n_parts;
+        for (auto& g : group) A.cols[A.n_cols++] = PartCol{g.src, g.idx, g.out, (uint32_t)g.width, g.src ? 0u : 1u};
+        launch_part_scatter(A, s);
+      }
+    }
+    group.clear();
+    group_bytes = 0;
+  };
+  auto push = [&](const void* src, const uint32_t* idx, void* out, int width) {
+    if (!group.empty() && (group_bytes + width > budget || (int)group.size() == (jit ? kPartMaxCols : kPartCols))) flush();
+    group.push_back(Pending{src, idx, out, width});
+    group_bytes += width;
+  };
+  for (size_t c = 0; c < in->cols.size(); ++c) {
+    const DevColumn& c0 = in->cols[c];
+    if ((keep && !keep[c]) || c0.type.id == QHIP_NULL) continue;
+    const int width = dtype_width(c0.type);
+    if (indirect_eligible(c0)) {
+      auto out = std::make_shared<DevBuf>((size_t)total * (size_t)width);
+      push(c0.deferred->src.values->ptr, c0.deferred->idx->as<uint32_t>(), out->ptr, width);
+      moved.push_back(Moved{c, out, width});
+      continue;
+    }
+    const DevColumn& rc = resolved(ctx, c0);
+    if (width > 0 && rc.null_count == 0 && rc.values) {
+      auto out = std::make_shared<DevBuf>((size_t)total * (size_t)width);
+      push(rc.values->ptr, nullptr, out->ptr, width);
+      moved.push_back(Moved{c, out, width});
+    } else odd.push_back(c);
+  }
+  std::shared_ptr<DevBuf> sel;
+  if (!odd.empty()) {
+    sel = std::make_shared<DevBuf>(((size_t)total + 1) * 4);
+    push(nullptr, nullptr, sel->ptr, 4);   // (no source: the row number itself)
+  }
+  flush();
+  if (!marked) time_mark(ctx, 2);
+  time_mark(ctx, 3);
+  for (int p = 0; p < n_parts; ++p) {
+    std::unique_ptr<qhip_table> t(new qhip_table());
+    t->ctx = ctx;
+    t->names = in->names;
+    t->nullable = in->nullable;
+    const uint64_t at = starts[p], m = (uint64_t)starts[p + 1] - at;
+    t->cols.resize(in->cols.size());
+    for (size_t c = 0; c < in->cols.size(); ++c) {   // dropped columns: NULL-typed placeholders (qhip_table_keep_columns)
+      DevColumn& oc = t->cols[c];
+      if ((keep && !keep[c]) || in->cols[c].type.id == QHIP_NULL) {
+        oc.type = DType{QHIP_NULL, 0, 0}; oc.length = (int64_t)m; oc.null_count = (int64_t)m;
+        t->nullable[c] = true;
+      }
+    }
+    for (const Moved& mv : moved) {
+      const DevColumn& src = in->cols[mv.col];
+      DevColumn& oc = t->cols[mv.col];
+      oc.type = src.type;
+      oc.length = (int64_t)m;
+      oc.value_maxabs = src.deferred ? src.deferred->src.value_maxabs : src.value_maxabs;
+      oc.range = src.deferred ? src.deferred->src.range : src.range; oc.range_inherited = true;
+      oc.values = std::make_shared<DevBuf>(mv.out, (size_t)at * (size_t)mv.width, (size_t)m * (size_t)mv.width);
+    }
+    for (size_t c : odd) t->cols[c] = gather_column(ctx, in->cols[c], sel->as<uint32_t>() + at, m, false);
+    t->num_rows = (int64_t)m;
+    t->batch_offsets = {0, (int64_t)m};
+    out_parts[p] = t.release();
+  }
+}
+
+void partition_filtered(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
+                        const int32_t* keep, int n_parts, qhip_table** out_parts) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  if (n_parts <= 0 || n_parts > 255 || n_keys <= 0) fail(QHIP_INVALID_ARGUMENT, "qhip_partition_filtered: bad arguments (1 .. 255 parts)");
+  if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+  hipStream_t s = ctx->stream;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->stats_timing_pending = 0;
+  PartitionWork w;
+  partition_pass1(ctx, in, exprs, n_exprs, roots, n_keys, pred_root, n_parts, w);   // (HIP events 0 / 4 around its kernel)
+  uint32_t* const back = (uint32_t*)ctx->pinned;   // [status words | parts' first positions + total]
+  if ((size_t)(QS_WORDS + n_parts + 1) * 4 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "qhip_partition_filtered: too many parts for the read-back scratch");
+  QHIP_HIP_CHECK(hipMemcpyAsync(back, w.dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
+  QHIP_HIP_CHECK(hipMemcpyAsync(back + QS_WORDS, w.starts.ptr, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, s));
+  QHIP_HIP_CHECK(sync_stream(s));
+  verify_pending_sizes(ctx);
+  check_status_words(back);
+  std::vector<uint32_t> starts(back + QS_WORDS, back + QS_WORDS + n_parts + 1);
+  partition_pass2(ctx, in, keep, n_parts, w, starts.data(), out_parts);   // (HIP events 2 / 3 around its scatter launches)
+  time_mark(ctx, 1);
+  // statistics (qhip_exec_stats): build_ms = pass 1's kernel, main_kernel_ms = pass 2's kernel(s), total_device_ms = first launch ..
+  // last launch incl. the scan and the host wait between the passes; bytes_per_row_read
+  // = column bytes pass 2 reads per INPUT row, build_bytes_per_row = column bytes pass 1 reads per input row
+  ctx->stats_timing_pending = ctx->timing ? 3 : 0;
+  ctx->stats.rows_in = in->num_rows;
+  ctx->stats.rows_out = (int64_t)starts[(size_t)n_parts];
+  ctx->stats.groups = n_parts;
+  ctx->stats.workgroups = (int32_t)((w.n_units + 3) / 4);
+  ctx->stats.build_rows = in->num_rows;
+  ctx->stats.build_bytes_per_row = w.pass1_bytes_per_row;
+  double moved = 0;
+  for (size_t c = 0; c < in->cols.size(); ++c)
+    if ((!keep || keep[c]) && in->cols[c].type.id != QHIP_NULL) moved += dtype_width(in->cols[c].type);
+  ctx->stats.bytes_per_row_read = moved;
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "k_part_scatter");
 }
 
 // One destination column assembled from n source sections on the device (shared by qhip_table_concat and the unpacking of
@@ -613,7 +890,34 @@ int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input, const qhip_exp
                           int32_t n_keys, int32_t n_parts, qhip_table** out_parts) {
   if (!ctx || !input || !out_parts) return QHIP_INVALID_ARGUMENT;
   for (int p = 0; p < n_parts; ++p) out_parts[p] = nullptr;
-  int rc = guarded(ctx, [&] { settle_rows(input); partition_by_key(ctx, input, exprs, n_exprs, key_roots, n_keys, n_parts, out_parts); });
+  int rc = guarded(ctx, [&] {
+    settle_rows(input);
+    if (n_parts <= 255 && env_int("QHIP_PARTITION_FUSED", 1) != 0) partition_filtered(ctx, input, exprs, n_exprs, key_roots, n_keys, -1, nullptr, n_parts, out_parts);
+    else partition_by_key(ctx, input, exprs, n_exprs, key_roots, n_keys, n_parts, out_parts);
+  });
+  if (rc != QHIP_OK)
+    for (int p = 0; p < n_parts; ++p) { if (out_parts[p]) { delete out_parts[p]; out_parts[p] = nullptr; } }
+  return rc;
+}
+
+int qhip_partition_filtered(qhip_ctx* ctx, const qhip_table* input, const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots,
+                            int32_t n_keys, int32_t predicate_root, const int32_t* keep_columns, int32_t n_parts, qhip_table** out_parts) {
+  if (!ctx || !input || !out_parts || !key_roots) return QHIP_INVALID_ARGUMENT;
+  for (int p = 0; p < n_parts; ++p) out_parts[p] = nullptr;
+  int rc = guarded(ctx, [&] {
+    if (n_parts > 255 || env_int("QHIP_PARTITION_FUSED", 1) == 0) {
+      // more parts than a byte names (or the switch): the generic sort-based path, which takes no filter and moves every column
+      if (predicate_root >= 0) fail(QHIP_UNSUPPORTED, "qhip_partition_filtered: a fused scan filter needs the fused path (<= 255 parts)");
+      settle_rows(input);
+      if (keep_columns) {
+        std::unique_ptr<qhip_table> kept(table_keep_columns(ctx, input, keep_columns));
+        partition_by_key(ctx, kept.get(), exprs, n_exprs, key_roots, n_keys, n_parts, out_parts);
+      } else partition_by_key(ctx, input, exprs, n_exprs, key_roots, n_keys, n_parts, out_parts);
+      return;
+    }
+    settle_rows(input);
+    partition_filtered(ctx, input, exprs, n_exprs, key_roots, n_keys, predicate_root, keep_columns, n_parts, out_parts);
+  });
   if (rc != QHIP_OK)
     for (int p = 0; p < n_parts; ++p) { if (out_parts[p]) { delete out_parts[p]; out_parts[p] = nullptr; } }
   return rc;

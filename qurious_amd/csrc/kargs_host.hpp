@@ -91,6 +91,31 @@ struct HDenseBuildLaunch {
 };
 static_assert(sizeof(HDenseBuildLaunch) == 40, "DenseBuildLaunch layout");
 
+struct HPartIdsLaunch {
+  uint8_t* ids;
+  uint32_t* hist;
+  uint32_t* status;
+  uint32_t n_units;
+  uint32_t rows_per_unit;
+  uint32_t wg_units;
+  uint32_t pad_;
+};
+static_assert(sizeof(HPartIdsLaunch) == 40, "PartIdsLaunch layout");
+
+constexpr int kPartMaxCols = 8;   // QH_PART_MAXC
+struct HPartScatterLaunch {
+  const uint8_t* ids;
+  const uint32_t* runs;
+  int64_t nrows;
+  const uint32_t* nrows_dev;
+  uint32_t n_units, rows_per_unit, n_parts, sub;
+  void* trash;
+  const void* src[kPartMaxCols];
+  const uint32_t* idx[kPartMaxCols];
+  void* out[kPartMaxCols];
+};
+static_assert(sizeof(HPartScatterLaunch) == 32 + 16 + 8 + 3 * 8 * 8, "PartScatterLaunch layout");
+
 struct HScatterLaunch {
   uint64_t* entries;
   uint32_t* first;

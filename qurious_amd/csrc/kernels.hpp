@@ -75,6 +75,26 @@ void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, 
 void launch_join_out_counts(const uint32_t* cnt, uint64_t np, uint32_t* out_cnt, hipStream_t s);
 void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const uint32_t* in_off, const uint32_t* out_off, uint64_t np,
                               uint32_t* b_out, uint32_t* p_out, hipStream_t s);
+// exchange, pass 2 (kernels_rel.hip k_part_scatter): every column of `cols` is moved from row order into per-part runs
+struct PartCol {
+  const void* src;       // the column's values (kind 0)
+  const uint32_t* idx;   // ... read through this index vector when set (a deferred gather that was never materialised)
+  void* out;             // ONE buffer over all parts: part p = positions [runs[p * n_units], runs[(p + 1) * n_units])
+  uint32_t width;        // bytes per value: 1, 2, 4, 8, 16
+  uint32_t kind;         // 0 = values; 1 = the row number itself (u32: the selection vector of the parts, for the columns that
+                         //     need a gather of their own — validity bits, strings, Booleans)
+};
+constexpr int kPartCols = 12;
+struct PartScatterArgs {
+  const uint8_t* ids;        // pass 1: part of every row, 0xFF = dropped
+  const uint32_t* runs;      // exclusive scan of pass 1's hist[part][unit] (part-major)
+  uint64_t nrows;
+  const uint32_t* nrows_dev; // the input's row count lives on the device (a join output of deferred size), nrows = capacity
+  uint32_t n_units, rows_per_unit, n_parts, n_cols;
+  PartCol cols[kPartCols];
+};
+void launch_part_scatter(const PartScatterArgs& a, hipStream_t s);
+void launch_gather_stride_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out, hipStream_t s);
 void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s);
 void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,
                            hipStream_t s);

@@ -799,7 +799,7 @@ __global__ void k_lookup_u32(const u32* off, const u64* rows, u32 n, u64 nrows, 
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) out[k] = rows[k] >= nrows ? total : off[rows[k]];
 }
-// partition id per row from its key words (exchange): mix64 of the key, top bits -> [0, nparts)
+// partition id per row from its key words (exchange, generic path): qh_part_hash, the function the fused pass 1 evaluates
 #define QH_MAX_PARTS 1024
 template <int W>
 __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64 n, u32 nparts, u32* part, u32* hist) {
@@ -809,15 +809,166 @@ __global__ __launch_bounds__(QH_BLOCK) void k_partition_ids(const u64* keys, u64
   for (u32 p = threadIdx.x; p < nparts; p += QH_BLOCK) lh[p] = 0;
   __syncthreads();
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
-    u64 h = 0;
+    u64 k[W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) h = qh_mix64(h ^ keys[(size_t)w * n + i]);
-    const u32 pid = (u32)(((h >> 32) * (u64)nparts) >> 32);
+    for (int w = 0; w < W; ++w) k[w] = keys[(size_t)w * n + i];   // (a NULL key's words are zero already, qh_eval_keys_body)
+    const u32 pid = qh_part_hash<W>(k, true, nparts);
     part[i] = pid;
     atomicAdd(&lh[pid], 1u);
   }
   __syncthreads();
   for (u32 p = threadIdx.x; p < nparts; p += QH_BLOCK) if (lh[p]) atomicAdd(&hist[p], lh[p]);
+}
+
+// ================================================================ exchange, pass 2: rows -> per-part runs
+// (pass 1 and the design: device/qhip_device.hpp qh_part_ids_body.) The wavefront that counted a row range in pass 1 reads it
+// again: the part bytes, then one column after the other. A tile of 64 * R rows is ranked per part with ballots (stable: a
+// part keeps the input's row order), ordered by part in the wavefront's OWN LDS area and written out so that consecutive
+// lanes store consecutive values of a part's run. Every column is ONE buffer over all parts (part p = positions
+// [runs[p * n_units], runs[(p + 1) * n_units]) of it): a part's column is a slice, never a copy. No workgroup barrier, no
+// atomic: the LDS traffic of a wavefront is ordered by the hardware (DS operations of one wavefront execute in order).
+// NPT = 8 / 16: the parts' counters are unrolled SGPR arrays; NPT = 0: up to 255 parts, the distinct parts of a tile row are
+// walked with readfirstlane + ballot and the counters live in LDS.
+template <class T>
+__device__ __forceinline__ void qh_scatter_column(const PartCol& col, const i64 tb, const i64 last, const int lane, const u32 (&id)[4], const u32 (&pos)[4],
+                                                  const u32 total, u8* sval, const u32* sdst) {
+  constexpr int R = 4;
+  T v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    i64 row = tb + r * 64 + lane;
+    row = row < last ? row : last - 1;
+    if (col.kind == 1) {   // the row number itself (T = u32)
+      if constexpr (sizeof(T) == 4) v[r] = (T)(u32)row;
+      else v[r] = T{};
+    } else {
+      const u64 src = col.idx ? (u64)col.idx[row] : (u64)row;
+      v[r] = col.idx ? ((const T*)col.src)[src] : __builtin_nontemporal_load((const T*)col.src + src);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) if (id[r] != 0xFFu) ((T*)sval)[pos[r]] = v[r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const u32 j = (u32)k * 64u + (u32)lane;
+    if (j < total) ((T*)col.out)[sdst[j]] = ((const T*)sval)[j];
+  }
+  asm volatile("" ::: "memory");
+}
+
+template <int NPT>
+__global__ __launch_bounds__(QH_BLOCK) void k_part_scatter(PartScatterArgs A) {
+  constexpr int R = 4, TILE = 64 * R, NW = QH_BLOCK / 64, NPL = NPT > 0 ? NPT : 256;
+  __shared__ __attribute__((aligned(16))) u8 s_val[NW][TILE * 16];
+  __shared__ u32 s_dst[NW][TILE];
+  __shared__ u32 s_cur[NW][NPL];   // per part: position (in the column buffers) of this wavefront's next row of the part
+  __shared__ u32 s_tf[NW][NPL];    // per part: first position of the part inside the ordered tile
+  const int lane = qh_lane();
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32 unit = blockIdx.x * NW + (u32)wv;
+  if (unit >= A.n_units) return;
+  i64 nrows = (i64)A.nrows;
+  if (A.nrows_dev) { const i64 d = (i64)*A.nrows_dev; nrows = d < nrows ? d : nrows; }
+  const i64 first = (i64)unit * A.rows_per_unit;
+  const i64 last = first + A.rows_per_unit < nrows ? first + A.rows_per_unit : nrows;
+  if (first >= last) return;
+  const u32 np = A.n_parts;
+  for (u32 p = (u32)lane; p < np; p += 64) s_cur[wv][p] = A.runs[(size_t)p * A.n_units + unit];
+  u32 idn[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const i64 row = first + r * 64 + lane; idn[r] = row < last ? (u32)A.ids[row] : 0xFFu; }
+  for (i64 tb = first; tb < last; tb += TILE) {
+    u32 id[R], q[R], pos[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { id[r] = idn[r]; q[r] = 0; pos[r] = 0; }
+    if (tb + TILE < last) {   // the next tile's part bytes fly while this tile is ranked and moved
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const i64 row = tb + TILE + r * 64 + lane; idn[r] = row < last ? (u32)A.ids[row] : 0xFFu; }
+    }
+    u32 total = 0, my_cnt = 0;   // my_cnt: rows of part `lane` (NPT = 0: parts lane * 4 .. lane * 4 + 3 summed) in this tile
+    if (NPT > 0) {
+      u32 run[NPT > 0 ? NPT : 1];
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) run[p] = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const u64 m = qh_ballot(id[r] == (u32)p);
+          q[r] = id[r] == (u32)p ? run[p] + (u32)qh_rank(m) : q[r];
+          run[p] += (u32)__builtin_popcountll(m);
+        }
+      }
+      u32 my_tf = 0;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) { my_tf = lane == p ? total : my_tf; my_cnt = lane == p ? run[p] : my_cnt; total += run[p]; }
+      if (lane < NPT) s_tf[wv][lane] = my_tf;
+    } else {
+      for (u32 p = (u32)lane; p < np; p += 64) s_tf[wv][p] = 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        u64 todo = qh_ballot(id[r] != 0xFFu);
+        while (todo) {   // wave-uniform
+          const int l = __builtin_ctzll(todo);
+          const u32 p = qh_readlane32(id[r], l);
+          const u64 m = qh_ballot(id[r] == p);
+          const u32 base = s_tf[wv][p];
+          if (id[r] == p) q[r] = base + (u32)qh_rank(m);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == l) s_tf[wv][p] = base + (u32)__builtin_popcountll(m);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          todo &= ~m;
+        }
+      }
+      // counts -> first positions: lane l owns parts 4 l .. 4 l + 3
+      u32 c[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; c[k] = p < np ? s_tf[wv][p] : 0u; }
+      my_cnt = c[0] + c[1] + c[2] + c[3];
+      const u32 incl = wave_incl_scan_u32(my_cnt);
+      total = qh_readlane32(incl, 63);
+      u32 at = incl - my_cnt;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_tf[wv][p] = at; at += c[k]; }
+      // (the counts are needed again below, per part: keep them where s_cur is advanced)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (id[r] != 0xFFu) { pos[r] = s_tf[wv][id[r]] + q[r]; s_dst[wv][pos[r]] = s_cur[wv][id[r]] + q[r]; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_cur[wv][p] += c[k]; }
+    }
+    if (NPT > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (id[r] != 0xFFu) { pos[r] = s_tf[wv][id[r]] + q[r]; s_dst[wv][pos[r]] = s_cur[wv][id[r]] + q[r]; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < NPT) s_cur[wv][lane] += my_cnt;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (total) {   // wave-uniform
+      for (u32 cix = 0; cix < A.n_cols; ++cix) {
+        const PartCol col = A.cols[cix];
+        switch (col.width) {
+          case 1: qh_scatter_column<u8>(col, tb, last, lane, id, pos, total, s_val[wv], s_dst[wv]); break;
+          case 2: qh_scatter_column<u16>(col, tb, last, lane, id, pos, total, s_val[wv], s_dst[wv]); break;
+          case 4: qh_scatter_column<u32>(col, tb, last, lane, id, pos, total, s_val[wv], s_dst[wv]); break;
+          case 8: qh_scatter_column<u64>(col, tb, last, lane, id, pos, total, s_val[wv], s_dst[wv]); break;
+          default: qh_scatter_column<qh_v4u>(col, tb, last, lane, id, pos, total, s_val[wv], s_dst[wv]); break;
+        }
+      }
+    }
+  }
+}
+// out[k] = in[k * stride] (the parts' first positions out of the scanned histogram: what the host reads back)
+__global__ void k_gather_stride_u32(const u32* in, u32 stride, u32 n, u32* out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = in[(size_t)k * stride];
 }
 
 // ================================================================ aggregate output assembly on the device
@@ -1108,6 +1259,16 @@ void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const u
                               uint32_t* b_out, uint32_t* p_out, hipStream_t s) {
   if (np) hipLaunchKernelGGL(k_join_adjust_right, dim3(grid_for(np)), dim3(QH_BLOCK), 0, s, (const u32*)b_in, (const u32*)cnt, (const u32*)in_off,
                              (const u32*)out_off, (u64)np, (u32*)b_out, (u32*)p_out);
+}
+void launch_part_scatter(const PartScatterArgs& a, hipStream_t s) {
+  if (!a.n_units || !a.n_cols) return;
+  const dim3 g((a.n_units + QH_BLOCK / 64 - 1) / (QH_BLOCK / 64)), b(QH_BLOCK);
+  if (a.n_parts <= 8) hipLaunchKernelGGL(k_part_scatter<8>, g, b, 0, s, a);
+  else if (a.n_parts <= 16) hipLaunchKernelGGL(k_part_scatter<16>, g, b, 0, s, a);
+  else hipLaunchKernelGGL(k_part_scatter<0>, g, b, 0, s, a);
+}
+void launch_gather_stride_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_gather_stride_u32, dim3((n + 255) / 256), dim3(256), 0, s, (const u32*)in, stride, n, (u32*)out);
 }
 void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s) {
   if (!n) return;

@@ -122,6 +122,35 @@ int qhip_plan_scatter_source(const qhip_dtype* col_types, const int32_t* col_has
   } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
 }
 
+int qhip_plan_partition_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
+                               int32_t n_exprs, const int32_t* key_roots, int32_t n_keys, int32_t predicate_root, int32_t n_parts, char* buf,
+                               size_t buflen, size_t* needed) {
+  try {
+    auto in = make_input(col_types, col_has_nulls, n_cols);
+    // (like an execution: Utf8 key columns of the exchange always pack into 4 words)
+    for (int k = 0; k < n_keys; ++k)
+      if (key_roots[k] >= 0 && key_roots[k] < n_exprs && exprs[key_roots[k]].kind == QHIP_EXPR_COLUMN && exprs[key_roots[k]].column >= 0 &&
+          exprs[key_roots[k]].column < n_cols && in[(size_t)exprs[key_roots[k]].column].type.id == QHIP_UTF8)
+        in[(size_t)exprs[key_roots[k]].column].utf8_max_len = 31;
+    ExprSet es; es.build(exprs, n_exprs, in);
+    KeysPlan p;
+    plan_keys(es, in, key_roots, n_keys, p, predicate_root, KEYS_KERNEL_PARTITION, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0, n_parts);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
+int qhip_plan_part_scatter_source(const int32_t* widths, const int32_t* indirect, int32_t n_cols, int32_t n_parts, char* buf, size_t buflen,
+                                  size_t* needed) {
+  try {
+    std::vector<int> w(widths, widths + (n_cols > 0 ? n_cols : 0));
+    std::vector<char> ind;
+    for (int k = 0; k < n_cols; ++k) ind.push_back(indirect && indirect[k] ? 1 : 0);
+    PartScatterPlan p;
+    plan_part_scatter(w, ind, n_parts, env_int("QHIP_PLAN_DEV_ROWS", 0) != 0, p);
+    return give(p.source, buf, buflen, needed);
+  } catch (const Error& e) { g_plan_err = e.what(); return e.code; }
+}
+
 int qhip_plan_sort_keys_source(const qhip_dtype* col_types, const int32_t* col_has_nulls, int32_t n_cols, const qhip_expr* exprs,
                                int32_t n_exprs, const int32_t* key_roots, int32_t n_keys, char* buf, size_t buflen, size_t* needed) {
   try {

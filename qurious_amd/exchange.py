@@ -246,6 +246,22 @@ def partition_by_key(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts: 
     return [DeviceTable(ctx, C.c_void_p(outs[p])) for p in range(n_parts)]
 
 
+def partition_filtered(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts: int, predicate: Optional[PhysicalExpr] = None,
+                       keep: Optional[Sequence[bool]] = None) -> List[DeviceTable]:
+    """qhip_partition_filtered: the split by key hash fused with the join side's scan filter (`predicate`: rows it rejects are
+    in no part) and with the projection pushdown of the exchange (`keep`: only these columns are moved, the others become
+    NULL-typed placeholders) — two streaming passes over the columns involved, one host wait."""
+    ctx = table.ctx
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    proot = ea.lower(predicate) if predicate is not None else -1
+    arr, n = ea.c_array()
+    outs = (C.c_void_p * n_parts)()
+    keep_arr = None if keep is None else int32_array([1 if k else 0 for k in keep])
+    ctx.check(ctx.lib.qhip_partition_filtered(ctx.handle, table.handle, arr, n, int32_array(roots), len(roots), proot, keep_arr, n_parts, outs))
+    return [DeviceTable(ctx, C.c_void_p(outs[p])) for p in range(n_parts)]
+
+
 def concat_tables(tables: Sequence[DeviceTable]) -> DeviceTable:
     ctx = tables[0].ctx
     hs = (C.c_void_p * len(tables))(*[t.handle for t in tables])

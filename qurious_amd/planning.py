@@ -106,6 +106,29 @@ def scatter_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: O
     return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot))
 
 
+def partition_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], predicate: Optional[PhysicalExpr], n_parts: int,
+                     has_nulls: Optional[Sequence[bool]] = None) -> str:
+    """Source of pass 1 of the exchange's fused filter + partition (qhip_partition_filtered) for `n_parts` parts."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_partition_source
+    fn.restype = C.c_int
+    types, hn, n = _cols(schema, has_nulls)
+    ea = ExprArray()
+    roots = [ea.lower(k) for k in keys]
+    proot = ea.lower(predicate) if predicate is not None else -1
+    arr, ne = ea.c_array()
+    return _call(fn, types, hn, C.c_int32(n), arr, C.c_int32(ne), int32_array(roots), C.c_int32(len(roots)), C.c_int32(proot), C.c_int32(n_parts))
+
+
+def part_scatter_source(widths: Sequence[int], n_parts: int, indirect: Optional[Sequence[bool]] = None) -> str:
+    """Source of pass 2 of the exchange's fused filter + partition for one group of columns (bytes per value; 0 = row number)."""
+    lib = _ffi.load_library()
+    fn = lib.qhip_plan_part_scatter_source
+    fn.restype = C.c_int
+    n = len(widths)
+    return _call(fn, int32_array(list(widths)), int32_array([1 if (indirect and indirect[k]) else 0 for k in range(n)]), C.c_int32(n), C.c_int32(n_parts))
+
+
 def sort_keys_source(schema: pa.Schema, keys: Sequence[PhysicalExpr], has_nulls: Optional[Sequence[bool]] = None) -> str:
     """Source of the order-preserving key image kernel Sort launches (Utf8 keys have no generated part)."""
     lib = _ffi.load_library()

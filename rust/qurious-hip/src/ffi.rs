@@ -282,6 +282,18 @@ extern "C" {
         n_parts: i32,
         out_parts: *mut *mut qhip_table,
     ) -> c_int;
+    pub fn qhip_partition_filtered(
+        ctx: *mut qhip_ctx,
+        input: *const qhip_table,
+        exprs: *const qhip_expr,
+        n_exprs: i32,
+        key_roots: *const i32,
+        n_keys: i32,
+        predicate_root: i32,
+        keep_columns: *const i32,
+        n_parts: i32,
+        out_parts: *mut *mut qhip_table,
+    ) -> c_int;
     pub fn qhip_table_concat(ctx: *mut qhip_ctx, tables: *const *const qhip_table, n: i32, out: *mut *mut qhip_table) -> c_int;
     pub fn qhip_table_keep_columns(ctx: *mut qhip_ctx, t: *const qhip_table, keep: *const i32, n_cols: i32, out: *mut *mut qhip_table) -> c_int;
     pub fn qhip_table_stride_sample(ctx: *mut qhip_ctx, t: *const qhip_table, stride: i64, out: *mut *mut qhip_table) -> c_int;
