@@ -400,6 +400,29 @@ int qhip_exchange_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* const
 int qhip_all_gather_table(qhip_ctx* ctx, qhip_comm* comm, const qhip_table* t, const char* const* names,
                           const qhip_dtype* dtypes, int32_t n_cols, qhip_table** out);
 
+/* The whole exchange step of a distributed hash join in ONE call with ONE host wait (round 4): for every input — the two sides
+ * of a repartitioned join, or the build side of a broadcast join (all_gather != 0: every rank receives every kept row) — the
+ * scan filter and the key are evaluated and the rows counted per destination (pass 1 of qhip_partition_filtered), the counts
+ * of all inputs are all-gathered as device-resident metadata, the host waits ONCE (everybody's sizes), then the kept columns
+ * are moved into per-destination runs (pass 2) and sent with one group of ncclSend / ncclRecv per input STRAIGHT from those
+ * runs INTO the final columns of the result (no wire image, no pack / unpack copies). The transfers run on the
+ * communicator's own stream: input k's transfers overlap input k + 1's pass 2.
+ * An input may be a join output of deferred size (qhip_ctx_allow_deferred_sizes): whether such a join had too little room is
+ * part of the metadata, so that EVERY rank returns QHIP_RETRY together (and re-executes its input) — never one rank alone.
+ * Only tables whose kept columns are fixed-width without NULLs travel this way; QHIP_UNSUPPORTED (decided by column types,
+ * identically on every rank, before any collective) or — when NULLs turn up on some rank — an agreed QHIP_UNSUPPORTED after the
+ * metadata round tells the caller to take qhip_partition_filtered + qhip_exchange_tables instead.
+ * *outs[k]: one batch per source rank, columns as the input's (dropped columns QHIP_NULL). */
+typedef struct qhip_shuffle_input {
+  const qhip_table* table;
+  const qhip_expr* exprs; int32_t n_exprs;
+  const int32_t* key_roots; int32_t n_keys;     /* the join keys (also for all_gather: they are not hashed then) */
+  int32_t predicate_root;                        /* the side's scan filter or -1 */
+  int32_t all_gather;                            /* 0: row -> rank mix(key) (repartition); 1: every row to every rank (broadcast) */
+  const int32_t* keep_columns;                   /* per input column, NULL = all */
+} qhip_shuffle_input;
+int qhip_shuffle_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_shuffle_input* inputs, int32_t n_inputs, qhip_table** outs);
+
 /* ---------------------------------------------------------------- plan-only entry points (no GPU needed) */
 /* Return (snprintf-style; *needed = bytes incl. NUL) the policy source libqhip instantiates the kernel
  * templates of csrc/device/qhip_device.hpp with, for an input whose column c has type col_types[c] and

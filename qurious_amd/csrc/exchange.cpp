@@ -200,14 +200,13 @@ void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int
   launch_gather_stride_u32(w.runs.as<uint32_t>(), w.n_units, (uint32_t)n_parts + 1, w.starts.as<uint32_t>(), s);   // (entry n_parts = the scan's total)
 }
 
-// the parts' tables from the parts' first positions (host copy of PartitionWork::starts): pass 2 + the gathers of the odd columns
-void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, const uint32_t* starts,
-                     qhip_table** out_parts) {
+struct MovedColumn { size_t col; std::shared_ptr<DevBuf> out; int width; };   // a column's values of all parts, part after part
+// pass 2's launches: the plain kept columns into `moved` (one buffer each over all parts), the others listed in `odd` with the
+// parts' selection vector in `sel` (the caller gathers them per part)
+void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, uint64_t total,
+                       std::vector<MovedColumn>& moved, std::vector<size_t>& odd, std::shared_ptr<DevBuf>& sel) {
   hipStream_t s = ctx->stream;
-  const uint64_t total = starts[n_parts];
-  struct Moved { size_t col; std::shared_ptr<DevBuf> out; int width; };
-  std::vector<Moved> moved;
-  std::vector<size_t> odd;   // columns gathered per part through the selection vector
+  typedef MovedColumn Moved;
   // one generated kernel per group of columns (qh_part_scatter_body: the registers of two tiles' values bound the group: <= 48
   // bytes per row, <= 8 columns); the AOT kernel k_part_scatter (any shape, QHIP_PART_SCATTER_JIT=0) is the plan-independent form
   const bool jit = env_int("QHIP_PART_SCATTER_JIT", 1) != 0;
@@ -291,7 +290,6 @@ void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_
       moved.push_back(Moved{c, out, width});
     } else odd.push_back(c);
   }
-  std::shared_ptr<DevBuf> sel;
   if (!odd.empty()) {
     sel = std::make_shared<DevBuf>(((size_t)total + 1) * 4);
     push(nullptr, nullptr, sel->ptr, 4);   // (no source: the row number itself)
@@ -299,6 +297,16 @@ void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_
   flush();
   if (!marked) time_mark(ctx, 2);
   time_mark(ctx, 3);
+}
+
+// the parts' tables from the parts' first positions (host copy of PartitionWork::starts): pass 2 + the gathers of the odd columns
+void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, const uint32_t* starts,
+                     qhip_table** out_parts) {
+  typedef MovedColumn Moved;
+  std::vector<Moved> moved;
+  std::vector<size_t> odd;   // columns gathered per part through the selection vector
+  std::shared_ptr<DevBuf> sel;
+  partition_scatter(ctx, in, keep, n_parts, w, starts[n_parts], moved, odd, sel);
   for (int p = 0; p < n_parts; ++p) {
     std::unique_ptr<qhip_table> t(new qhip_table());
     t->ctx = ctx;
@@ -695,6 +703,10 @@ struct qhip_comm {
   qhip_comm_stats stats;
   hipEvent_t ev[2] = {nullptr, nullptr};
   bool timed = false;            // ev[0] .. ev[1] bracket the last exchange's transfers, not yet added to stats.seconds
+  // qhip_shuffle_tables: the transfers run on the communicator's own stream (behind `ready`, recorded on the context's stream
+  // when an input's runs are written; the context's stream waits for `done` before the results are used)
+  hipStream_t xstream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
 };
 
 namespace {
@@ -813,9 +825,192 @@ qhip_table* comm_exchange(Ctx* ctx, qhip_comm* c, const qhip_table* const* parts
   }
   return out;
 }
+// ---- qhip_shuffle_tables (include/qhip.h): the exchange step of a distributed join in one call, one host wait
+void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_in, qhip_table** outs) {
+  QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int W = c->world, me = c->rank;
+  if (W > 255) fail(QHIP_UNSUPPORTED, "qhip_shuffle_tables: more than 255 ranks");
+  const bool self_rccl = c->comm != nullptr && env_int("QHIP_COMM_SELF_RCCL", 0) != 0;
+  // ---- which columns travel, and may they? Decided by TYPES (identical on every rank) before anything collective happens.
+  struct Side {
+    const qhip_table* in; std::vector<int32_t> keep; int np; PartitionWork w;
+    std::vector<size_t> cols;          // the kept, non-NULL-typed columns
+    size_t meta_at = 0;                // first metadata word of the side: rows per part [np], then (known, min, max) per kept column
+    bool has_nulls = false;
+  };
+  std::vector<Side> sides((size_t)n_in);
+  size_t M = 1;   // word 0: flags (bit 0: a join of deferred size below must run again; bit 1: a kept column holds NULLs here)
+  for (int k = 0; k < n_in; ++k) {
+    Side& sd = sides[(size_t)k];
+    const qhip_shuffle_input& I = ins[k];
+    if (!I.table || !I.key_roots || I.n_keys <= 0) fail(QHIP_INVALID_ARGUMENT, "qhip_shuffle_tables: an input without table / keys");
+    sd.in = I.table;
+    sd.np = I.all_gather ? 1 : W;
+    sd.keep.assign(sd.in->cols.size(), 1);
+    if (I.keep_columns) for (size_t col = 0; col < sd.keep.size(); ++col) sd.keep[col] = I.keep_columns[col] ? 1 : 0;
+    if (sd.in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+    for (size_t col = 0; col < sd.in->cols.size(); ++col) {
+      if (!sd.keep[col] || sd.in->cols[col].type.id == QHIP_NULL) continue;
+      if (dtype_width(sd.in->cols[col].type) <= 0)
+        fail(QHIP_UNSUPPORTED, "qhip_shuffle_tables: only fixed-width columns travel this way (" + dtype_name(sd.in->cols[col].type) + ")");
+      sd.cols.push_back(col);
+    }
+    sd.meta_at = M;
+    M += (size_t)sd.np + 3 * sd.cols.size();
+  }
+  comm_settle_time(c, false);
+  // ---- pass 1 of every input; the device-side metadata row of this rank
+  DevBuf meta_dev(M * 8), all_dev(M * 8 * (size_t)W);
+  int64_t* const stage = (int64_t*)ctx->pinned;   // [my host-known words | everybody's rows]
+  if ((M * (size_t)(W + 1)) * 8 + 64 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "qhip_shuffle_tables: metadata of this many columns x ranks exceeds the read-back scratch");
+  memset(stage, 0, M * 8);
+  bool deferred_in = false;
+  for (int k = 0; k < n_in; ++k) {
+    Side& sd = sides[(size_t)k];
+    const qhip_shuffle_input& I = ins[k];
+    if (sd.in->rows_dev) deferred_in = true;
+    partition_pass1(ctx, sd.in, I.exprs, I.n_exprs, I.key_roots, I.n_keys, I.predicate_root, sd.np, sd.w);
+    // (NULLs in a kept column: known once the column is resolved — a deferred gather through a nullable index vector is made now)
+    for (size_t j = 0; j < sd.cols.size(); ++j) {
+      const DevColumn& c0 = sd.in->cols[sd.cols[j]];
+      const DevColumn& rc = indirect_eligible(c0) ? c0.deferred->src : resolved(ctx, c0);
+      if (rc.null_count > 0) sd.has_nulls = true;
+      const DevColumn& stat = c0.deferred && !c0.deferred->done ? c0.deferred->src : rc;
+      const bool known = stat.range && stat.range->known;
+      stage[sd.meta_at + (size_t)sd.np + 3 * j] = known ? 1 : 0;
+      stage[sd.meta_at + (size_t)sd.np + 3 * j + 1] = known ? stat.range->min : 0;
+      stage[sd.meta_at + (size_t)sd.np + 3 * j + 2] = known ? stat.range->max : 0;
+    }
+    if (sd.has_nulls) stage[0] |= 2;
+  }
+  QHIP_HIP_CHECK(hipMemcpyAsync(meta_dev.ptr, stage, M * 8, hipMemcpyHostToDevice, s));
+  for (int k = 0; k < n_in; ++k) launch_shuffle_meta(sides[(size_t)k].w.starts.as<uint32_t>(), (uint32_t)sides[(size_t)k].np, meta_dev.as<int64_t>() + sides[(size_t)k].meta_at, s);
+  if (!ctx->pending_sizes.empty()) {   // joins of deferred size in flight: their verdict becomes part of the metadata (see below)
+    PendingSlots ps;
+    memset(&ps, 0, sizeof ps);
+    for (const Ctx::PendingSize& p : ctx->pending_sizes) { if (ps.n >= 64) break; ps.slot[ps.n] = p.slot; ps.cap[ps.n] = p.capacity; ++ps.n; }
+    launch_pending_flags(ps, meta_dev.as<int64_t>(), s);   // (ORs bit 0 into word 0 behind the copy above)
+  }
+  int64_t* const all = stage + M;
+  if (W == 1 && !self_rccl) QHIP_HIP_CHECK(hipMemcpyAsync(all, meta_dev.ptr, M * 8, hipMemcpyDeviceToHost, s));
+  else {
+    rccl_check(rccl().AllGather(meta_dev.ptr, all_dev.ptr, M, QH_NCCL_INT64, c->comm, s), "ncclAllGather (shuffle metadata)");
+    QHIP_HIP_CHECK(hipMemcpyAsync(all, all_dev.ptr, M * 8 * (size_t)W, hipMemcpyDeviceToHost, s));
+  }
+  // pass 1's status words ride along (one block per input)
+  uint32_t* const st_back = (uint32_t*)(all + M * (size_t)W);
+  if ((M * (size_t)(W + 1)) * 8 + (size_t)n_in * QS_WORDS * 4 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "qhip_shuffle_tables: read-back scratch too small");
+  for (int k = 0; k < n_in; ++k) QHIP_HIP_CHECK(hipMemcpyAsync(st_back + (size_t)k * QS_WORDS, sides[(size_t)k].w.dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
+  QHIP_HIP_CHECK(sync_stream(s));   // THE host wait of the exchange
+  ++c->stats.host_waits;
+  // ---- agreed verdicts first: every rank sees every rank's flags
+  bool any_retry = false, any_nulls = false;
+  for (int r = 0; r < W; ++r) { any_retry |= (all[(size_t)r * M] & 1) != 0; any_nulls |= (all[(size_t)r * M] & 2) != 0; }
+  {
+    bool local_retry = false;
+    try { verify_pending_sizes(ctx); } catch (const Error& e) { if (e.code != QHIP_RETRY) throw; local_retry = true; }
+    if (local_retry && !any_retry) fail(QHIP_HIP_ERROR, "qhip_shuffle_tables: the device-side verdict on a join of deferred size differs from the host's (internal error)");
+    if (any_retry) fail(QHIP_RETRY, "a hash join of deferred size below the exchange has to run again on some rank: every rank re-executes its input");
+  }
+  (void)deferred_in;
+  for (int k = 0; k < n_in; ++k) check_status_words(st_back + (size_t)k * QS_WORDS);
+  if (any_nulls) fail(QHIP_UNSUPPORTED, "qhip_shuffle_tables: a kept column holds NULLs on some rank (take qhip_partition_filtered + qhip_exchange_tables)");
+  // ---- pass 2 of every input, and behind it (on the communicator's stream) its transfers: runs -> final columns
+  QHIP_HIP_CHECK(hipEventRecord(c->ev[0], s));
+  std::vector<std::shared_ptr<DevBuf>> keep_alive;   // send runs: read by the transfer stream until `done`
+  for (int k = 0; k < n_in; ++k) {
+    Side& sd = sides[(size_t)k];
+    const int64_t* mine = all + (size_t)me * M + sd.meta_at;
+    std::vector<uint32_t> starts((size_t)sd.np + 1, 0);
+    for (int p = 0; p < sd.np; ++p) starts[(size_t)p + 1] = starts[(size_t)p] + (uint32_t)mine[p];
+    std::vector<MovedColumn> moved;
+    std::vector<size_t> odd;
+    std::shared_ptr<DevBuf> sel;
+    partition_scatter(ctx, sd.in, sd.keep.data(), sd.np, sd.w, starts[(size_t)sd.np], moved, odd, sel);
+    if (!odd.empty()) fail(QHIP_HIP_ERROR, "qhip_shuffle_tables: a column needs a gather of its own (internal error)");
+    // rows every rank sends here, in rank order
+    std::vector<int64_t> from((size_t)W), at((size_t)W + 1, 0);
+    for (int r = 0; r < W; ++r) {
+      from[(size_t)r] = all[(size_t)r * M + sd.meta_at + (size_t)(ins[k].all_gather ? 0 : me)];
+      at[(size_t)r + 1] = at[(size_t)r] + from[(size_t)r];
+    }
+    const int64_t N = at[(size_t)W];
+    if (N >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
+    std::unique_ptr<qhip_table> t(new qhip_table());
+    t->ctx = ctx;
+    t->names = sd.in->names;
+    t->nullable = sd.in->nullable;
+    t->num_rows = N;
+    t->batch_offsets.push_back(0);
+    for (int r = 0; r < W; ++r) t->batch_offsets.push_back(at[(size_t)r + 1]);   // one batch per source rank
+    t->cols.resize(sd.in->cols.size());
+    for (size_t col = 0; col < sd.in->cols.size(); ++col) {
+      DevColumn& oc = t->cols[col];
+      oc.type = DType{QHIP_NULL, 0, 0}; oc.length = N; oc.null_count = N;
+      if (!sd.keep[col] || sd.in->cols[col].type.id == QHIP_NULL) t->nullable[col] = true;
+    }
+    QHIP_HIP_CHECK(hipEventRecord(c->ready, s));
+    QHIP_HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ready, 0));
+    const bool grouped = W > 1 || self_rccl;
+    if (grouped) rccl_check(rccl().GroupStart(), "ncclGroupStart");
+    for (size_t j = 0; j < moved.size(); ++j) {
+      const MovedColumn& mv = moved[j];
+      DevColumn& oc = t->cols[mv.col];
+      const DevColumn& src = sd.in->cols[mv.col];
+      oc.type = src.type; oc.null_count = 0; oc.length = N;
+      oc.value_maxabs = src.deferred ? src.deferred->src.value_maxabs : src.value_maxabs;
+      oc.values = std::make_shared<DevBuf>((size_t)N * (size_t)mv.width);
+      keep_alive.push_back(mv.out);
+      for (int r = 0; r < W; ++r) {
+        const int p = ins[k].all_gather ? 0 : r;   // the run that goes to rank r
+        const size_t out_bytes = (size_t)(starts[(size_t)p + 1] - starts[(size_t)p]) * (size_t)mv.width, in_bytes = (size_t)from[(size_t)r] * (size_t)mv.width;
+        const uint8_t* sp = mv.out->as<uint8_t>() + (size_t)starts[(size_t)p] * (size_t)mv.width;
+        uint8_t* dp = oc.values->as<uint8_t>() + (size_t)at[(size_t)r] * (size_t)mv.width;
+        if (r == me && !self_rccl) { if (in_bytes) QHIP_HIP_CHECK(hipMemcpyAsync(dp, sp, in_bytes, hipMemcpyDeviceToDevice, c->xstream)); continue; }
+        if (out_bytes) { rccl_check(rccl().Send(sp, out_bytes, QH_NCCL_UINT8, r, c->comm, c->xstream), "ncclSend"); c->stats.bytes_sent += out_bytes; }
+        if (in_bytes) { rccl_check(rccl().Recv(dp, in_bytes, QH_NCCL_UINT8, r, c->comm, c->xstream), "ncclRecv"); c->stats.bytes_received += in_bytes; }
+      }
+      c->stats.bytes_packed += (uint64_t)starts[(size_t)sd.np] * (uint64_t)mv.width;
+      // the union of the senders' value ranges (a rank without rows says nothing)
+      size_t jm = 0;
+      for (; jm < sd.cols.size(); ++jm) if (sd.cols[jm] == mv.col) break;
+      bool all_known = true, any = false;
+      int64_t lo = 0, hi = 0;
+      for (int r = 0; r < W && jm < sd.cols.size(); ++r) {
+        if (from[(size_t)r] == 0) continue;
+        const int64_t* m = all + (size_t)r * M + sd.meta_at + (size_t)sd.np + 3 * jm;
+        if (!m[0]) { all_known = false; break; }
+        lo = any ? std::min(lo, m[1]) : m[1];
+        hi = any ? std::max(hi, m[2]) : m[2];
+        any = true;
+      }
+      if (all_known && any) { oc.range = std::make_shared<ColRange>(); oc.range->known = true; oc.range->min = lo; oc.range->max = hi; oc.range_inherited = false; }
+    }
+    if (grouped) rccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    ++c->stats.exchanges;
+    outs[k] = t.release();
+  }
+  QHIP_HIP_CHECK(hipEventRecord(c->done, c->xstream));
+  QHIP_HIP_CHECK(hipStreamWaitEvent(s, c->done, 0));   // everything the caller does next is ordered behind the transfers
+  QHIP_HIP_CHECK(hipEventRecord(c->ev[1], s));
+  c->timed = true;
+  // (keep_alive goes back to the pool here: whoever gets those buffers next runs on the context's stream, behind `done`)
+}
 }  // namespace
 
 extern "C" {
+
+int qhip_shuffle_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_shuffle_input* inputs, int32_t n_inputs, qhip_table** outs) {
+  if (!ctx || !comm || !inputs || !outs || n_inputs <= 0 || n_inputs > 8 || comm->ctx != ctx) return QHIP_INVALID_ARGUMENT;
+  for (int k = 0; k < n_inputs; ++k) outs[k] = nullptr;
+  int rc = guarded(ctx, [&] { comm_shuffle(ctx, comm, inputs, n_inputs, outs); });
+  if (rc != QHIP_OK) {
+    if (rc == QHIP_RETRY) ctx->pending_sizes.clear();
+    for (int k = 0; k < n_inputs; ++k) { if (outs[k]) { delete outs[k]; outs[k] = nullptr; } }
+  }
+  return rc;
+}
 
 int qhip_comm_unique_id(void* id_out, size_t id_bytes) {
   if (!id_out || id_bytes < 128) return QHIP_INVALID_ARGUMENT;
@@ -835,6 +1030,9 @@ int qhip_comm_create(qhip_ctx* ctx, const void* unique_id, int32_t rank, int32_t
     c->ctx = ctx; c->rank = rank; c->world = world;
     memset(&c->stats, 0, sizeof c->stats);
     for (auto& e : c->ev) QHIP_HIP_CHECK(hipEventCreate(&e));
+    QHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    QHIP_HIP_CHECK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    QHIP_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     if (world > 1 || env_int("QHIP_COMM_FORCE_RCCL", 0) != 0) {
       // (QHIP_COMM_FORCE_RCCL=1: a ONE-rank communicator is a real RCCL communicator too — the one-GPU rehearsal of the init path)
       qh_nccl_unique_id id;
@@ -851,8 +1049,12 @@ int qhip_comm_create(qhip_ctx* ctx, const void* unique_id, int32_t rank, int32_t
 void qhip_comm_destroy(qhip_comm* c) {
   if (!c) return;
   if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   if (c->comm) (void)rccl().CommDestroy(c->comm);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  if (c->done) (void)hipEventDestroy(c->done);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
   delete c;
 }
 

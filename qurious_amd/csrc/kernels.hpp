@@ -94,6 +94,9 @@ struct PartScatterArgs {
   PartCol cols[kPartCols];
 };
 void launch_part_scatter(const PartScatterArgs& a, hipStream_t s);
+struct PendingSlots { const uint32_t* slot[64]; uint64_t cap[64]; uint32_t n; uint32_t pad_; };   // (kSizeSlots joins of deferred size in flight at most)
+void launch_shuffle_meta(const uint32_t* starts, uint32_t n_parts, int64_t* rows_out, hipStream_t s);
+void launch_pending_flags(const PendingSlots& p, int64_t* flag, hipStream_t s);
 void launch_gather_stride_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out, hipStream_t s);
 void launch_partition_ids(int W, const uint64_t* keys, uint64_t n, uint32_t nparts, uint32_t* part, uint32_t* hist, hipStream_t s);
 void stable_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint64_t n, int bits,

@@ -965,6 +965,22 @@ __global__ __launch_bounds__(QH_BLOCK) void k_part_scatter(PartScatterArgs A) {
     }
   }
 }
+// the exchange's metadata words that only the DEVICE knows when the collective starts (qhip_shuffle_tables): rows per part from
+// the parts' first positions, and whether a hash join of deferred size below (its status block in a page-locked slot the device
+// can read) met duplicate build keys / had too little room — a flag every rank will see and act on together
+__global__ void k_shuffle_meta(const u32* starts, u32 n_parts, long long* rows_out) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_parts) rows_out[k] = (long long)(starts[k + 1] - starts[k]);
+}
+__global__ void k_pending_flags(PendingSlots P, long long* flag) {
+  if (blockIdx.x || threadIdx.x) return;
+  long long f = 0;
+  for (u32 k = 0; k < P.n; ++k) {
+    const volatile u32* sl = (const volatile u32*)P.slot[k];
+    if (sl[QS_MAXCOUNT] > 1u || sl[QS_OVERFLOW] || (u64)sl[2 * QS_WORDS] > P.cap[k]) f = 1;
+  }
+  *flag |= f;   // (bit 0 of the metadata row's flag word; the host-known bits were copied in ahead of this launch)
+}
 // out[k] = in[k * stride] (the parts' first positions out of the scanned histogram: what the host reads back)
 __global__ void k_gather_stride_u32(const u32* in, u32 stride, u32 n, u32* out) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1266,6 +1282,12 @@ void launch_part_scatter(const PartScatterArgs& a, hipStream_t s) {
   if (a.n_parts <= 8) hipLaunchKernelGGL(k_part_scatter<8>, g, b, 0, s, a);
   else if (a.n_parts <= 16) hipLaunchKernelGGL(k_part_scatter<16>, g, b, 0, s, a);
   else hipLaunchKernelGGL(k_part_scatter<0>, g, b, 0, s, a);
+}
+void launch_shuffle_meta(const uint32_t* starts, uint32_t n_parts, int64_t* rows_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_shuffle_meta, dim3((n_parts + 255) / 256), dim3(256), 0, s, (const u32*)starts, n_parts, (long long*)rows_out);
+}
+void launch_pending_flags(const PendingSlots& p, int64_t* flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_pending_flags, dim3(1), dim3(64), 0, s, p, (long long*)flag);
 }
 void launch_gather_stride_u32(const uint32_t* in, uint32_t stride, uint32_t n, uint32_t* out, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_gather_stride_u32, dim3((n + 255) / 256), dim3(256), 0, s, (const u32*)in, stride, n, (u32*)out);

@@ -24,7 +24,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 from . import _ffi
 from ._ffi import DeviceTable, get_context
@@ -260,6 +260,65 @@ def partition_filtered(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts
     keep_arr = None if keep is None else int32_array([1 if k else 0 for k in keep])
     ctx.check(ctx.lib.qhip_partition_filtered(ctx.handle, table.handle, arr, n, int32_array(roots), len(roots), proot, keep_arr, n_parts, outs))
     return [DeviceTable(ctx, C.c_void_p(outs[p])) for p in range(n_parts)]
+
+
+class qhip_shuffle_input(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("exprs", C.POINTER(_ffi.qhip_expr)), ("n_exprs", C.c_int32), ("key_roots", C.POINTER(C.c_int32)),
+                ("n_keys", C.c_int32), ("predicate_root", C.c_int32), ("all_gather", C.c_int32), ("keep_columns", C.POINTER(C.c_int32))]
+
+
+def shuffle_tables(inputs) -> List[DeviceTable]:
+    """qhip_shuffle_tables: the exchange step of a distributed join in ONE call with ONE host wait. `inputs`: tuples (device
+    table, key expressions, scan filter or None, keep mask or None, all_gather) — the two sides of a repartitioned join, or
+    the build side of a broadcast join. Raises UnsupportedError (on every rank alike) when a column cannot travel this way."""
+    ctx = inputs[0][0].ctx
+    lib = ctx.lib
+    lib.qhip_shuffle_tables.restype = C.c_int
+    lib.qhip_shuffle_tables.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(qhip_shuffle_input), C.c_int32, C.POINTER(C.c_void_p)]
+    arr = (qhip_shuffle_input * len(inputs))()
+    hold = []
+    for k, (table, keys, predicate, keep, all_gather) in enumerate(inputs):
+        ea = ExprArray()
+        roots = [ea.lower(e) for e in keys]
+        proot = ea.lower(predicate) if predicate is not None else -1
+        exprs, n = ea.c_array()
+        roots_c = int32_array(roots)
+        keep_c = None if keep is None else int32_array([1 if v else 0 for v in keep])
+        hold.append((ea, exprs, roots_c, keep_c))
+        arr[k].table = table.handle
+        arr[k].exprs = exprs
+        arr[k].n_exprs = n
+        arr[k].key_roots = roots_c
+        arr[k].n_keys = len(roots)
+        arr[k].predicate_root = proot
+        arr[k].all_gather = 1 if all_gather else 0
+        arr[k].keep_columns = keep_c
+    outs = (C.c_void_p * len(inputs))()
+    ctx.check(lib.qhip_shuffle_tables(ctx.handle, get_comm(ctx), arr, len(inputs), outs))
+    return [DeviceTable(ctx, C.c_void_p(outs[k])) for k in range(len(inputs))]
+
+
+def _fast_exchange() -> bool:
+    """the one-call exchange (qhip_shuffle_tables) needs libqhip's own communicator; QHIP_EXCHANGE_FAST=0 switches it off"""
+    return transport() == "rccl" and os.environ.get("QHIP_EXCHANGE_FAST", "1") != "0"
+
+
+def _is_table_access(node) -> bool:
+    from .plan import Scan
+    return isinstance(node, Scan) and node.projections is None
+
+
+def _side_for_exchange(node: PhysicalPlan, may_defer: bool):
+    """(device table, scan filter or None) of a join side that goes into an exchange: a Scan's filter is handed to the exchange
+    (evaluated in its first pass: the filtered batches are never materialised — valid for every join type, the rows are
+    dropped BEFORE the join); any other node is executed, with a hash join at its top allowed to leave its size on the
+    device when `may_defer` (the exchange reads it there, and every rank learns whether any rank must run it again)."""
+    from .plan import _feeding
+    if _is_table_access(node):
+        return node.datasource.device_table(), node.filter
+    if may_defer:
+        return _feeding(get_context(), node), None
+    return node.execute_device(), None
 
 
 def concat_tables(tables: Sequence[DeviceTable]) -> DeviceTable:
@@ -537,13 +596,63 @@ class DistributedHashJoinExec(HashJoinExec):
         return bool(_exchange_world(_dist()))
 
     def execute_device(self) -> DeviceTable:
+        from .plan import _retrying, exchange_cache
         world = _exchange_world(_dist())
         if not world:
             return HashJoinExec.execute_device(self)
-        with get_context().no_deferred_sizes():   # (a QHIP_RETRY on one rank would repeat collectives alone)
+        ctx = get_context()
+
+        def once():
+            # what this operator received earlier in the SAME execution of the plan (a local retry above it): no collective again
+            got = exchange_cache(ctx).get(id(self))
+            if got is None:
+                got = self._exchange_inputs(world)
+                exchange_cache(ctx)[id(self)] = got
+            return self._join_tables(*got)
+        return _retrying(ctx, once)
+
+    def _heavy_keys_now(self, world, rs, rw):
+        """the join's heavy probe keys (cached; sampled on the probe side's base table every HEAVY_REFRESH executions), or None
+        when heavy-hitter handling does not apply to this join"""
+        if len(self.on) != 1 or self.join_type not in (JoinType.Inner, JoinType.Right) or os.environ.get("QHIP_EXCHANGE_NO_HEAVY") == "1":
+            return None
+        rkey = self.on[0][1]
+        rdtype = _expr_type(rkey, rs)
+        if rdtype is None or not _is_table_access(self.right):
+            return None
+        cached = getattr(self, "_heavy_cache", None)
+        if cached is not None and cached[0] == world and cached[2] > 0 and os.environ.get("QHIP_EXCHANGE_NO_HEAVY_CACHE") != "1":
+            self._heavy_cache = (world, cached[1], cached[2] - 1)
+            return cached[1]
+        # (sampled on the UNFILTERED table: a heavy key of the table is what matters for balance; a stale or approximate set
+        # costs balance, never correctness)
+        top, n_sample = _local_top_keys(self.right.datasource.device_table(), rs, rkey, rdtype)
+        keys = heavy_keys(top, n_sample)
+        self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
+        return keys
+
+    def _exchange_inputs(self, world):
+        """(build table, probe table) of the local join: both sides repartitioned by key hash"""
+        ls, rs = self.left.schema(), self.right.schema()
+        lneed, rneed = self._needed_per_side()
+        if _fast_exchange():
+            heavy = self._heavy_keys_now(world, rs, _wire_schema(rs, rneed))
+            if not heavy:
+                # ONE call, ONE host wait for both sides; the build side may be a join of deferred size when nothing executes
+                # between it and the exchange (the probe side is a table access)
+                try:
+                    lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
+                    rt, rpred = _side_for_exchange(self.right, False)
+                    got = shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), False),
+                                          (rt, [r for _, r in self.on], rpred, _keep_mask(len(rs), rneed), False)])
+                    _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + got[1].num_rows
+                    return got[0], got[1]
+                except _ffi.UnsupportedError:
+                    pass   # (a column kind the fast path does not move — every rank decides alike: the generic path below)
+        with get_context().no_deferred_sizes():   # (the generic path settles its inputs one by one: no sizes left on the device)
             return self._execute_exchanged(world)
 
-    def _execute_exchanged(self, world) -> DeviceTable:
+    def _execute_exchanged(self, world):
         ls, rs = self.left.schema(), self.right.schema()
         lneed, rneed = self._needed_per_side()
         # columns nothing above this join reads are dropped BEFORE the partitioning: never gathered, never sent
@@ -575,12 +684,12 @@ class DistributedHashJoinExec(HashJoinExec):
                     heavy_l, left = all_gather_device_table(_filter_device(left, hl, None), lw), _filter_device(left, ll, None)
                     heavy_r, right = _filter_device(right, hr, None), _filter_device(right, lr, None)
                     _STATS["heavy_keys"] = _STATS.get("heavy_keys", 0) + len(keys)
-        lt = exchange_device_tables(partition_by_key(left, [l for l, _ in self.on], world), lw)
-        rt = exchange_device_tables(partition_by_key(right, [r for _, r in self.on], world), rw)
+        lt = exchange_device_tables(partition_filtered(left, [l for l, _ in self.on], world), lw)
+        rt = exchange_device_tables(partition_filtered(right, [r for _, r in self.on], world), rw)
         _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + rt.num_rows + (heavy_r.num_rows if heavy_r is not None else 0)
         if heavy_l is not None:
             lt, rt = concat_tables([lt, heavy_l]), concat_tables([rt, heavy_r])
-        return self._join_tables(lt, rt)
+        return lt, rt
 
     @staticmethod
     def try_new(left, right, join_type, on, filter=None) -> "DistributedHashJoinExec":
@@ -617,18 +726,40 @@ class BroadcastHashJoinExec(HashJoinExec):
     _exchanges = DistributedHashJoinExec._exchanges
 
     def execute_device(self) -> DeviceTable:
-        if not _exchange_world(_dist()):
+        from .plan import _retrying, exchange_cache
+        world = _exchange_world(_dist())
+        if not world:
             return HashJoinExec.execute_device(self)
         if self.join_type not in (JoinType.Inner, JoinType.Right):
             return DistributedHashJoinExec.execute_device(self)
-        with get_context().no_deferred_sizes():   # (a QHIP_RETRY on one rank would repeat collectives alone)
-            ls = self.left.schema()
-            lneed, _ = self._needed_per_side()
-            build = all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
+        ctx = get_context()
+
+        def once():
+            build = exchange_cache(ctx).get(id(self))
+            if build is None:
+                build = self._gather_build()
+                exchange_cache(ctx)[id(self)] = build
             probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
             return self._join_tables(build, probe, None, rpred)
+        return _retrying(ctx, once)
 
-    _repartitioned = DistributedHashJoinExec.execute_device
+    def _gather_build(self) -> DeviceTable:
+        """every rank's build rows on every rank: ONE call, ONE host wait, the build side's scan filter evaluated in its first
+        pass and a build side that is a join of deferred size read as it is (qhip_shuffle_tables, all_gather)"""
+        ls = self.left.schema()
+        lneed, _ = self._needed_per_side()
+        if _fast_exchange():
+            try:
+                lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
+                return shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), True)])[0]
+            except _ffi.UnsupportedError:
+                pass
+        with get_context().no_deferred_sizes():
+            return all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
+
+    _exchange_inputs = DistributedHashJoinExec._exchange_inputs
+    _execute_exchanged = DistributedHashJoinExec._execute_exchanged
+    _heavy_keys_now = DistributedHashJoinExec._heavy_keys_now
 
     @staticmethod
     def try_new(left, right, join_type, on, filter=None) -> "BroadcastHashJoinExec":
@@ -680,16 +811,31 @@ class DistributedHashAggregate(PhysicalPlan):
     def execute_device(self) -> DeviceTable:
         from .expr import Column
         from .plan import HashAggregate
+        from .plan import _retrying, exchange_cache
         world = _exchange_world(_dist())
-        part = self.partial.execute_device()
         if not world:
-            return part
+            return self.partial.execute_device()
         ng = len(self.group_exprs)
         pschema = self._schema if self._schema is not None else None
         keys = [Column(f"g{k}", k) for k in range(ng)]
         if pschema is None:
             raise _ffi.InternalError(_ffi.QHIP_INVALID_ARGUMENT, "DistributedHashAggregate needs its output schema (the partials travel)")
-        mine = exchange_device_tables(partition_by_key(part, keys, world), pschema)
-        merge = HashAggregate(pschema, DeviceSource(pschema, mine), keys, merge_aggregate_exprs(self.aggregate_exprs, ng))
-        return merge.execute_device()
+        ctx = get_context()
+
+        def once():
+            mine = exchange_cache(ctx).get(id(self))
+            if mine is None:
+                part = self.partial.execute_device()
+                mine = None
+                if _fast_exchange():
+                    try:
+                        mine = shuffle_tables([(part, keys, None, None, False)])[0]
+                    except _ffi.UnsupportedError:
+                        mine = None   # (string group keys, NULLs among the partials: the generic path)
+                if mine is None:
+                    mine = exchange_device_tables(partition_filtered(part, keys, world), pschema)
+                exchange_cache(ctx)[id(self)] = mine
+            merge = HashAggregate(pschema, DeviceSource(pschema, mine), keys, merge_aggregate_exprs(self.aggregate_exprs, ng))
+            return merge.execute_device()
+        return _retrying(ctx, once)
 

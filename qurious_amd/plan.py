@@ -10,6 +10,7 @@ batches stay in HBM (``execute_device``) and only the root's result is downloade
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import pyarrow as pa
@@ -63,6 +64,7 @@ class MemoryTable:
         self.data = list(data)
         self.lazy_upload = lazy_upload   # True: a column moves to HBM when a query first reads it (file-backed tables)
         self._device: Optional[DeviceTable] = None
+        self._device_of: Optional[tuple] = None   # the batch objects the device copy was made from (held: ids cannot be reused)
 
     @staticmethod
     def try_new(schema: pa.Schema, data: Sequence[pa.RecordBatch]) -> "MemoryTable":
@@ -72,10 +74,32 @@ class MemoryTable:
         return self._schema
 
     def device_table(self) -> DeviceTable:
-        """Batches pinned in HBM (uploaded once; the reference keeps them in host memory behind an RwLock)."""
-        if self._device is None:
+        """Batches pinned in HBM (the reference keeps them in host memory behind an RwLock): uploaded once — and again when
+        `data` no longer holds the very batches the copy was made from. MemoryTable::insert appends and ::delete rewrites /
+        clears the batch list (memory.rs:104-137), so neither the table's identity nor its batch and row counts tell
+        whether the data changed; the batch OBJECTS do (immutable, compared by identity, kept alive by the cache entry).
+        The same rule as the Rust shim's HipContext::table_of (INTEGRATION.md §5)."""
+        now = tuple(self.data)
+        same = self._device_of is not None and len(now) == len(self._device_of) and all(a is b for a, b in zip(now, self._device_of))
+        if self._device is None or not same:
             self._device = DeviceTable.from_batches(get_context(), self._schema, self.data, lazy=self.lazy_upload)
+            self._device_of = now
         return self._device
+
+    def insert(self, batches: Sequence[pa.RecordBatch]) -> int:
+        """MemoryTable::insert (memory.rs:104-111): appends; returns the reference's (quirky) 0 affected rows"""
+        self.data.extend(batches)
+        return 0
+
+    def delete(self, predicate_mask_of=None) -> int:
+        """MemoryTable::delete (memory.rs:113-137): no filter clears the table; a filter (here: batch -> boolean keep mask
+        of the rows that STAY, the host's business) rewrites every batch"""
+        before = sum(b.num_rows for b in self.data)
+        if predicate_mask_of is None:
+            self.data = []
+        else:
+            self.data = [b.filter(predicate_mask_of(b)) for b in self.data]
+        return before - sum(b.num_rows for b in self.data)
 
     def scan(self, projection: Optional[List[str]], filters: Optional[PhysicalExpr]) -> List[pa.RecordBatch]:
         """TableProvider::scan (memory.rs:69-98)."""
@@ -119,11 +143,13 @@ class Scan(PhysicalPlan):
 
 def _feeding(ctx, node: "PhysicalPlan") -> DeviceTable:
     """Execute `node` as the input of an operator that reads a device-side row count (HashAggregate's input, a hash
-    join's build side): a hash join at the top of `node` may then skip the wait for its output size
-    (qhip.h: qhip_ctx_allow_deferred_sizes). The consumer runs right after, inside `_retrying`."""
-    if _subtree_exchanges(node):
-        # a join of deferred size can answer QHIP_RETRY on ONE rank only; re-executing `node` would then repeat the
-        # collectives of the exchange operator inside it alone, and the job would hang: such a subtree never defers
+    join's build side, an exchange): a hash join at the top of `node` may then skip the wait for its output size
+    (qhip.h: qhip_ctx_allow_deferred_sizes). The consumer runs right after, inside `_retrying`.
+    A subtree with exchange operators may defer too (round 4): a QHIP_RETRY on ONE rank re-executes `node`, but an exchange
+    operator inside it hands back what it received in this execution (`exchange_cache`) instead of repeating its
+    collectives, which the other ranks would not take part in — only local operators run again. (QHIP_EXCHANGE_NO_DEFER=1:
+    the round-3 rule — such a subtree never defers.)"""
+    if _subtree_exchanges(node) and os.environ.get("QHIP_EXCHANGE_NO_DEFER") == "1":
         with ctx.no_deferred_sizes():
             return node.execute_device()
     ctx.allow_deferred_sizes(+1)
@@ -145,16 +171,35 @@ def _subtree_exchanges(node) -> bool:
 
 def _retrying(ctx, run):
     """run() = execute the input(s), then the operator. QHIP_RETRY from the operator: a join of deferred size below had
-    too little room; it has forgotten its hint, so the second run waits for the size."""
-    for attempt in range(3):
-        try:
-            return run()
-        except _ffi.RetryInput:
-            if attempt == 2:
+    too little room; it has forgotten its hint, so the second run waits for the size.
+    The outermost call brackets one EXECUTION of a plan: what the exchange operators below received during it stays in
+    `exchange_cache(ctx)` until it ends, so that a re-run of their subtree repeats no collective."""
+    depth = getattr(ctx, "_retry_depth", 0)
+    ctx._retry_depth = depth + 1
+    try:
+        for attempt in range(3):
+            try:
+                return run()
+            except _ffi.RetryInput:
+                if attempt == 2:
+                    raise
+            except Exception:
+                ctx.allow_deferred_sizes(0)   # reset: nothing of deferred size is left in flight after an error
                 raise
-        except Exception:
-            ctx.allow_deferred_sizes(0)   # reset: nothing of deferred size is left in flight after an error
-            raise
+    finally:
+        ctx._retry_depth = depth
+        if depth == 0:
+            exchange_cache(ctx).clear()
+
+
+def exchange_cache(ctx) -> dict:
+    """{id(exchange operator): what it received} for the plan execution in progress (cleared when the outermost
+    `_retrying` returns): the tables an exchange delivered are a function of the query's inputs, so an operator that is
+    executed again inside the same execution — a local retry after QHIP_RETRY — reuses them."""
+    cache = getattr(ctx, "_exchange_cache", None)
+    if cache is None:
+        cache = ctx._exchange_cache = {}
+    return cache
 
 
 # Instrumented executions (bench.py's per-kernel roofline records): while a list is installed here every device operator

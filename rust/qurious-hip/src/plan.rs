@@ -27,9 +27,28 @@ use crate::lower::{ExprArray, HipError, HipResult};
 pub struct HipContext {
     raw: *mut qhip_ctx,
     lock: Mutex<()>,
-    /// device copies of scanned tables, keyed by (provider address, batches, rows): a table is uploaded once, like
-    /// `MemoryTable` keeps its batches in host memory (datasource/memory.rs:20-35)
-    tables: Mutex<HashMap<(usize, usize, usize), Arc<DeviceTable>>>,
+    /// device copies of scanned tables: a table is uploaded once, like `MemoryTable` keeps its batches in host memory
+    /// (datasource/memory.rs:20-35) — and again whenever its DATA changes. `MemoryTable::insert` appends batches and
+    /// `delete` rewrites or clears them (datasource/memory.rs:104-137), so a provider's address, batch count and row count
+    /// can all stay the same over different data (DELETE everything, INSERT as many rows): the entry therefore remembers the
+    /// batches it was made from and is valid only while the provider hands out the SAME arrays (`Arc::ptr_eq` on every
+    /// column of every batch — the stored batches are immutable `Arc`s, and `scan` clones those `Arc`s); holding them keeps
+    /// their addresses from being reused, and the `Weak` tells a dead provider from a new one at the same address.
+    tables: Mutex<HashMap<usize, CachedTable>>,
+}
+struct CachedTable {
+    provider: std::sync::Weak<dyn TableProvider>,
+    batches: Vec<RecordBatch>,
+    table: Arc<DeviceTable>,
+}
+/// the same stored data: as many batches, every batch the same rows and the very same column arrays
+fn same_batches(a: &[RecordBatch], b: &[RecordBatch]) -> bool {
+    a.len() == b.len()
+        && a.iter().zip(b).all(|(x, y)| {
+            x.num_rows() == y.num_rows()
+                && x.num_columns() == y.num_columns()
+                && x.columns().iter().zip(y.columns()).all(|(p, q)| Arc::ptr_eq(p, q))
+        })
 }
 unsafe impl Send for HipContext {}
 unsafe impl Sync for HipContext {}
@@ -85,16 +104,24 @@ impl HipContext {
         self.check(unsafe { qhip_table_from_arrow(self.raw, &ffi_schema, ptrs.as_ptr(), ptrs.len() as i64, &mut out) })?;
         Ok(Arc::new(DeviceTable { ctx: self.clone(), raw: out }))
     }
-    /// the device copy of a provider's batches (uploaded on first use)
+    /// the device copy of a provider's batches: uploaded on first use and whenever the provider's data is no longer what the
+    /// copy was made from (INSERT / DELETE / a new provider at a freed one's address) — see `tables`
     pub fn table_of(self: &Arc<Self>, source: &Arc<dyn TableProvider>) -> HipResult<Arc<DeviceTable>> {
         let batches = source.scan(None, None)?;
-        let rows: usize = batches.iter().map(|b| b.num_rows()).sum();
-        let key = (Arc::as_ptr(source) as *const () as usize, batches.len(), rows);
-        if let Some(t) = self.tables.lock().unwrap().get(&key) {
-            return Ok(t.clone());
+        let key = Arc::as_ptr(source) as *const () as usize;
+        {
+            let mut tables = self.tables.lock().unwrap();
+            tables.retain(|_, e| e.provider.strong_count() > 0);   // dropped providers give their device tables back
+            if let Some(e) = tables.get(&key) {
+                let alive = e.provider.upgrade().map_or(false, |p| Arc::ptr_eq(&p, source));
+                if alive && same_batches(&e.batches, &batches) {
+                    return Ok(e.table.clone());
+                }
+            }
         }
         let t = self.upload(&source.schema(), &batches)?;
-        self.tables.lock().unwrap().insert(key, t.clone());
+        let entry = CachedTable { provider: Arc::downgrade(source), batches, table: t.clone() };
+        self.tables.lock().unwrap().insert(key, entry);
         Ok(t)
     }
     /// +1 around the execution of a child whose table goes straight into an aggregate / a join's build side: a hash join at

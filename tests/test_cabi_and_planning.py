@@ -243,12 +243,14 @@ def test_retry_protocol_of_the_host_mirror():
         _ffi._raise(_ffi.QHIP_RETRY, "x")
 
 
-def test_no_deferred_join_sizes_above_an_exchange_operator():
-    """A local operator ABOVE a multi-rank join must not run joins of deferred size: QHIP_RETRY can fire on one rank only,
-    whose re-execution of the input would repeat the exchange's collectives alone (round-2 advisor finding). `_feeding`
-    therefore runs a subtree that holds an active exchange operator under `no_deferred_sizes`, at any depth, and also
-    through nodes whose `children()` hide their input like the reference's (Sort / Limit)."""
+def test_a_retry_above_an_exchange_operator_never_repeats_its_collectives(monkeypatch):
+    """QHIP_RETRY can fire on ONE rank only (its join of deferred size had too little room); re-executing the consumer's
+    input must then not repeat the collectives of an exchange operator inside it, which the other ranks would not take part
+    in (round-2 advisor finding). Round 3 forbade deferral above an exchange; round 4 keeps what an exchange operator received
+    for the duration of one plan execution (`exchange_cache`, cleared when the outermost `_retrying` returns), so the
+    re-run takes it from there — and `_feeding` may defer through such a subtree. QHIP_EXCHANGE_NO_DEFER=1 is the old rule."""
     import contextlib
+    from qurious_amd import _ffi
     from qurious_amd import plan as P
 
     class Ctx:
@@ -293,7 +295,39 @@ def test_no_deferred_join_sizes_above_an_exchange_operator():
     assert seen == [1] and ctx.suppressed == 0 and ctx.depth == 0          # a purely local subtree may defer
     ctx.depth = 1                                                          # (an outer consumer already allowed deferral)
     P._feeding(ctx, Through(Through(Leaf(True))))
-    assert seen == [1, 0] and ctx.suppressed == 1 and ctx.depth == 1       # ... one with an exchange inside never does
+    assert seen == [1, 2] and ctx.suppressed == 0 and ctx.depth == 1       # ... and so may one with an exchange inside
+    monkeypatch.setenv("QHIP_EXCHANGE_NO_DEFER", "1")
+    P._feeding(ctx, Through(Through(Leaf(True))))
+    assert seen == [1, 2, 0] and ctx.suppressed == 1 and ctx.depth == 1    # the round-3 rule, on request
+    monkeypatch.delenv("QHIP_EXCHANGE_NO_DEFER")
+
+    # what makes that safe: an exchange operator runs its collectives ONCE per plan execution, whatever re-runs above it
+    collectives = []
+
+    class Exchange(P.PhysicalPlan):
+        _exchanges = True
+
+        def execute_device(self):
+            def once():
+                got = P.exchange_cache(ctx).get(id(self))
+                if got is None:
+                    collectives.append("all-to-all")
+                    got = P.exchange_cache(ctx)[id(self)] = "received"
+                return got
+            return P._retrying(ctx, once)
+
+    ex, attempts = Exchange(), []
+
+    def consumer():
+        attempts.append(ex.execute_device())
+        if len(attempts) < 3:
+            raise _ffi.RetryInput(_ffi.QHIP_RETRY, "one rank's join had too little room")
+        return "done"
+
+    assert P._retrying(ctx, consumer) == "done"
+    assert attempts == ["received"] * 3 and collectives == ["all-to-all"]          # two local retries, one collective
+    assert P.exchange_cache(ctx) == {}                                              # ... and nothing outlives the execution
+    assert P._retrying(ctx, lambda: ex.execute_device()) == "received" and collectives == ["all-to-all"] * 2   # the next one exchanges again
     # the product's multi-rank operators carry the mark exactly while an exchange would really run
     from qurious_amd import exchange as X
     for cls in (X.DistributedHashJoinExec, X.BroadcastHashJoinExec, X.DistributedHashAggregate):

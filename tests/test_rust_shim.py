@@ -194,3 +194,51 @@ def test_the_crate_is_complete():
     declared = set(_rust_functions(_rust("ffi.rs")))
     for called in set(re.findall(r"\b(qhip_[a-z0-9_]+)\s*\(", plan)):
         assert called in declared, called
+
+
+def test_the_table_cache_is_keyed_on_the_identity_of_the_data():
+    """`(provider address, batches, rows)` is the same key after DELETE-all + INSERT of the same shape
+    (datasource/memory.rs:104-137) or for a new provider at a freed address — the HIP path would answer from the old table.
+    The entry must be validated against the provider's liveness and the very arrays it was uploaded from."""
+    src = _rust("plan.rs")
+    fn = src[src.index("pub fn table_of"):]
+    fn = fn[:fn.index("\n    }\n") + 7]
+    # the old key is gone ...
+    assert "batches.len(), rows)" not in src and "HashMap<(usize, usize, usize)" not in src
+    # ... the entry remembers a Weak to the provider and the batches it was made from, and both are checked before reuse
+    entry = src[src.index("struct CachedTable"):src.index("fn same_batches")]
+    assert "Weak<dyn TableProvider>" in entry and "Vec<RecordBatch>" in entry and "Arc<DeviceTable>" in entry
+    assert "upgrade()" in fn and "Arc::ptr_eq(&p, source)" in fn and "same_batches(&e.batches, &batches)" in fn
+    assert "Arc::downgrade(source)" in fn and "strong_count() > 0" in fn
+    same = src[src.index("fn same_batches"):src.index("unsafe impl Send for HipContext")]
+    assert "Arc::ptr_eq(p, q)" in same and "num_rows()" in same and "a.len() == b.len()" in same
+    # the rule is written down where a maintainer looks for it
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "memory.rs:104-137" in integ and "Arc::ptr_eq" in integ and "Weak<dyn TableProvider>" in integ
+
+
+def test_the_python_mirror_applies_the_same_invalidation_rule():
+    """MemoryTable.device_table re-uploads when the batch list no longer holds the objects the copy was made from (checked
+    without a GPU: DeviceTable.from_batches is replaced by a recorder)"""
+    import pyarrow as pa
+    from qurious_amd import plan as P
+    made = []
+    real = P.DeviceTable.from_batches
+    P.DeviceTable.from_batches = staticmethod(lambda ctx, schema, data, lazy=False: made.append(list(data)) or object())
+    real_ctx = P.get_context
+    P.get_context = lambda: None
+    try:
+        schema = pa.schema([pa.field("v", pa.int64())])
+        mk = lambda vals: pa.RecordBatch.from_arrays([pa.array(vals, type=pa.int64())], schema=schema)   # noqa: E731
+        t = P.MemoryTable.try_new(schema, [mk([1, 2, 3])])
+        a = t.device_table()
+        assert t.device_table() is a and len(made) == 1                 # unchanged data: one upload
+        t.delete()                                                      # DELETE everything ...
+        t.insert([mk([7, 8, 9])])                                       # ... INSERT the same shape: same table, 1 batch, 3 rows
+        b = t.device_table()
+        assert b is not a and len(made) == 2 and made[1][0].column(0).to_pylist() == [7, 8, 9]
+        t.insert([mk([4])])
+        assert t.device_table() is not b and len(made) == 3             # an append is new data too
+    finally:
+        P.DeviceTable.from_batches = real
+        P.get_context = real_ctx

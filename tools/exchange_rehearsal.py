@@ -23,7 +23,9 @@ from qurious_amd import exchange, queries, synth  # noqa: E402
 
 # host waits (stream synchronisations inside libqhip, the transport's included) of one REPEATED Q3 through the multi-rank
 # operators, measured on the one-rank rehearsal; asserted as ceilings
-WAIT_CEILING = {"repartition": 24, "broadcast": 24}
+# (round 4: one wait per exchange CALL — both sides of a repartitioned join in one — and joins of deferred size below the
+# exchanges: a repartitioned Q3 waits 3 times, a broadcast one 5 times; VERDICT r03 item 2 asked for <= 5)
+WAIT_CEILING = {"repartition": 5, "broadcast": 5}
 
 
 def rows_of(batches):
@@ -132,7 +134,7 @@ def main():
                     plan = make()
                     if prune:
                         exchange.prune_exchange_columns(plan)
-                    for execution in range(3):          # (from the second execution on the heavy-key set is remembered)
+                    for execution in range(4):          # (from the second execution on the heavy-key set is remembered, from the third the joins' sizes)
                         exchange.exchange_stats()
                         before = ctx.sync_count()
                         t_dev = plan.execute_device()
@@ -151,7 +153,8 @@ def main():
                           f"{st['transport_waits'] if transport == 'torch' else 0} in torch; heavy-key rounds {st['heavy_key_rounds']}")
                 os.environ.pop("QHIP_TRANSPORT", None)
         for name in ("repartition", "broadcast"):
-            assert wire[(name, True, "rccl")] < wire[(name, False, "rccl")] and wire[(name, True, "rccl")] == wire[(name, True, "torch")]
+            # (the one-call exchange moves the columns' runs themselves: no 16-byte section padding of a wire image)
+            assert wire[(name, True, "rccl")] < wire[(name, False, "rccl")] and wire[(name, True, "torch")] - 4096 <= wire[(name, True, "rccl")] <= wire[(name, True, "torch")]
             # the host-wait budget of a REPEATED query through libqhip's transport (ceilings asserted so that a regression shows):
             # no heavy-key sampling any more, ONE wait per exchange inside the transport
             lib_waits, transport_waits, heavy_rounds = waits[(name, True, "rccl")]
