@@ -222,12 +222,21 @@ int qhip_ctx_set_timing(qhip_ctx* ctx, int32_t on);
  * No reference counterpart. */
 int qhip_ctx_allow_deferred_sizes(qhip_ctx* ctx, int32_t delta);
 int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen);
-/* Forget what the context has LEARNT about the plans it ran — lowered plans, remembered join output sizes, duplicate-key
- * flags, the aggregates' group counts and pre-zeroed tables — while compiled kernels stay loaded: the next execution of a
+/* Forget what the context has LEARNT about the plans it ran — lowered plans (with them the aggregates' remembered group
+ * counts and pre-zeroed tables, which live in the lowered plan), remembered join output sizes, duplicate-key flags — while
+ * compiled kernels stay loaded. Joins of deferred size still in flight are checked first (their verdict is discarded with
+ * the hints: nothing may consume such a table across this call): the next execution of a
  * query is then a first execution with a warm code cache (what the reference's caller sees for every new
  * `session.sql`, execution/session.rs:74-104: it builds a new plan each time). Statistics cached on TABLE columns (value
  * ranges, longest strings) are properties of the data and stay. bench.py measures first_execution_ms this way. */
 int qhip_ctx_forget_plans(qhip_ctx* ctx);
+/* Forget what the library has learnt about a TABLE's columns: value statistics (max |value|, value range, longest string) and
+ * the narrow copies made from them. The next big operator over the table collects them again — what a query over a
+ * freshly uploaded table pays once (bench.py: records.*.cold_first_query_ms / table_prepare_ms). */
+int qhip_table_forget_statistics(qhip_table* t);
+/* Bytes of HBM the table's auxiliary copies occupy beside its Arrow-layout buffers (the narrow copies of Decimal128 / Int64
+ * columns); qhip_table_column_bytes reports the Arrow-layout bytes. */
+int64_t qhip_table_aux_bytes(const qhip_table* t);
 
 /* ---------------------------------------------------------------- tables (Vec<RecordBatch> in HBM) */
 /* Upload n_batches struct-typed ArrowArrays (one per RecordBatch, children = columns)
@@ -418,7 +427,10 @@ typedef struct qhip_shuffle_input {
   const qhip_expr* exprs; int32_t n_exprs;
   const int32_t* key_roots; int32_t n_keys;     /* the join keys (also for all_gather: they are not hashed then) */
   int32_t predicate_root;                        /* the side's scan filter or -1 */
-  int32_t all_gather;                            /* 0: row -> rank mix(key) (repartition); 1: every row to every rank (broadcast) */
+  int32_t all_gather;                            /* bit 0: 0 = row -> rank mix(key) (repartition), 1 = every row to every rank
+                                                  * (broadcast); bit 1: a JOIN on these keys follows — the value range of a key
+                                                  * column travels with it (found once per base column: one reduction + wait) so
+                                                  * that the join can address its table by the key without reducing what it received */
   const int32_t* keep_columns;                   /* per input column, NULL = all */
 } qhip_shuffle_input;
 int qhip_shuffle_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_shuffle_input* inputs, int32_t n_inputs, qhip_table** outs);

@@ -159,6 +159,8 @@ def load_library() -> C.CDLL:
             "qhip_limit_execute": (C.c_int, [vp, vp, i64, i64, P(vp)]),
             "qhip_partition_by_key": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(vp)]),
             "qhip_partition_filtered": (C.c_int, [vp, vp, P(qhip_expr), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
+            "qhip_table_forget_statistics": (C.c_int, [vp]),
+            "qhip_table_aux_bytes": (i64, [vp]),
             "qhip_table_concat": (C.c_int, [vp, P(vp), i32, P(vp)]),
             "qhip_table_column_buffer": (C.c_int, [vp, i64, i32, P(vp), P(i64)]),
             "qhip_table_wire_meta": (C.c_int, [vp, vp, P(i64), i32]),
@@ -297,6 +299,14 @@ class DeviceTable:
             _release_schema(c_schema)
             for a in arrays:
                 _release_array(a)
+
+    def forget_statistics(self):
+        """drop the column statistics and narrow copies libqhip has collected on this table (qhip_table_forget_statistics)"""
+        self.ctx.check(self.ctx.lib.qhip_table_forget_statistics(self.handle))
+
+    @property
+    def aux_bytes(self) -> int:
+        return int(self.ctx.lib.qhip_table_aux_bytes(self.handle))
 
     @property
     def num_rows(self) -> int:

@@ -40,7 +40,8 @@ void HostColumn::set_null(int64_t i) {
   ++null_count;
 }
 
-// A host-assembled column -> HBM (synchronous; runs when a device operator first reads the column)
+// A host-assembled column -> HBM (runs when a device operator first reads the column; no host wait: the host vectors are kept
+// alive in a small ring until an event recorded behind the copies has passed)
 DevColumn upload_host_column(Ctx* ctx, const DeferredUpload& u) {
   HostColumn& hc = *std::static_pointer_cast<HostColumn>(u.host_col);
   const int64_t nrows = hc.length;
@@ -65,7 +66,12 @@ DevColumn upload_host_column(Ctx* ctx, const DeferredUpload& u) {
   } else if (hc.type.id != QHIP_NULL) {
     dc.values = up(hc.values.data(), hc.values.size());
   }
-  QHIP_HIP_CHECK(sync_stream(ctx->stream));   // the host vectors may go away with the DeferredUpload
+  // the host vectors may go away with the DeferredUpload while the copies are still queued: park them behind an event
+  Ctx::HostKeep& k = ctx->host_keep[ctx->host_keep_next++ % 32];
+  if (!k.ev) QHIP_HIP_CHECK(hipEventCreateWithFlags(&k.ev, hipEventDisableTiming));
+  else if (k.p && hipEventQuery(k.ev) != hipSuccess) { (void)hipGetLastError(); QHIP_HIP_CHECK(sync_event(k.ev)); }   // (32 uploads ago: long done)
+  k.p = u.host_col;
+  QHIP_HIP_CHECK(hipEventRecord(k.ev, ctx->stream));
   return dc;
 }
 

@@ -260,6 +260,11 @@ struct Ctx {
   hipEvent_t up_ev[2] = {nullptr, nullptr};
   std::string cache_dir;
   std::unordered_map<std::string, std::shared_ptr<void>> plan_cache;   // lowered plans keyed by their POD description
+  // host-assembled columns whose upload is in flight (agg.cpp upload_host_column): kept alive until an event behind their
+  // copies has passed, instead of a host wait per column (an aggregate's few result rows feeding the next device operator)
+  struct HostKeep { hipEvent_t ev = nullptr; std::shared_ptr<void> p; };
+  HostKeep host_keep[32];
+  size_t host_keep_next = 0;
 };
 
 // wraps a C entry point: runs f(), converts exceptions to status codes + last_error

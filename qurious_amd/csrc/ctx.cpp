@@ -349,6 +349,7 @@ void qhip_ctx_destroy(qhip_ctx* ctx) {
   }
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); g_live_contexts[ctx->device & 31].fetch_sub(1); }
+  for (auto& k : ctx->host_keep) { k.p.reset(); if (k.ev) (void)hipEventDestroy(k.ev); }   // (behind the wait: their copies are done)
   delete ctx;
 }
 
@@ -385,11 +386,40 @@ int qhip_ctx_forget_plans(qhip_ctx* ctx) {
   return guarded(ctx, [&] {
     QHIP_HIP_CHECK(hipSetDevice(ctx->device));
     QHIP_HIP_CHECK(sync_stream(ctx->stream));   // (plans own device arenas: nothing of theirs may still be in flight)
+    // joins of deferred size still in flight: their status slots are read now (the stream is idle) so that the tables they
+    // produced get their verified row counts (rows_final); an overflow is of no consequence for a caller that forgets the plans
+    try { verify_pending_sizes(ctx); } catch (const Error&) {}
     ctx->plan_cache.clear();
     ctx->join_size_hints.clear();
     ctx->join_dup_builds.clear();
     ctx->pending_sizes.clear();
   });
+}
+
+int qhip_table_forget_statistics(qhip_table* t) {
+  if (!t) return QHIP_INVALID_ARGUMENT;
+  for (DevColumn& c : t->cols) {
+    for (DevColumn* col : {&c, c.deferred && c.deferred->done ? &c.deferred->result : nullptr, c.pending_upload && c.pending_upload->done ? &c.pending_upload->result : nullptr}) {
+      if (!col) continue;
+      col->value_maxabs = 0;
+      col->utf8_max_len = -1;
+      col->narrow.reset();
+      col->big_reads = 0;
+      col->range = std::make_shared<ColRange>();
+      col->range_inherited = false;
+    }
+  }
+  return QHIP_OK;
+}
+
+int64_t qhip_table_aux_bytes(const qhip_table* t) {
+  if (!t) return 0;
+  int64_t b = 0;
+  for (const DevColumn& c : t->cols) {
+    const DevColumn& col = c.pending_upload && c.pending_upload->done ? c.pending_upload->result : c;
+    if (col.narrow && col.narrow->buf) b += (int64_t)col.narrow->buf->bytes;
+  }
+  return b;
 }
 
 int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {

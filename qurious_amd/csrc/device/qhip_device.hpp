@@ -221,6 +221,16 @@ __device__ __forceinline__ u64 qh_wave_sum_u64(u64 x) {
   x += qh_dpp64<0x143, 0xc>(x);
   return qh_readlane64(x, 63);
 }
+// OR over the 64 lanes (every lane active; the DPP moves read 0 outside a row, the identity of OR). Wave-uniform result.
+__device__ __forceinline__ u32 qh_wave_or_u32(u32 x) {
+  x |= qh_dpp0<0x111, 0xf>(x);
+  x |= qh_dpp0<0x112, 0xf>(x);
+  x |= qh_dpp0<0x114, 0xf>(x);
+  x |= qh_dpp0<0x118, 0xf>(x);
+  x |= qh_dpp0<0x142, 0xa>(x);
+  x |= qh_dpp0<0x143, 0xc>(x);
+  return qh_readlane32(x, 63);
+}
 __device__ __forceinline__ u64 qh_shfl_xor64(u64 v, int m) {
   u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
   return ((u64)hi << 32) | lo;
@@ -1633,6 +1643,9 @@ __device__ __forceinline__ void qh_join_dense_build_body(const KArgs& a, const D
       ok[r] = P::keys(a, inb ? i : nrows - 1, k[r], e) && inb;
       err |= inb ? e : 0u;
     }
+    // (Tried in round 4: the lanes of one bitmap word OR their bits together (DPP) and one lane issues the atomic. Q3's build
+    // sides do not have the locality it needs — join 2's keys, a fifth of the orders in order-key order, touch ~40 words per 64
+    // rows, join 1's are random — so the atomics stayed: 56 vs 52-62 us.)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const u64 idx = k[r][0] - L.kmin;

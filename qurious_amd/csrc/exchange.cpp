@@ -846,7 +846,7 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
     const qhip_shuffle_input& I = ins[k];
     if (!I.table || !I.key_roots || I.n_keys <= 0) fail(QHIP_INVALID_ARGUMENT, "qhip_shuffle_tables: an input without table / keys");
     sd.in = I.table;
-    sd.np = I.all_gather ? 1 : W;
+    sd.np = (I.all_gather & 1) ? 1 : W;
     sd.keep.assign(sd.in->cols.size(), 1);
     if (I.keep_columns) for (size_t col = 0; col < sd.keep.size(); ++col) sd.keep[col] = I.keep_columns[col] ? 1 : 0;
     if (sd.in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
@@ -877,6 +877,19 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
       const DevColumn& rc = indirect_eligible(c0) ? c0.deferred->src : resolved(ctx, c0);
       if (rc.null_count > 0) sd.has_nulls = true;
       const DevColumn& stat = c0.deferred && !c0.deferred->done ? c0.deferred->src : rc;
+      // the value range of an integer column travels with it (a join behind the exchange addresses its table by the key when
+      // the range is small: without it, it would reduce the received column and wait at EVERY execution). Found once per base
+      // column (one reduction + one wait, cached on the column and shared by whatever is gathered from it).
+      bool is_key = false;
+      for (int kk = 0; kk < I.n_keys; ++kk)
+        if (I.key_roots[kk] >= 0 && I.key_roots[kk] < I.n_exprs && I.exprs[I.key_roots[kk]].kind == QHIP_EXPR_COLUMN && I.exprs[I.key_roots[kk]].column == (int)sd.cols[j]) is_key = true;
+      if ((I.all_gather & 2) && is_key && !(stat.range && stat.range->known) && sd.in->num_rows > 0) {
+        const int id = stat.type.id;
+        if (id == QHIP_INT64 || id == QHIP_INT32 || id == QHIP_UINT8 || id == QHIP_DATE32 || id == QHIP_DATE64 || (id >= QHIP_TIME32_S && id <= QHIP_TIME64_NS)) {
+          int64_t mn = 0, mx = 0;
+          (void)key_range_of(ctx, c0, mn, mx);
+        }
+      }
       const bool known = stat.range && stat.range->known;
       stage[sd.meta_at + (size_t)sd.np + 3 * j] = known ? 1 : 0;
       stage[sd.meta_at + (size_t)sd.np + 3 * j + 1] = known ? stat.range->min : 0;
@@ -932,7 +945,7 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
     // rows every rank sends here, in rank order
     std::vector<int64_t> from((size_t)W), at((size_t)W + 1, 0);
     for (int r = 0; r < W; ++r) {
-      from[(size_t)r] = all[(size_t)r * M + sd.meta_at + (size_t)(ins[k].all_gather ? 0 : me)];
+      from[(size_t)r] = all[(size_t)r * M + sd.meta_at + (size_t)((ins[k].all_gather & 1) ? 0 : me)];
       at[(size_t)r + 1] = at[(size_t)r] + from[(size_t)r];
     }
     const int64_t N = at[(size_t)W];
@@ -963,7 +976,7 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
       oc.values = std::make_shared<DevBuf>((size_t)N * (size_t)mv.width);
       keep_alive.push_back(mv.out);
       for (int r = 0; r < W; ++r) {
-        const int p = ins[k].all_gather ? 0 : r;   // the run that goes to rank r
+        const int p = (ins[k].all_gather & 1) ? 0 : r;   // the run that goes to rank r
         const size_t out_bytes = (size_t)(starts[(size_t)p + 1] - starts[(size_t)p]) * (size_t)mv.width, in_bytes = (size_t)from[(size_t)r] * (size_t)mv.width;
         const uint8_t* sp = mv.out->as<uint8_t>() + (size_t)starts[(size_t)p] * (size_t)mv.width;
         uint8_t* dp = oc.values->as<uint8_t>() + (size_t)at[(size_t)r] * (size_t)mv.width;

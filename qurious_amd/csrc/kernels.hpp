@@ -26,7 +26,8 @@ void launch_gather_utf8_lengths(const int32_t* offsets, const uint32_t* idx, uin
 void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const uint32_t* idx, uint64_t m, const uint32_t* out_off,
                               uint8_t* out_data, hipStream_t s);
 // out[0] = max |v| of the 63-bit values of an Int64 (words 1) / Decimal128 (words 2) column, out[1] != 0: some value is wider
-void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s);
+// (narrow32: when set, value i's low 4 bytes are written there in the same pass — the speculative narrow copy)
+void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s, uint32_t* narrow32 = nullptr);
 // out[i] = the low 4 / 8 bytes of the 16-byte value i (the narrow copy of a Decimal128 column whose values fit, DevColumn::narrow)
 // (src_words = 1: the source is an Int64 column, bytes = 4)
 void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words = 2);

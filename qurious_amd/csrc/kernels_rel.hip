@@ -353,12 +353,14 @@ __global__ __launch_bounds__(QH_BLOCK) void k_utf8_max_len(const int* offsets, u
 // out[1] != 0 when some value does not. NULL slots count too (an upper bound is all the callers need). One atomic per
 // wavefront, none when it would change nothing.
 template <int WORDS>
-__global__ __launch_bounds__(QH_BLOCK) void k_value_maxabs(const u64* v, u64 n, u64* out) {
+__global__ __launch_bounds__(QH_BLOCK) void k_value_maxabs(const u64* v, u64 n, u64* out, u32* narrow32) {
   u64 m = 0;
   u32 big = 0;
   for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK) {
     const u64 lo = v[(size_t)i * WORDS];
     const u64 hi = WORDS == 2 ? v[(size_t)i * WORDS + 1] : (u64)((i64)lo >> 63);
+    // (speculative 4-byte narrow copy in the same pass: adopted by the host when the maximum turns out to fit 31 bits)
+    if (narrow32) narrow32[i] = (u32)lo;
     const bool fits = hi == (u64)((i64)lo >> 63);
     const u64 a = (lo >> 63) ? (u64)0 - lo : lo;
     if (fits && a < (1ULL << 63)) m = a > m ? a : m; else big = 1;
@@ -1149,11 +1151,11 @@ void launch_gather_utf8_bytes(const int32_t* offsets, const uint8_t* data, const
 void launch_utf8_max_len(const int32_t* offsets, uint64_t n, uint32_t* out, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_utf8_max_len, dim3(grid_for(n, QH_BLOCK, 1024)), dim3(QH_BLOCK), 0, s, (const int*)offsets, (u64)n, (u32*)out);
 }
-void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s) {
+void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* out, hipStream_t s, uint32_t* narrow32) {
   if (!n) return;
   const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);
-  if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
-  else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out);
+  if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out, (u32*)narrow32);
+  else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out, (u32*)narrow32);
 }
 void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words) {
   if (!n) return;

@@ -130,6 +130,44 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   const bool narrow_ok = env_int("QHIP_NARROW_DECIMALS", 1) != 0;
   const bool narrow_first = env_int("QHIP_NARROW_FIRST_USE", 0) != 0;
   std::vector<char> seen(t->cols.size(), 0);   // (a column referenced by several expression nodes counts as ONE read)
+  // Statistics first, for ALL the columns that lack them: one pass per column, ONE host wait for the lot (round 3: a wait per
+  // column), and — Decimal128 columns — the 4-byte narrow copy written speculatively by the same pass (round 3: a second pass
+  // over the column at its second big read). Adopted below when the maximum fits 31 bits, dropped otherwise.
+  {
+    struct Pending { const DevColumn* col; std::shared_ptr<DevBuf> spec; size_t at; };
+    std::vector<Pending> pend;
+    std::vector<char> seen0(t->cols.size(), 0);
+    for (int k = 0; k < n_exprs; ++k) {
+      const qhip_expr& e = exprs[k];
+      if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size() || seen0[(size_t)e.column]) continue;
+      if (t->cols[(size_t)e.column].type.id != QHIP_DECIMAL128 && t->cols[(size_t)e.column].type.id != QHIP_INT64) continue;
+      seen0[(size_t)e.column] = 1;
+      const DevColumn& col = icols[(size_t)e.column].indirect ? t->cols[(size_t)e.column] : resolved(ctx, t->cols[(size_t)e.column]);
+      if (col.value_maxabs == 0 && col.length >= min_rows && col.values) pend.push_back(Pending{&col, nullptr, pend.size() * 2});
+    }
+    if (!pend.empty()) {
+      DevBuf out(pend.size() * 16);
+      QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, out.bytes, ctx->stream));
+      for (Pending& p : pend) {
+        const DevColumn& col = *p.col;
+        const bool spec = narrow_ok && col.type.id == QHIP_DECIMAL128 && !col.deferred && env_int("QHIP_NARROW_SPECULATIVE", 1) != 0;
+        if (spec) p.spec = std::make_shared<DevBuf>((size_t)col.length * 4);
+        launch_value_maxabs(col.values->ptr, (uint64_t)col.length, col.type.id == QHIP_DECIMAL128 ? 2 : 1, out.as<uint64_t>() + p.at, ctx->stream,
+                            spec ? p.spec->as<uint32_t>() : nullptr);
+      }
+      std::vector<uint64_t> h(pend.size() * 2, 0);
+      copy_sync(ctx->stream, h.data(), out.ptr, h.size() * 8, hipMemcpyDeviceToHost);
+      for (Pending& p : pend) {
+        const DevColumn& col = *p.col;
+        col.value_maxabs = h[p.at + 1] ? ~0ULL : std::max<uint64_t>(h[p.at], 1);
+        if (p.spec && col.value_maxabs < (1ULL << 31)) {
+          auto nc = std::make_shared<DevColumn::NarrowCopy>();
+          nc->buf = p.spec; nc->bytes = 4; nc->src = col.values->ptr; nc->rows = col.length;
+          col.narrow = nc;
+        }
+      }
+    }
+  }
   for (int k = 0; k < n_exprs; ++k) {
     const qhip_expr& e = exprs[k];
     if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size()) continue;
@@ -138,14 +176,6 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
     seen[(size_t)e.column] = 1;
     // (a deferred gather the kernel reads through its index vector is not gathered for the statistic: it carries its source's)
     const DevColumn& col = icols[(size_t)e.column].indirect ? t->cols[(size_t)e.column] : resolved(ctx, t->cols[(size_t)e.column]);
-    if (col.value_maxabs == 0 && col.length >= min_rows && col.values) {
-      DevBuf out(16);
-      QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, 16, ctx->stream));
-      launch_value_maxabs(col.values->ptr, (uint64_t)col.length, col.type.id == QHIP_DECIMAL128 ? 2 : 1, out.as<uint64_t>(), ctx->stream);
-      uint64_t h[2] = {0, 0};
-      copy_sync(ctx->stream, h, out.ptr, 16, hipMemcpyDeviceToHost);
-      col.value_maxabs = h[1] ? ~0ULL : std::max<uint64_t>(h[0], 1);
-    }
     // the bound enters lowered-plan cache keys: rounded up to a whole number of bits so that plans are shared by data
     // of the same magnitude
     uint64_t m = col.value_maxabs;

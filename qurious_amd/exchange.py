@@ -291,7 +291,7 @@ def shuffle_tables(inputs) -> List[DeviceTable]:
         arr[k].key_roots = roots_c
         arr[k].n_keys = len(roots)
         arr[k].predicate_root = proot
-        arr[k].all_gather = 1 if all_gather else 0
+        arr[k].all_gather = int(all_gather)   # bit 0: all-gather; bit 1: a join on the keys follows (their value ranges travel)
         arr[k].keep_columns = keep_c
     outs = (C.c_void_p * len(inputs))()
     ctx.check(lib.qhip_shuffle_tables(ctx.handle, get_comm(ctx), arr, len(inputs), outs))
@@ -643,8 +643,8 @@ class DistributedHashJoinExec(HashJoinExec):
                 try:
                     lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
                     rt, rpred = _side_for_exchange(self.right, False)
-                    got = shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), False),
-                                          (rt, [r for _, r in self.on], rpred, _keep_mask(len(rs), rneed), False)])
+                    got = shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), 2),
+                                          (rt, [r for _, r in self.on], rpred, _keep_mask(len(rs), rneed), 2)])
                     _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + got[1].num_rows
                     return got[0], got[1]
                 except _ffi.UnsupportedError:
@@ -751,7 +751,7 @@ class BroadcastHashJoinExec(HashJoinExec):
         if _fast_exchange():
             try:
                 lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
-                return shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), True)])[0]
+                return shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), 3)])[0]
             except _ffi.UnsupportedError:
                 pass
         with get_context().no_deferred_sizes():
@@ -829,7 +829,7 @@ class DistributedHashAggregate(PhysicalPlan):
                 mine = None
                 if _fast_exchange():
                     try:
-                        mine = shuffle_tables([(part, keys, None, None, False)])[0]
+                        mine = shuffle_tables([(part, keys, None, None, 0)])[0]
                     except _ffi.UnsupportedError:
                         mine = None   # (string group keys, NULLs among the partials: the generic path)
                 if mine is None:

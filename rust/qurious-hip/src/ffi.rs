@@ -145,6 +145,21 @@ pub struct qhip_comm_stats {
     pub reserved: i32,
 }
 
+/// one input of `qhip_shuffle_tables`: a join side (or the build side of a broadcast join) with its scan filter, keys and the
+/// columns the plan above the exchange reads
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct qhip_shuffle_input {
+    pub table: *const qhip_table,
+    pub exprs: *const qhip_expr,
+    pub n_exprs: i32,
+    pub key_roots: *const i32,
+    pub n_keys: i32,
+    pub predicate_root: i32,
+    pub all_gather: i32,
+    pub keep_columns: *const i32,
+}
+
 extern "C" {
     // ---- context
     pub fn qhip_ctx_create(device_index: c_int, out: *mut *mut qhip_ctx) -> c_int;
@@ -294,6 +309,8 @@ extern "C" {
         n_parts: i32,
         out_parts: *mut *mut qhip_table,
     ) -> c_int;
+    pub fn qhip_table_forget_statistics(t: *mut qhip_table) -> c_int;
+    pub fn qhip_table_aux_bytes(t: *const qhip_table) -> i64;
     pub fn qhip_table_concat(ctx: *mut qhip_ctx, tables: *const *const qhip_table, n: i32, out: *mut *mut qhip_table) -> c_int;
     pub fn qhip_table_keep_columns(ctx: *mut qhip_ctx, t: *const qhip_table, keep: *const i32, n_cols: i32, out: *mut *mut qhip_table) -> c_int;
     pub fn qhip_table_stride_sample(ctx: *mut qhip_ctx, t: *const qhip_table, stride: i64, out: *mut *mut qhip_table) -> c_int;
@@ -310,6 +327,9 @@ extern "C" {
         n_cols: i32,
         out: *mut *mut qhip_table,
     ) -> c_int;
+    /// the whole exchange step of a distributed join — both sides of a repartitioned join, or a broadcast join's build side — in
+    /// one call with one host wait; QHIP_RETRY is returned by EVERY rank when a join of deferred size below must run again
+    pub fn qhip_shuffle_tables(ctx: *mut qhip_ctx, comm: *mut qhip_comm, inputs: *const qhip_shuffle_input, n_inputs: i32, outs: *mut *mut qhip_table) -> c_int;
     pub fn qhip_all_gather_table(
         ctx: *mut qhip_ctx,
         comm: *mut qhip_comm,

@@ -231,7 +231,11 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
             assert 0 < z["aggregate_table"]["lds_occupancy"] <= 1 and z["aggregate_table"]["groups"] > 0
             assert z["exchange"]["xgmi_peak_GBps"] == 7 * 153.0 and z["exchange"]["transport"] == "rccl"
             assert 0 < z["exchange"]["host_waits_per_query"] < 40 and z["exchange"]["heavy_key_rounds_per_query"] <= 1
-            assert rec["q3_sf10"]["exchange"]["transport"] == "rccl" and rec["q3_sf10"]["exchange"]["host_waits_per_query"] < 40
+            # a repeated distributed Q3 waits for the device at most 5 times, whatever the strategy (round 3:
+            # 16-17): one wait per exchange CALL (both sides of a repartitioned join in one), joins of deferred size below them
+            assert rec["q3_sf10"]["exchange"]["transport"] == "rccl"
+            assert 0 < rec["q3_sf10"]["host_waits_per_query"] <= 5 and 0 < rec["q3_sf10_repartition"]["host_waits_per_query"] <= 5, \
+                (rec["q3_sf10"]["host_waits_per_query"], rec["q3_sf10_repartition"]["host_waits_per_query"])
         if "q3" in extra:
             assert line["exchange"]["exchanges_per_query"] > 0
 
