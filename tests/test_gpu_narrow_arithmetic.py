@@ -270,8 +270,10 @@ def test_narrow_copies_of_decimal_columns(ctx, monkeypatch, extreme, width):
         return sorted(zip(b.column(0).to_pylist(), _i128_of(b.column(1)), b.column(2).to_pylist())), st
 
     first, st_first = run()
-    assert abs(st_first["bytes_per_row_read"] - (8 + 16 + 0.125)) < 1e-9   # the first big read streams the Arrow layout ...
-    got, st = run()                                                        # ... the second one finds / makes the narrow copy
+    # the first big read collects the column's statistics; the same pass writes the 4-byte copy speculatively (round 4), so a
+    # column that fits 31 bits is streamed narrow from the first execution on; the 8-byte copy is made at the second big read
+    assert abs(st_first["bytes_per_row_read"] - (8 + (4 if width == 4 else 16) + 0.125)) < 1e-9, st_first["bytes_per_row_read"]
+    got, st = run()
     assert got == first
     # 8 bytes of group key + the value column at its narrow width + its validity bits
     assert abs(st["bytes_per_row_read"] - (8 + width + 0.125)) < 1e-9, st["bytes_per_row_read"]
