@@ -14,6 +14,7 @@ struct Module {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
   int wgs_per_cu = 0;   // occupancy of the kernel at the launch shape its operator uses (0 = not asked yet)
+  size_t wgs_dyn_lds = 0;   // ... and the dynamic LDS size it was asked for
   ~Module();
 };
 

@@ -46,6 +46,8 @@ uint32_t read_u32(hipStream_t s, const void* dev) {
   return v;
 }
 
+thread_local int g_dense_off = 0;   // > 0: the dense (direct-address) layout is switched off for the join being (re-)run
+
 qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int join_type, const qhip_expr* lex, int nlex, const qhip_expr* rex,
                       int nrex, const int32_t* on_l, const int32_t* on_r, int n_on, const qhip_expr* fex, int nfex, int froot,
                       const int32_t* fsides, const int32_t* fcols, int nfcols, int lpred, int rpred) {
@@ -73,7 +75,8 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   // still names its source): the table is then an exact bitmap over the range + row_of[key - kmin]
   // (qh_join_dense_build_body / qh_join_probe_dense_body). QHIP_JOIN_DENSE: 0 never, 1 when the range is within 256x the
   // build rows (default), 2 whenever the key qualifies (tests).
-  const int dense_mode = env_int("QHIP_JOIN_DENSE", 1);
+  // (g_dense_off: this join is being re-run after its dense table did not fit the device memory, see below)
+  const int dense_mode = g_dense_off > 0 ? 0 : env_int("QHIP_JOIN_DENSE", 1);
   bool dense_candidate = false;
   int64_t kmin = 0, kmax = 0;
   uint64_t dense_n = 0;
@@ -84,7 +87,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if ((id == QHIP_INT64 || id == QHIP_INT32 || id == QHIP_UINT8 || id == QHIP_DATE32 || id == QHIP_DATE64 || (id >= QHIP_TIME32_S && id <= QHIP_TIME64_NS)) &&
         key_range_of(ctx, kc, kmin, kmax)) {
       const uint64_t span = (uint64_t)kmax - (uint64_t)kmin;   // (kmax >= kmin; the difference fits 64 unsigned bits)
-      if (span < (1ULL << 30) && (dense_mode == 2 || span < 256 * B + 65536)) { dense_candidate = true; dense_n = span + 1; }
+      // automatic mode: the bitmap at most 32 bytes per build row AND the table bounded in absolute terms — row_of is 4 bytes per
+      // VALUE of the range (span < 2^28: at most 1 GB beside a 32 MB bitmap; Q3's join 2 at SF100: 600 M values would be 2.4 GB
+      // for 15 M build rows — the hashed layouts take over there). Whatever the mode, an allocation that fails falls back to
+      // the hashed layouts instead of failing the query.
+      const uint64_t max_span = (uint64_t)1 << std::max(16, std::min(30, env_int("QHIP_JOIN_DENSE_MAX_SPAN_BITS", 28)));
+      if (span < (1ULL << 30) && (dense_mode == 2 || (span < 256 * B + 65536 && span < max_span))) { dense_candidate = true; dense_n = span + 1; }
     }
   }
   // the build key of a join over a join's output is a deferred gather: the dense build kernel reads it THROUGH the index
@@ -248,7 +256,15 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   const size_t table_bytes = dense ? ((size_t)dense_n * 4 + 127) / 128 * 128 : (size_t)nslots * (1 + W) * 8;
   const size_t count_bytes = (region_build || dense) ? 0 : (((size_t)nslots + 2) * 4 + 7) / 8 * 8;
   const size_t bloom_bytes = dense ? ((size_t)dense_words * 4 + 127) / 128 * 128 : (size_t)filter_words * 8;
-  DevBuf arena(table_bytes + count_bytes + bloom_bytes);
+  DevBuf arena;
+  try {
+    arena.alloc(table_bytes + count_bytes + bloom_bytes);
+  } catch (const Error& e) {
+    if (e.code != QHIP_OUT_OF_MEMORY || !dense) throw;
+    // the direct-address table does not fit: the hashed layouts need 16-24 bytes per build ROW, not 4 per key VALUE
+    struct Off { Off() { ++g_dense_off; } ~Off() { --g_dense_off; } } off;
+    return hash_join(ctx, L, R, join_type, lex, nlex, rex, nrex, on_l, on_r, n_on, fex, nfex, froot, fsides, fcols, nfcols, lpred, rpred);
+  }
   uint64_t* table = arena.as<uint64_t>();
   uint32_t* count = (uint32_t*)(arena.as<uint8_t>() + table_bytes);
   uint64_t* bloom = (uint64_t*)(arena.as<uint8_t>() + table_bytes + count_bytes);
@@ -395,10 +411,13 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const unsigned waves_per_wg = dense_lds ? 16 : 4;
     // dynamic LDS: [bitmap words of the LDS variants | per wavefront: stage_cap x (idx, row)] (dense layout only)
     const size_t dyn_lds = !dense ? 0 : (((size_t)lds_words + 1) & ~(size_t)1) * 4 + (size_t)waves_per_wg * 2 * 4 * (dense_lds ? stage_cap_lds : stage_cap_small);
-    if (mod->wgs_per_cu == 0) {
+    // (asked once per module AND dynamic-LDS size: the LDS / hybrid variants' bitmap part changes with the data under one cached
+    // plan, and with it the workgroups a CU holds — ADVICE r03)
+    if (mod->wgs_per_cu == 0 || mod->wgs_dyn_lds != dyn_lds) {
       int nb = 0;
       if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mod->fn, (int)waves_per_wg * 64, dyn_lds) != hipSuccess || nb < 1) nb = 1;
       mod->wgs_per_cu = nb;
+      mod->wgs_dyn_lds = dyn_lds;
     }
     const uint64_t resident = (uint64_t)ctx->num_cus * (uint64_t)mod->wgs_per_cu * waves_per_wg;   // wavefronts the chip runs at once
     const uint64_t tpw_max = (uint64_t)std::max(1, env_int("QHIP_PROBE_TILES_PER_WAVE", 32));

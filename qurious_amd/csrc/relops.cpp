@@ -212,7 +212,9 @@ void ensure_narrow_int_columns(Ctx* ctx, const qhip_table* t, const qhip_expr* e
     const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
     if (!col.values || col.length < min_rows) continue;
     int64_t mn = 0, mx = 0;
-    if (!key_range_of(ctx, col, mn, mx) || col.range_inherited) continue;   // (an inherited range is a superset's: still valid bounds, but only base columns are worth a copy)
+    // (only base columns are worth a copy: a column with an inherited range — a gathered / filtered subset — is an intermediate
+    // result; tested BEFORE the range is asked for, which on such a column would cost a reduction and a host wait per query)
+    if (col.range_inherited || !key_range_of(ctx, col, mn, mx)) continue;
     if (mn < -(int64_t)0x7fffffff || mx > (int64_t)0x7fffffff) continue;
     if (++col.big_reads < 2 && !col.narrow && env_int("QHIP_NARROW_FIRST_USE", 0) == 0) continue;   // (DevColumn::big_reads: the second read earns the copy)
     if (!col.narrow || col.narrow->bytes != 4 || col.narrow->src != col.values->ptr || col.narrow->rows != col.length) {

@@ -512,6 +512,11 @@ def heavy_keys(local_top: Sequence[Tuple[object, int]], local_sample_rows: int, 
         row += [int(k), int(c)]
     row += [0, 0] * (HEAVY_CANDIDATES - (len(local_top) if ints else 0))
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    if dev.type == "cuda" and "h" in _COMM:
+        # libqhip's own communicator may still have a grouped send / recv in flight on the context's stream: two RCCL
+        # communicators active at once on one device is the hazard NCCL warns about — drain ours before torch's runs (ADVICE r03;
+        # this sampling round happens once in HEAVY_REFRESH executions)
+        _COMM["ctx"].synchronize()
     mine = torch.tensor(row + [1 if ints else 0], dtype=torch.int64, device=dev)     # last word: "my keys are integers"
     everyone = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(everyone, mine, group=group)                                      # (every rank, whatever its key type)

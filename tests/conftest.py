@@ -84,7 +84,7 @@ def join_layout(request, monkeypatch):
     direct-address layout for one integer key of a small value range, else one hashed table filled with atomics / the
     LDS-staged region build for big build sides), the region build forced on every join (QHIP_JOIN_REGION=2) and the hashed
     layouts only (QHIP_JOIN_DENSE=0), the dense layout wherever the key qualifies whatever the range-to-rows ratio
-    (QHIP_JOIN_DENSE=2), and the dense layout with its bitmap staged in LDS (QHIP_JOIN_DENSE_LDS=1)."""
+    (QHIP_JOIN_DENSE=2), and the dense layout with its bitmap staged in LDS whatever the pays-rule says (QHIP_JOIN_DENSE_LDS=2)."""
     if request.param == "regions":
         monkeypatch.setenv("QHIP_JOIN_REGION", "2")
         monkeypatch.setenv("QHIP_JOIN_DENSE", "0")
