@@ -165,9 +165,29 @@ static double ord_to_f64(uint64_t k) {
 }
 
 // ---------------------------------------------------------------- the operator
+// The input of a mid-sized many-group aggregate, ordered by key hash into one part per workgroup (qk_filter_agg_parts reads part
+// p = rows [runs[p * stride], runs[(p + 1) * stride]) of the view and appends its groups to the dense slots: AggLaunch)
+struct AggParts { const uint32_t* runs; uint32_t stride; int n_parts; uint64_t hint_key; };
+
+static uint64_t agg_hint_key(const qhip_expr* exprs, int n_exprs, int pred_root, const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs) {
+  uint64_t h = 1469598103934665603ULL;
+  auto mix = [&](const void* p, size_t n) { for (size_t k = 0; k < n; ++k) { h ^= ((const unsigned char*)p)[k]; h *= 1099511628211ULL; } };
+  for (int k = 0; k < n_exprs; ++k) {
+    qhip_expr e = exprs[k];
+    const char* str = e.lit_str; const int64_t len = e.lit_len;
+    e.lit_str = nullptr;
+    mix(&e, sizeof e);
+    if (str && len > 0 && e.kind == QHIP_EXPR_LITERAL) mix(str, (size_t)len);
+  }
+  mix(&pred_root, sizeof pred_root);
+  mix(group_roots, sizeof(int32_t) * (size_t)n_groups);
+  mix(aggs, sizeof(qhip_agg) * (size_t)n_aggs);
+  return h;
+}
+
 static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, int pred_root,
                                   const int32_t* group_roots, int n_groups, const qhip_agg* aggs, int n_aggs,
-                                  const char* const* out_names) {
+                                  const char* const* out_names, const AggParts* parts = nullptr) {
   const bool trace = getenv("QHIP_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
@@ -184,6 +204,62 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats_timing_pending = 0;
 
+  // ---- mid-sized input, many groups (the same aggregate produced them last time): order the rows by key hash into one part per
+  // workgroup first — the exchange's two partition passes over the ROW NUMBERS (nothing but the parts' selection vector is
+  // written; the columns are then read through it, composed with whatever index vectors a join below left) — and aggregate
+  // every part in its workgroup's LDS table alone: no group is shared between workgroups, so nothing is merged into the HBM
+  // table and no LDS table overflows (configs[4]'s per-rank aggregate, 2 M joined rows -> 200 k groups: round 3 spent 46 % of
+  // the kernel merging ~1.5 M (workgroup, group) pairs with memory-side atomics). QHIP_AGG_PARTS: 0 never, 1 auto, 2 always.
+  const uint64_t hint_key = parts ? parts->hint_key : agg_hint_key(exprs, n_exprs, pred_root, group_roots, n_groups, aggs, n_aggs);
+  if (!parts && n_groups > 0 && pred_root < 0 && !in->no_batches()) {
+    const int mode = env_int("QHIP_AGG_PARTS", 1);
+    const auto hint = ctx->agg_group_hints.find(hint_key);
+    const uint32_t groups_hint = hint != ctx->agg_group_hints.end() ? hint->second : 0u;
+    const int64_t N0 = in->num_rows;
+    // Only over plain columns. A join output read through index vectors pays ~64 bytes of random sector traffic per row and
+    // referenced column; ordering the rows first makes the key columns pay it twice (pass 1 and the aggregate) — measured on
+    // configs[4]'s per-rank aggregate (2 M joined rows, 5 columns through 2 index vectors, Zipf keys): pass 1 141 us + pass 2 /
+    // index composition 67 us + aggregate 347 us against 307 us for the unpartitioned kernel, whose own floor those gathers
+    // are (profiles/r04_q3_sf100_slice_parts_timeline.txt). What that input needs is the aggregate's arguments evaluated where
+    // the pairs are emitted (a dense record stream), not another pass over the index vectors.
+    bool plain_input = !in->rows_dev;
+    for (int k = 0; k < n_exprs; ++k)
+      if (exprs[k].kind == QHIP_EXPR_COLUMN && exprs[k].column >= 0 && exprs[k].column < (int)in->cols.size() && in->cols[(size_t)exprs[k].column].deferred)
+        plain_input = false;
+    const bool three_pass_forced = env_int("QHIP_AGG_PARTITION", 1) == 2;   // (tests: the three-pass partitioned path keeps precedence)
+    // (from 2^20 rows: below, the five launches in front of the kernel cost what the merges did — Q3 at SF10, 0.34 M rows -> 113 k
+    // groups: 118 us against 59)
+    if (!three_pass_forced && (mode == 2 ? N0 > 0 : (mode == 1 && plain_input && groups_hint >= 16384 && N0 >= ((int64_t)1 << 20) && N0 <= ((int64_t)1 << 22) &&
+                                                      env_int("QHIP_AGG_STATS", 0) == 0))) {
+      // parts: a 1 024-thread workgroup's LDS table (128 KB) at a load of ~0.4
+      int slot_words_guess = 8;
+      { const auto sw = ctx->agg_slot_words.find(hint_key); if (sw != ctx->agg_slot_words.end()) slot_words_guess = sw->second; }
+      uint32_t lslots = 16;
+      while ((uint64_t)lslots * 2 * (uint64_t)slot_words_guess * 8 <= 128 * 1024) lslots *= 2;
+      // (at least ~3/4 of the CUs' worth of parts: a part is one workgroup's work)
+      const int np = (int)std::max<uint64_t>(mode == 2 ? 2 : std::min<uint64_t>(255, (uint64_t)ctx->num_cus * 3 / 4),
+                                             std::min<uint64_t>(255, ((uint64_t)std::max<uint32_t>(groups_hint, 1) * 5 / 2 + lslots - 1) / lslots));
+      PartitionWork w;
+      partition_pass1(ctx, in, exprs, n_exprs, group_roots, n_groups, -1, np, w);
+      std::vector<MovedColumn> moved;
+      std::vector<size_t> odd;
+      std::shared_ptr<DevBuf> sel;
+      partition_scatter(ctx, in, nullptr, np, w, (uint64_t)N0, moved, odd, sel, true);
+      qhip_table view;
+      view.ctx = ctx;
+      view.names = in->names;
+      view.nullable = in->nullable;
+      view.num_rows = N0;
+      view.batch_offsets = {0, N0};
+      defer_gather(ctx, in->cols, sel, (uint64_t)N0, false, view.cols);
+      AggParts ap{w.runs.as<uint32_t>(), w.n_units, np, hint_key};
+      qhip_table* out = hash_aggregate(ctx, &view, exprs, n_exprs, pred_root, group_roots, n_groups, aggs, n_aggs, out_names, &ap);
+      ctx->stats.rows_in = in->rows_dev ? in->deferred_count() : N0;
+      // a join of deferred size that turned out to have produced nothing has no output batches (hash_join.rs:363-372)
+      if (in->rows_dev && in->deferred_count() == 0 && out->num_rows == 0) { out->batch_offsets.assign(1, 0); out->pending_offsets.reset(); }
+      return out;   // (w / sel go back to the stream-ordered pool: whoever gets them next runs behind the kernels that read them)
+    }
+  }
   // (late materialisation: the plain deferred gathers of a join output are read through their index vectors by the kernel)
   resolve_referenced(ctx, in, exprs, n_exprs, true);
   std::vector<InputCol> icols = input_cols_of(in, true);
@@ -305,6 +381,12 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if ((uint64_t)l_nslots * slot_bytes > (wide ? 128 : 64) * 1024) l_nslots = 0;   // slot too wide for LDS staging
     if (l_nslots == 0) wide = false;
   }
+  if (parts) {   // one 1 024-thread workgroup per part on the biggest LDS table that fits
+    l_nslots = 16;
+    while ((uint64_t)l_nslots * 2 * slot_bytes <= 128 * 1024) l_nslots *= 2;
+    wide = true;
+  }
+  ctx->agg_slot_words[hint_key] = plan.slot_words;
   const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
   const int block = wide ? 1024 : 256;
   const int64_t tile_rows = (int64_t)block * plan.R;
@@ -312,6 +394,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   const bool merge_heavy_grid = plan.W > 0 && plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
   const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : merge_heavy_grid ? 1 : 4);
   unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * bpc));
+  if (parts) grid = (unsigned)parts->n_parts;
 
   // First attempt: a SMALL table (4096 slots) replicated 32 times, workgroup b merging into replica b % 32. Clearing and
   // compacting cost time proportional to the table size, and with few groups (Q1: 4) the ~1000 workgroups would
@@ -325,6 +408,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     replicas = 1;
     cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(cap, 4096));
   }
+  if (parts) {   // the HBM table only takes what an LDS table cannot hold (a part with more groups than planned)
+    replicas = 1;
+    cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(1u << 16, pow2_ceil((uint64_t)plan.last_groups / 2 + 1)));   // (+ the sliced parts' groups; grown x16 on overflow like any table)
+  } else
   if (plan.W > 0 && plan.last_groups > cap / 4) {
     // the same plan produced many groups last time: go straight to one table with room for them
     cap = std::min<uint32_t>(cap_max, std::max<uint32_t>(1u << 16, pow2_ceil((uint64_t)plan.last_groups * 2)));
@@ -478,10 +565,11 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     const uint32_t total_slots = cap * replicas;
     // (a plan that produced many groups last time gets a dense buffer that should hold them all at once)
     guess = plan.W == 0 ? 0 : std::min<uint32_t>(total_slots, std::max<uint32_t>(8192, plan.last_groups + plan.last_groups / 4));
+    if (parts) guess = (uint32_t)std::max<int64_t>(N, 1);   // (the workgroups append their groups themselves: room for one group per row, nothing can be lost)
     // Small replicated attempt: a persistent arena [status | counter | table | dense slots] that the PREVIOUS call left
     // zeroed, so the kernel launch is the first thing on the stream. (total_slots <= guess there: one compaction always
     // suffices and the table is not needed again after it.)
-    const bool use_arena = plan.W > 0 && replicas > 1 && total_slots <= 8192 && table_bytes <= (1u << 20) && env_int("QHIP_AGG_NO_ARENA", 0) == 0;
+    const bool use_arena = !parts && plan.W > 0 && replicas > 1 && total_slots <= 8192 && table_bytes <= (1u << 20) && env_int("QHIP_AGG_NO_ARENA", 0) == 0;
     // [status words (64 bytes) | compaction counter]: in the arena, else a zeroed block of the context's ring; read back together
     uint32_t* status_dev = nullptr;
     std::shared_ptr<DevBuf> arena;
@@ -514,7 +602,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     L.replicas = replicas;
     L.collect_stats = env_int("QHIP_AGG_STATS", 0) ? 1u : 0u;
     void* args[] = {&ka, &L};
-    time_mark(ctx, 0);
+    if (!parts) time_mark(ctx, 0);   // (parts: the clock started in front of the partition passes)
     // Many groups on a big input: partition the rows by key hash first, so that every bin's groups fit an LDS table and the
     // HBM table is touched once per GROUP instead of once per row (device/qhip_device.hpp, "partitioned aggregation").
     // QHIP_AGG_PARTITION: 0 never, 1 when the plan's previous run says it pays (default), 2 always (tests).
@@ -529,7 +617,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     // avoid. Off by default; what this size needs is a combiner in front of the partitioning, not fewer host waits.
     const bool mid = N < ((int64_t)1 << 22);
     const bool mid_on = env_int("QHIP_AGG_PARTITION_MID", 0) != 0;
-    bool partitioned = plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
+    bool partitioned = !parts && plan.W > 0 && N > 0 && replicas == 1 && l_nslots >= 64 && !use_arena && !L.collect_stats &&
                              (pa_mode == 2 || (pa_mode == 1 && N >= ((int64_t)1 << 22) && plan.last_groups >= 32768) ||
                               (pa_mode == 1 && mid && N >= ((int64_t)1 << 18) && plan.last_groups >= 16384 && mid_on));
     const bool device_items = partitioned && mid && (mid_on || pa_mode == 2);
@@ -647,6 +735,17 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       }
       }
 
+    } else if (N > 0 && parts) {
+      dense.alloc((size_t)guess * slot_bytes + 8);
+      dense_dev = dense.as<uint64_t>();
+      L.part_runs = parts->runs; L.part_stride = parts->stride;
+      L.dense_out = dense_dev + 1; L.dense_counter = status_dev + 16; L.dense_cap = guess;
+      // a part of more than 4x the average is sliced (heavy keys): at most n_parts / 4 + 1 slices in all
+      L.n_parts = (uint32_t)parts->n_parts;
+      L.part_max = (uint32_t)std::max<int64_t>(1024, env_int("QHIP_AGG_PARTS_MAX_FACTOR", 4) * ((N + parts->n_parts - 1) / parts->n_parts));
+      const unsigned pgrid = grid + (unsigned)((uint64_t)N / L.part_max) + 1;
+      std::shared_ptr<Module> pmod = get_module(ctx, plan.source, "qk_filter_agg_parts");
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(pmod->fn, pgrid, 1, 1, 1024, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
     } else if (N > 0) {
       if (wide) {
         std::shared_ptr<Module> wmod = get_module(ctx, plan.source, "qk_filter_agg_wide");
@@ -676,8 +775,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, 64 + 8, hipMemcpyDeviceToHost, ctx->stream));   // status + counter
         if (!direct) QHIP_HIP_CHECK(hipMemcpyAsync(pre_host + 1, dense_dev + 1, (size_t)pre_copied * slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
       } else {
-        dense.alloc((size_t)guess * slot_bytes + 8);
-        dense_dev = dense.as<uint64_t>();
+        if (!parts) { dense.alloc((size_t)guess * slot_bytes + 8); dense_dev = dense.as<uint64_t>(); }   // (parts: allocated in front of the kernel, which appends to it)
         // a plan that produced many groups last time will most likely do so again: assemble its output columns on the
         // device right away (the kernel reads the group count from the compaction counter) — one synchronisation in all,
         // and no slot crosses PCIe
@@ -686,7 +784,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         spec_enqueued = false;
         const bool will_spec = replicas == 1 && plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0;
         // (a host-side result: its first dense slots go to page-locked host memory straight from the compaction kernel)
-        const bool direct = !will_spec && env_int("QHIP_AGG_PINNED_SLOTS", 1) != 0;
+        // (parts: the workgroups appended most slots themselves — the first ones are copied out of the dense buffer instead)
+        const bool direct = !will_spec && !parts && env_int("QHIP_AGG_PINNED_SLOTS", 1) != 0;
         launch_compact_slots(table_dev, total_slots, plan.slot_words, dense_dev + 1, counter_dev, guess, ctx->stream, direct ? pre_host + 1 : nullptr,
                              std::min(PRE, guess));
         if (will_spec) {
@@ -757,6 +856,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
       // the speculative device-side assembly is the result
       plan.last_groups = G; plan.learnt_at = ++g_learn_tick;
+      if (ctx->agg_group_hints.size() > 4096) ctx->agg_group_hints.clear();
+      ctx->agg_group_hints[hint_key] = G;
       qhip_table* result = finish_device_finalize(spec, dense_dev + 1, G, true);
       ctx->stats.main_kernel_ms = main_ms;
       ctx->stats.total_device_ms = main_ms;
@@ -771,7 +872,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
       ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
       ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : plan.kernel_name.c_str());
+      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : plan.kernel_name.c_str());
       return result;
     }
     if (replicas == 1 && G >= dev_threshold) {
@@ -833,6 +934,8 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   }
 
   plan.last_groups = G; plan.learnt_at = ++g_learn_tick;
+  if (ctx->agg_group_hints.size() > 4096) ctx->agg_group_hints.clear();
+  ctx->agg_group_hints[hint_key] = G;
   auto set_stats = [&]() {
     ctx->stats.main_kernel_ms = main_ms;
     ctx->stats.total_device_ms = main_ms;
@@ -847,7 +950,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
     ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : plan.kernel_name.c_str());
+    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : plan.kernel_name.c_str());
   };
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe

@@ -899,6 +899,9 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (P.W > 0)
       s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_wide(KArgs a, AggLaunch L) { qh_filter_agg_body<P, " << (dev_rows ? "true" : "false")
         << ", 1024>(a, L); }\n";
+    // ... and over an input pre-partitioned by key hash, one part per workgroup (AggLaunch::part_runs; agg.cpp)
+    if (P.W > 0 && !dev_rows)
+      s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_parts(KArgs a, AggLaunch L) { qh_filter_agg_body<P, false, 1024, true>(a, L); }\n";
   }
   if (P.W > 0) {
     // the partitioned path for many groups on a big input (same policy, three more entry points of the same module)
@@ -1023,7 +1026,7 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
 }
 
 // ---------------------------------------------------------------- exchange, pass 2
-void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out) {
+void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out, bool unstable) {
   out = PartScatterPlan();
   if (widths.empty() || widths.size() > 8) fail(QHIP_INVALID_ARGUMENT, "partition scatter: 1 .. 8 columns per launch");
   auto T = [](int w) { return w == 1 ? "u8" : w == 2 ? "u16" : (w == 4 || w == 0) ? "u32" : w == 8 ? "u64" : "qh_v4u"; };
@@ -1037,7 +1040,7 @@ void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& 
   const bool direct = env_int("QHIP_PART_SCATTER_DIRECT", 0) != 0, no_stores = env_int("QHIP_PART_SCATTER_NOSTORE", 0) != 0;
   const bool nt_store = env_int("QHIP_PART_SCATTER_NT", 0) != 0;
   const int tb = std::max(256, std::min(1024, env_int("QHIP_PART_SCATTER_TB", 512))) / 64 * 64;
-  s << "struct P {\n  static constexpr int TB = " << tb << ";\n  static constexpr int NC = " << widths.size() << ", R = " << R << ", NPT = " << (n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0)
+  s << "struct P {\n  static constexpr int TB = " << tb << ";\n  static constexpr int NC = " << widths.size() << ", R = " << R << ", NPT = " << (unstable ? -1 : n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0)
     << ", MAXW = " << maxw << ", DIRECT = " << (direct ? 1 : 0) << ", PIPE = " << (env_int("QHIP_PART_SCATTER_PIPE", 1) != 0 ? 1 : 0) << ";\n";
   s << "  struct Vals {\n";
   for (size_t c = 0; c < widths.size(); ++c) s << "    " << T(widths[c]) << " c" << c << "[R];\n";

@@ -132,7 +132,8 @@ void plan_keys(const ExprSet& es, const std::vector<InputCol>& input, const int3
 // widths[c]: bytes per value of column c (1, 2, 4, 8, 16), 0 = the row number itself as u32 (the parts' selection vector);
 // indirect[c]: the column is read through an index vector; n_parts picks the ranking variant (<= 8, <= 16, more)
 struct PartScatterPlan { std::string source; std::string kernel_name; int rows_per_lane = 4; int wg_threads = 512; /* qk_part_scatter_wg's workgroup */ };
-void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out);
+// unstable: the order of the rows inside a part is free (ranks from returning DS atomics: cheap for many parts)
+void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& indirect, int n_parts, bool dev_rows, PartScatterPlan& out, bool unstable = false);
 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };

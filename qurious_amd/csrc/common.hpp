@@ -246,6 +246,10 @@ struct Ctx {
   // (verify_pending_sizes): more pairs than the capacity / duplicate build keys -> the hint is dropped and the consumer
   // returns QHIP_RETRY (its input is re-executed, this time waiting).
   std::unordered_map<uint64_t, uint64_t> join_size_hints;
+  // groups an aggregate (identified by its expressions, whatever its input's layout) produced the last time it ran, and the words
+  // of its table slots: decide whether a mid-sized input is ordered by key hash first (agg.cpp, AggParts)
+  std::unordered_map<uint64_t, uint32_t> agg_group_hints;
+  std::unordered_map<uint64_t, int> agg_slot_words;
   // (total_out: the output table's own host word — the page-locked slot is part of a ring and is reused by later joins, so
   // the verified total is copied where the table can still find it however long it stays unsettled)
   struct PendingSize { uint32_t* slot; uint64_t key; uint64_t capacity; uint64_t dup_hint; std::shared_ptr<uint64_t> total_out; };

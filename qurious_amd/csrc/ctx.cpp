@@ -392,6 +392,8 @@ int qhip_ctx_forget_plans(qhip_ctx* ctx) {
     ctx->plan_cache.clear();
     ctx->join_size_hints.clear();
     ctx->join_dup_builds.clear();
+    ctx->agg_group_hints.clear();
+    ctx->agg_slot_words.clear();
     ctx->pending_sizes.clear();
   });
 }

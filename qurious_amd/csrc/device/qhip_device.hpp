@@ -231,6 +231,12 @@ __device__ __forceinline__ u32 qh_wave_or_u32(u32 x) {
   x |= qh_dpp0<0x143, 0xc>(x);
   return qh_readlane32(x, 63);
 }
+// inclusive prefix sum over the lanes of the wavefront
+__device__ __forceinline__ u32 qh_wave_incl_scan_u32(u32 v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)v, d, 64); if (lane >= d) v += t; }
+  return v;
+}
 __device__ __forceinline__ u64 qh_shfl_xor64(u64 v, int m) {
   u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
   return ((u64)hi << 32) | lo;
@@ -387,6 +393,15 @@ struct AggLaunch {
   u32 replicas;     // workgroup b uses replica b % replicas (few groups: spreads the end-of-kernel merge of ~1000
                     // workgroups over many cache lines instead of one slot per group; the host merges replicas)
   u32 collect_stats;  // != 0: every workgroup adds its count of occupied LDS slots to status[QS_LDS_USED]
+  // PARTS form (qh_filter_agg_body<.., PARTS = true>: the input was split by key hash, one part per workgroup — the groups of
+  // two workgroups are disjoint): workgroup p takes rows [part_runs[p * part_stride], part_runs[(p + 1) * part_stride]) and
+  // APPENDS its LDS table's groups to dense_out (one atomic per workgroup on dense_counter) instead of merging them into the
+  // HBM table with a find-or-insert and the cells' atomics per group
+  const u32* part_runs;
+  u64* dense_out;
+  u32* dense_counter;
+  u32 part_stride, dense_cap;
+  u32 n_parts, part_max;   // parts (<= 255); rows a workgroup takes of one part before the part is sliced
 };
 
 template <class P, class M>
@@ -441,7 +456,11 @@ __device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& 
 // TB: threads per workgroup — 256 (QH_BLOCK), or 1024 for the one-workgroup-per-CU shape of mid-sized many-group inputs
 // (qk_filter_agg_wide: sixteen wavefronts share ONE LDS table of up to 128 KB, so the chains of dependent loads and table
 // updates of four times as many rows overlap while the number of end-of-kernel merges stays that of one table per CU)
-template <class P, bool DEVROWS = false, int TB = QH_BLOCK>
+// PARTS: see AggLaunch. The rows of a mid-sized many-group input are first ordered by key hash into as many parts as there
+// are workgroups (the exchange's partition kernels over the row numbers, agg.cpp); what made that size slow was the END of the
+// kernel — every workgroup merging its few thousand LDS groups into the shared HBM table, ~9 memory-side operations per
+// (workgroup, group), a group living in as many workgroups as it has rows — and the rows that found their LDS table full.
+template <class P, bool DEVROWS = false, int TB = QH_BLOCK, bool PARTS = false>
 __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
   constexpr int R = P::R;
@@ -471,9 +490,58 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   u64 seen_pass = 0, seen_hits = 0;
 
   const i64 tile_rows = (i64)TB * R;
-  const i64 nrows_dr = DEVROWS ? qh_rows(a) : 0;
-#define QH_NROWS (DEVROWS ? nrows_dr : a.nrows)
-  const i64 ntiles = (QH_NROWS + tile_rows - 1) / tile_rows;
+  // PARTS: workgroup p < n_parts takes part p — or, when the part holds more than part_max rows (a heavy key's part: hashing
+  // sends every row of one key to one part), its first part_max rows; the rest of such a part is cut into slices of part_max
+  // rows for the workgroups behind the first n_parts (at most rows / part_max of them in all). The slices of one part share
+  // their groups, so THEY merge into the HBM table like the unpartitioned kernel; everybody else appends.
+  i64 part_lo = 0, part_hi = 0;
+  bool part_shared = false;
+  if (PARTS) {
+    const u32 np = L0.n_parts, pmax = L0.part_max;
+    if (blockIdx.x < np) {
+      part_lo = (i64)L0.part_runs[(size_t)blockIdx.x * L0.part_stride];
+      part_hi = (i64)L0.part_runs[(size_t)(blockIdx.x + 1) * L0.part_stride];
+      part_shared = part_hi - part_lo > (i64)pmax;
+      if (part_shared) part_hi = part_lo + (i64)pmax;
+    } else {
+      // slice j of the oversized parts, in part order: every wavefront finds it with one scan over the parts' sizes
+      const u32 j = blockIdx.x - np;
+      u32 ext[4], first[4], lo4[4], n4[4];
+      u32 mine = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 p = (u32)lane * 4u + (u32)k;
+        lo4[k] = p < np ? L0.part_runs[(size_t)p * L0.part_stride] : 0u;
+        n4[k] = p < np ? L0.part_runs[(size_t)(p + 1) * L0.part_stride] - lo4[k] : 0u;
+        ext[k] = n4[k] ? (n4[k] - 1u) / pmax : 0u;
+        first[k] = mine;
+        mine += ext[k];
+      }
+      const u32 before = qh_wave_incl_scan_u32(mine, lane) - mine;
+      u32 found_lo = 0, found_hi = 0;
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 f = before + first[k];
+        if (j >= f && j < f + ext[k]) {
+          const u32 sl = j - f + 1u;
+          found_lo = lo4[k] + sl * pmax;
+          const u32 end = lo4[k] + n4[k];
+          found_hi = found_lo + pmax < end ? found_lo + pmax : end;
+          found = true;
+        }
+      }
+      const u64 who = qh_ballot(found);
+      if (!who) return;   // (workgroup-uniform: every wavefront scans the same sizes)
+      const int src = __builtin_ctzll(who);
+      part_lo = (i64)qh_readlane32(found_lo, src);
+      part_hi = (i64)qh_readlane32(found_hi, src);
+      part_shared = true;
+    }
+  }
+  const i64 nrows_dr = PARTS ? part_hi : DEVROWS ? qh_rows(a) : 0;
+#define QH_NROWS ((DEVROWS || PARTS) ? nrows_dr : a.nrows)
+  const i64 ntiles = PARTS ? (part_hi - part_lo + tile_rows - 1) / tile_rows : (QH_NROWS + tile_rows - 1) / tile_rows;
   // phase timers (P::PROF, measurements only): cycles per wavefront in [0] loads + evaluation, [1] hot-key cache, [2] table
   // updates of a tile, [3] cached keys -> table at the end, [4] LDS table -> HBM table; summed into status words 8..12
   u64 prof[5] = {0, 0, 0, 0, 0};
@@ -490,10 +558,10 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     const bool inb = (TBASE) + (i64)o < (NROWS);                            \
     P::load(a, (TBASE), inb ? o : (u32)((NROWS) - 1 - (TBASE)), RAW[r]);    \
   }
-  if (P::PIPE == 0) {
-    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  if (P::PIPE == 0 || PARTS) {
+    for (i64 t = PARTS ? 0 : blockIdx.x; t < ntiles; t += PARTS ? 1 : gridDim.x) {
       const u32 overflowed = QH_OVERFLOWED();
-      const i64 tb = t * tile_rows;
+      const i64 tb = part_lo + t * tile_rows;
       typename P::Raw raw[R];
       QH_ISSUE(raw, tb, QH_NROWS)
 #define QH_TILE_RAW raw
@@ -568,6 +636,35 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
   }
   // ---- merge this workgroup's LDS table into the HBM table
   __syncthreads();
+  if (PARTS && !part_shared) {
+    // nobody else holds these groups: the ready slots go out as they are, behind ONE reservation per workgroup
+    __shared__ u32 wsum[TB / 64 + 1];
+    __shared__ u32 wg_base;
+    u32 mine = 0;
+    for (u32 s0 = tid; s0 < L.l_nslots; s0 += TB) mine += ltable[(size_t)s0 * P::SLOT_WORDS] == QH_READY ? 1u : 0u;
+    const u32 incl = qh_wave_incl_scan_u32(mine, lane);
+    if (lane == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      u32 all = 0;
+      for (int w = 0; w < TB / 64; ++w) { const u32 c = wsum[w]; wsum[w] = all; all += c; }
+      wg_base = all ? atomicAdd(L.dense_counter, all) : 0u;
+    }
+    __syncthreads();
+    u32 at = wg_base + wsum[tid >> 6] + (incl - mine);
+    for (u32 s0 = tid; s0 < L.l_nslots; s0 += TB) {
+      const u64* ls = ltable + (size_t)s0 * P::SLOT_WORDS;
+      if (ls[0] == QH_READY) {
+        if (at < L.dense_cap) {
+          u64* o = L.dense_out + (size_t)at * P::SLOT_WORDS;
+#pragma unroll
+          for (int k = 0; k < P::SLOT_WORDS; ++k) o[k] = ls[k];
+        }
+        ++at;
+      }
+    }
+    return;
+  }
   u32 used = qh_merge_lds_table<P, TB>(ltable, L);
   QH_PROF_MARK(4)
   if (P::PROF && lane == 0) {
@@ -1026,18 +1123,31 @@ struct PartScatterLaunch {
   const u32* idx[QH_PART_MAXC];    // ... read through this index vector where the policy says so (a deferred gather never materialised)
   void* out[QH_PART_MAXC];
 };
-__device__ __forceinline__ u32 qh_wave_incl_scan_u32(u32 v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const u32 t = (u32)__shfl_up((int)v, d, 64); if (lane >= d) v += t; }
-  return v;
-}
 // ranks of a tile's rows inside their parts (q), the tile's first position per part (s_tf), rows in the tile (total) and the
 // count this lane is responsible for when the running positions advance (cnt4: NPT > 0: part `lane`; NPT = 0: parts 4 lane ..)
+// (NPT < 0: up to 255 parts, UNSTABLE — a row's rank inside its part is what a returning DS atomic on the part's counter hands
+// out, 64 cycles per 64 rows where the stable walk over the distinct parts costs up to 64 trips; for consumers that do not care
+// about the order inside a part: the aggregate's pre-partitioning, agg.cpp)
 template <int NPT, int R>
 __device__ __forceinline__ void qh_part_rank(const u32 (&id)[R], u32 (&q)[R], u32& total, u32 (&cnt4)[4], u32* s_tf, const u32 np, const int lane) {
   total = 0;
   cnt4[0] = cnt4[1] = cnt4[2] = cnt4[3] = 0;
-  if (NPT > 0) {
+  if (NPT < 0) {
+    for (u32 p = (u32)lane; p < np; p += 64) s_tf[p] = 0;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] = id[r] != 0xFFu ? atomicAdd(&s_tf[id[r]], 1u) : 0u;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; cnt4[k] = p < np ? s_tf[p] : 0u; }
+    const u32 mine = cnt4[0] + cnt4[1] + cnt4[2] + cnt4[3];
+    const u32 incl = qh_wave_incl_scan_u32(mine, lane);
+    total = qh_readlane32(incl, 63);
+    u32 at = incl - mine;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u32 p = (u32)lane * 4u + (u32)k; if (p < np) s_tf[p] = at; at += cnt4[k]; }
+  } else if (NPT > 0) {
     u32 run[NPT > 0 ? NPT : 1];
 #pragma unroll
     for (int p = 0; p < NPT; ++p) run[p] = 0;

@@ -91,6 +91,9 @@ void partition_by_key(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, in
   flush();
 }
 
+}  // namespace
+
+namespace qhip {
 // ---- the fused path (round 4): scan filter + key -> part byte per row + per-wavefront histogram (qk_part_ids, generated) ->
 // scan -> ONE host wait (the parts' sizes + the status words) -> k_part_scatter moves only the columns `keep` names, each into
 // ONE buffer over all parts; a part's column is a slice (view) of it. Columns the scatter kernel cannot move itself
@@ -104,14 +107,6 @@ bool scatter_wg_form(int64_t rows) {
   return env_int("QHIP_PART_SCATTER_JIT", 1) != 0 && (wg_mode == 2 || (wg_mode == 1 && rows >= (1 << 20)));
 }
 
-struct PartitionWork {       // what pass 1 leaves on the device for pass 2
-  DevBuf trash{2048};        // where pass 2's unconditional stores of a tile without rows go
-  DevBuf ids, runs, starts;  // part byte per row | scanned hist [n_parts * n_units] + total | the parts' first positions (n_parts + 1)
-  uint32_t n_units = 0, rows_per_unit = 0;
-  bool wg_units = false;     // a unit is a workgroup of pass 1 (pass 2 then runs its workgroup form)
-  uint32_t* dstat = nullptr;
-  double pass1_bytes_per_row = 0;   // column bytes the filter + key expressions read per row
-};
 
 void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
                      int n_parts, PartitionWork& w) {
@@ -200,11 +195,10 @@ void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int
   launch_gather_stride_u32(w.runs.as<uint32_t>(), w.n_units, (uint32_t)n_parts + 1, w.starts.as<uint32_t>(), s);   // (entry n_parts = the scan's total)
 }
 
-struct MovedColumn { size_t col; std::shared_ptr<DevBuf> out; int width; };   // a column's values of all parts, part after part
 // pass 2's launches: the plain kept columns into `moved` (one buffer each over all parts), the others listed in `odd` with the
 // parts' selection vector in `sel` (the caller gathers them per part)
 void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, uint64_t total,
-                       std::vector<MovedColumn>& moved, std::vector<size_t>& odd, std::shared_ptr<DevBuf>& sel) {
+                       std::vector<MovedColumn>& moved, std::vector<size_t>& odd, std::shared_ptr<DevBuf>& sel, bool rows_only) {
   hipStream_t s = ctx->stream;
   typedef MovedColumn Moved;
   // one generated kernel per group of columns (qh_part_scatter_body: the registers of two tiles' values bound the group: <= 48
@@ -222,7 +216,7 @@ void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int 
       if (jit) {
         std::vector<int> widths; std::vector<char> ind;
         for (auto& g : group) { widths.push_back(g.src || g.width != 4 ? g.width : 0); ind.push_back(g.idx ? 1 : 0); }
-        std::string key = "part_scatter|" + std::to_string(n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0) + (in->rows_dev ? "|d" : "|h");
+        std::string key = "part_scatter|" + std::to_string(rows_only ? -1 : n_parts <= 8 ? 8 : n_parts <= 16 ? 16 : 0) + (in->rows_dev ? "|d" : "|h");
         for (size_t k = 0; k < widths.size(); ++k) key += "|" + std::to_string(widths[k]) + (ind[k] ? "i" : "");
         struct ScatterPlan { PartScatterPlan sp; std::shared_ptr<Module> mod, mod_wg; };
         std::shared_ptr<ScatterPlan> sp;
@@ -230,7 +224,7 @@ void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int 
         if (cached != ctx->plan_cache.end()) sp = std::static_pointer_cast<ScatterPlan>(cached->second);
         else {
           sp = std::make_shared<ScatterPlan>();
-          plan_part_scatter(widths, ind, n_parts, in->rows_dev != nullptr, sp->sp);
+          plan_part_scatter(widths, ind, n_parts, in->rows_dev != nullptr, sp->sp, rows_only);
           sp->mod = get_module(ctx, sp->sp.source, sp->sp.kernel_name);
           ctx->plan_cache[key] = sp;
         }
@@ -273,7 +267,7 @@ void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int 
     group.push_back(Pending{src, idx, out, width});
     group_bytes += width;
   };
-  for (size_t c = 0; c < in->cols.size(); ++c) {
+  for (size_t c = 0; c < in->cols.size() && !rows_only; ++c) {
     const DevColumn& c0 = in->cols[c];
     if ((keep && !keep[c]) || c0.type.id == QHIP_NULL) continue;
     const int width = dtype_width(c0.type);
@@ -290,8 +284,10 @@ void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int 
       moved.push_back(Moved{c, out, width});
     } else odd.push_back(c);
   }
-  if (!odd.empty()) {
+  if (!odd.empty() || rows_only) {
     sel = std::make_shared<DevBuf>(((size_t)total + 1) * 4);
+    // (rows_only: the consumer reads sel[0 .. capacity) before it knows the row count: no garbage row numbers behind the parts)
+    if (rows_only) QHIP_HIP_CHECK(hipMemsetAsync(sel->ptr, 0, sel->bytes, s));
     push(nullptr, nullptr, sel->ptr, 4);   // (no source: the row number itself)
   }
   flush();
@@ -299,6 +295,9 @@ void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int 
   time_mark(ctx, 3);
 }
 
+}  // namespace qhip
+
+namespace {
 // the parts' tables from the parts' first positions (host copy of PartitionWork::starts): pass 2 + the gathers of the odd columns
 void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, const uint32_t* starts,
                      qhip_table** out_parts) {
@@ -306,7 +305,7 @@ void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_
   std::vector<Moved> moved;
   std::vector<size_t> odd;   // columns gathered per part through the selection vector
   std::shared_ptr<DevBuf> sel;
-  partition_scatter(ctx, in, keep, n_parts, w, starts[n_parts], moved, odd, sel);
+  partition_scatter(ctx, in, keep, n_parts, w, starts[n_parts], moved, odd, sel, false);
   for (int p = 0; p < n_parts; ++p) {
     std::unique_ptr<qhip_table> t(new qhip_table());
     t->ctx = ctx;
@@ -940,7 +939,7 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
     std::vector<MovedColumn> moved;
     std::vector<size_t> odd;
     std::shared_ptr<DevBuf> sel;
-    partition_scatter(ctx, sd.in, sd.keep.data(), sd.np, sd.w, starts[(size_t)sd.np], moved, odd, sel);
+    partition_scatter(ctx, sd.in, sd.keep.data(), sd.np, sd.w, starts[(size_t)sd.np], moved, odd, sel, false);
     if (!odd.empty()) fail(QHIP_HIP_ERROR, "qhip_shuffle_tables: a column needs a gather of its own (internal error)");
     // rows every rank sends here, in rank order
     std::vector<int64_t> from((size_t)W), at((size_t)W + 1, 0);

@@ -33,8 +33,13 @@ struct HAggLaunch {
   uint32_t* status;
   uint32_t replicas;
   uint32_t collect_stats;
+  const uint32_t* part_runs = nullptr;   // PARTS form (qk_filter_agg_parts)
+  uint64_t* dense_out = nullptr;
+  uint32_t* dense_counter = nullptr;
+  uint32_t part_stride = 0, dense_cap = 0;
+  uint32_t n_parts = 0, part_max = 0;
 };
-static_assert(sizeof(HAggLaunch) == 32, "AggLaunch layout");
+static_assert(sizeof(HAggLaunch) == 72, "AggLaunch layout");
 
 // host mirrors of PartLaunch / ReduceLaunch (the aggregate's partitioned path)
 struct HPartLaunch {

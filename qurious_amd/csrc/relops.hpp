@@ -56,4 +56,21 @@ void eval_key_words(Ctx* ctx, const qhip_table* t, const ExprSet& es, const std:
                     KeysPlan& kp, DevBuf& keys, DevBuf& keyvalid, int predicate_root = -1, bool deferred_status = false,
                     uint32_t* status_dev = nullptr);   // (status words: the context's block unless the caller keeps its own)
 
+// exchange.cpp — the two streaming passes of the fused filter + partition (qhip_partition_filtered), also used by the aggregate's
+// pre-partitioning (agg.cpp): pass 1 = scan filter + key -> part byte per row + scanned (part, unit) counters; partition_scatter
+// = pass 2's launches for the kept columns (rows_only: nothing but the parts' selection vector, ranks in any order)
+struct PartitionWork {       // what pass 1 leaves on the device for pass 2
+  DevBuf trash{2048};        // where pass 2's unconditional stores of a tile without rows go
+  DevBuf ids, runs, starts;  // part byte per row | scanned hist [n_parts * n_units] + total | the parts' first positions (n_parts + 1)
+  uint32_t n_units = 0, rows_per_unit = 0;
+  bool wg_units = false;     // a unit is a workgroup of pass 1 (pass 2 then runs its workgroup form)
+  uint32_t* dstat = nullptr;
+  double pass1_bytes_per_row = 0;   // column bytes the filter + key expressions read per row
+};
+struct MovedColumn { size_t col; std::shared_ptr<DevBuf> out; int width; };   // a column's values of all parts, part after part
+void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
+                     int n_parts, PartitionWork& w);
+void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, uint64_t total,
+                       std::vector<MovedColumn>& moved, std::vector<size_t>& odd, std::shared_ptr<DevBuf>& sel, bool rows_only);
+
 }  // namespace qhip

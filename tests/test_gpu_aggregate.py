@@ -322,3 +322,56 @@ def test_wide_workgroups_for_mid_sized_many_group_inputs(ctx, monkeypatch):
             assert row[0][6] == (decimal.Decimal(int(d_raw[md].max())).scaleb(-2) if md.any() else None)
             assert row[0][7] == (decimal.Decimal(int(d_raw[md].min())).scaleb(-2) if md.any() else None)
             assert row[0][8] == (decimal.Decimal(int(d_raw[md].sum())).scaleb(-2) if md.any() else None)
+
+
+def test_prepartitioned_aggregate_of_mid_sized_many_group_inputs(ctx, oracle, monkeypatch):
+    """Round 4 (csrc/agg.cpp AggParts): a mid-sized input with many groups is ordered by key hash into one part per workgroup
+    first (the exchange's partition passes over the row numbers), every part is aggregated in its workgroup's LDS table alone
+    and appended to the result — nothing merged into the HBM table; a part holding a heavy key is sliced and its slices merge
+    like the unpartitioned kernel. Forced on small inputs here: every cell kind, NULL keys and values, Utf8 + Int64 keys, heavy
+    keys next to a long tail (sliced parts), a single group, more groups than the parts' LDS tables hold; then the automatic
+    choice on 2 M rows -> 200 k groups."""
+    import decimal
+    monkeypatch.setenv("QHIP_AGG_PARTS", "2")
+    rng = np.random.default_rng(43)
+    n = 260_000
+    heavy = rng.random(n) < 0.4
+    k = np.where(heavy, rng.integers(0, 3, n), rng.integers(0, 100_000, n))
+    schema = pa.schema([pa.field("k", I64), pa.field("s", pa.string()), pa.field("v", I64), pa.field("d", pa.decimal128(15, 2)), pa.field("f", pa.float64())])
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(k, type=I64, mask=rng.random(n) < 0.02),
+        pa.array(["g%d" % v for v in rng.integers(0, 7, n)], type=pa.string(), mask=rng.random(n) < 0.02),
+        pa.array(rng.integers(-10**9, 10**9, n), type=I64, mask=rng.random(n) < 0.1),
+        pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**10, 10**10, n)], type=pa.decimal128(15, 2), mask=rng.random(n) < 0.1),
+        pa.array(rng.integers(-1000, 1000, n).astype(np.float64), type=pa.float64(), mask=rng.random(n) < 0.1)], schema=schema)
+    scan = table_scan(schema, [batch.slice(0, 100_000), batch.slice(100_000, 0), batch.slice(100_000)])
+    D = pa.decimal128(15, 2)
+    aggs = [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(col("v", 2)), q.CountAggregateExpr(lit_i64(1)),
+            q.MinAggregateExpr(col("v", 2), I64), q.MaxAggregateExpr(col("d", 3), D), q.SumAggregateExpr(col("d", 3), D),
+            q.AvgAggregateExpr(col("d", 3), D, pa.decimal128(19, 6)), q.SumAggregateExpr(col("f", 4), pa.float64()),
+            q.MinAggregateExpr(col("f", 4), pa.float64())]
+    plan = q.HashAggregate(None, scan, [col("k", 0)], aggs)
+    for _ in range(3):   # (the third execution knows the groups: as many parts as the LDS tables need, heavy parts sliced)
+        got = _same(plan, oracle)
+        assert "qk_filter_agg_parts" in ctx.last_stats()["main_kernel_name"]
+    assert len(got) > 70_000
+    _same(q.HashAggregate(None, scan, [col("k", 0), col("s", 1)], aggs[:4]), oracle)
+    _same(q.HashAggregate(None, scan, [col("s", 1)], aggs), oracle)                      # 8 groups: every part but a few empty
+    one = pa.RecordBatch.from_arrays([pa.array(np.zeros(5000, dtype=np.int64)), pa.array(np.arange(5000, dtype=np.int64))], names=["k", "v"])
+    _same(q.HashAggregate(None, table_scan(one.schema, [one]), [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64)]), oracle)
+    # the automatic choice: 2 M rows of plain columns that produced 200 k groups last time
+    monkeypatch.delenv("QHIP_AGG_PARTS")
+    m = 2_000_000
+    kk = rng.integers(0, 200_000, m)
+    vv = rng.integers(0, 100, m)
+    big = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+    bscan = table_scan(big, [pa.RecordBatch.from_arrays([pa.array(kk, type=I64), pa.array(vv, type=I64)], schema=big)])
+    bplan = q.HashAggregate(None, bscan, [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64), q.CountAggregateExpr(lit_i64(1))])
+    first = sorted(rows_of(bplan.execute()))
+    assert "parts" not in ctx.last_stats()["main_kernel_name"]
+    second = sorted(rows_of(bplan.execute()))
+    assert "qk_filter_agg_parts" in ctx.last_stats()["main_kernel_name"]
+    assert first == second
+    cnt = np.bincount(kk, minlength=200_000)
+    sm = np.bincount(kk, weights=vv, minlength=200_000)
+    assert [(r[0], r[1], r[2]) for r in first] == [(int(g), int(sm[g]), int(cnt[g])) for g in np.nonzero(cnt)[0]]
