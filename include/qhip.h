@@ -92,7 +92,11 @@ typedef enum qhip_type_id {
   QHIP_UTF8 = 15,
   /* Time32(Second | Millisecond) = i32, Time64(Microsecond | Nanosecond) = i64: key / comparison / MIN-MAX types of
      create_hashes (utils/array.rs:199-202); no arithmetic and no casts are defined on them here */
-  QHIP_TIME32_S = 16, QHIP_TIME32_MS = 17, QHIP_TIME64_US = 18, QHIP_TIME64_NS = 19
+  QHIP_TIME32_S = 16, QHIP_TIME32_MS = 17, QHIP_TIME64_US = 18, QHIP_TIME64_NS = 19,
+  /* Timestamp(Second | Millisecond | Microsecond | Nanosecond, None) = i64: comparison / MIN-MAX / sort-key types
+     (aggregate/mod.rs:108-111); NOT hash keys — the reference's create_hashes rejects them (utils/array.rs:205) and so does
+     this library, with the reference's error text. A timezone-qualified timestamp column is QHIP_UNSUPPORTED at upload. */
+  QHIP_TIMESTAMP_S = 20, QHIP_TIMESTAMP_MS = 21, QHIP_TIMESTAMP_US = 22, QHIP_TIMESTAMP_NS = 23
 } qhip_type_id;
 
 typedef struct qhip_dtype {

@@ -36,6 +36,7 @@ static int type_width(int id) {
     case QHIP_INT16: case QHIP_UINT16: return 2;
     case QHIP_INT32: case QHIP_UINT32: case QHIP_FLOAT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return 4;
     case QHIP_INT64: case QHIP_UINT64: case QHIP_FLOAT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return 8;
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return 8;   /* aggregate/mod.rs:108-111 */
     case QHIP_DECIMAL128: return 16;
     default: return 0;
   }
@@ -177,6 +178,7 @@ static i128 get_int(const qo_col* c, int64_t i) {
     case QHIP_INT16: return ((const int16_t*)c->values)[i];
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return ((const int32_t*)c->values)[i];
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return ((const int64_t*)c->values)[i];
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return ((const int64_t*)c->values)[i];
     case QHIP_UINT8: return ((const uint8_t*)c->values)[i];
     case QHIP_UINT16: return ((const uint16_t*)c->values)[i];
     case QHIP_UINT32: return ((const uint32_t*)c->values)[i];
@@ -197,6 +199,7 @@ static void put_int(qo_col* c, int64_t i, i128 v) {
     case QHIP_INT16: ((int16_t*)c->values)[i] = (int16_t)v; break;
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: ((int32_t*)c->values)[i] = (int32_t)v; break;
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: ((int64_t*)c->values)[i] = (int64_t)v; break;
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: ((int64_t*)c->values)[i] = (int64_t)v; break;
     case QHIP_UINT8: ((uint8_t*)c->values)[i] = (uint8_t)v; break;
     case QHIP_UINT16: ((uint16_t*)c->values)[i] = (uint16_t)v; break;
     case QHIP_UINT32: ((uint32_t*)c->values)[i] = (uint32_t)v; break;
@@ -212,6 +215,7 @@ static void int_limits(int id, i128* lo, i128* hi) {
     case QHIP_INT16: *lo = -32768; *hi = 32767; break;
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: *lo = INT32_MIN; *hi = INT32_MAX; break;
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: *lo = INT64_MIN; *hi = INT64_MAX; break;
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: *lo = INT64_MIN; *hi = INT64_MAX; break;
     case QHIP_UINT8: *lo = 0; *hi = 255; break;
     case QHIP_UINT16: *lo = 0; *hi = 65535; break;
     case QHIP_UINT32: *lo = 0; *hi = UINT32_MAX; break;

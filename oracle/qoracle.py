@@ -127,7 +127,8 @@ def siphash13_chunks(chunks: Sequence[bytes]) -> int:
 _NP = {pa.int8(): np.int8, pa.int16(): np.int16, pa.int32(): np.int32, pa.int64(): np.int64, pa.uint8(): np.uint8,
        pa.uint16(): np.uint16, pa.uint32(): np.uint32, pa.uint64(): np.uint64, pa.float32(): np.float32,
        pa.float64(): np.float64, pa.date32(): np.int32, pa.date64(): np.int64, pa.time32("s"): np.int32, pa.time32("ms"): np.int32,
-       pa.time64("us"): np.int64, pa.time64("ns"): np.int64}
+       pa.time64("us"): np.int64, pa.time64("ns"): np.int64, pa.timestamp("s"): np.int64, pa.timestamp("ms"): np.int64,
+       pa.timestamp("us"): np.int64, pa.timestamp("ns"): np.int64}
 
 
 class Col:
@@ -226,7 +227,8 @@ def _result_type(arr: pa.Array, c: qo_col) -> pa.DataType:
              D.T_UINT8: pa.uint8(), D.T_UINT16: pa.uint16(), D.T_UINT32: pa.uint32(), D.T_UINT64: pa.uint64(),
              D.T_FLOAT32: pa.float32(), D.T_FLOAT64: pa.float64(), D.T_DATE32: pa.date32(), D.T_DATE64: pa.date64(),
              D.T_UTF8: pa.string(), D.T_NULL: pa.null(), D.T_TIME32_S: pa.time32("s"), D.T_TIME32_MS: pa.time32("ms"),
-             D.T_TIME64_US: pa.time64("us"), D.T_TIME64_NS: pa.time64("ns")}
+             D.T_TIME64_US: pa.time64("us"), D.T_TIME64_NS: pa.time64("ns"), D.T_TIMESTAMP_S: pa.timestamp("s"),
+             D.T_TIMESTAMP_MS: pa.timestamp("ms"), D.T_TIMESTAMP_US: pa.timestamp("us"), D.T_TIMESTAMP_NS: pa.timestamp("ns")}
     if tid == D.T_DECIMAL128:
         return pa.decimal128(c.type.precision, c.type.scale)
     return table[tid]
@@ -494,7 +496,7 @@ def _dense_rank(arr: pa.Array) -> np.ndarray:
     decimals by value, floats by IEEE total order (`total_cmp`), Utf8 bytewise, false < true); NULL slots get 0."""
     t = arr.type
     n = len(arr)
-    valid = np.array([v is not None for v in arr.to_pylist()], dtype=bool) if arr.null_count else np.ones(n, dtype=bool)
+    valid = np.asarray(arr.is_valid().to_numpy(zero_copy_only=False), dtype=bool) if arr.null_count else np.ones(n, dtype=bool)   # (no to_pylist: a timestamp may lie outside datetime's range)
     if pa.types.is_floating(t):
         bits = np.asarray(arr.cast(pa.float64()).fill_null(0.0).to_numpy(zero_copy_only=False), dtype=np.float64).view(np.int64)
         keys = np.where(bits < 0, ~bits, bits | np.int64(-2**63)).view(np.uint64).astype(object)     # total order image
@@ -505,7 +507,7 @@ def _dense_rank(arr: pa.Array) -> np.ndarray:
         keys = np.array([(int(v.scaleb(sc)) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
     elif pa.types.is_boolean(t):
         keys = np.array([(int(v) if v is not None else 0) for v in arr.to_pylist()], dtype=object)
-    elif pa.types.is_date(t) or pa.types.is_time(t):
+    elif pa.types.is_date(t) or pa.types.is_time(t) or pa.types.is_timestamp(t):
         keys = np.array([0 if v is None else v for v in arr.cast(pa.int32() if (pa.types.is_date32(t) or pa.types.is_time32(t)) else pa.int64()).to_pylist()], dtype=object)
     elif pa.types.is_null(t):
         keys = np.zeros(n, dtype=object)

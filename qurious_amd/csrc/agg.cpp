@@ -499,7 +499,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
             if (ad.ret.id == QHIP_DECIMAL128) f.kind = F_MM_DEC;
             else if (ad.ret.id == QHIP_FLOAT64) f.kind = F_MM_F64;
             else if (ad.ret.id == QHIP_FLOAT32) f.kind = F_MM_F32;
-            else { f.kind = F_MM_INT; f.is_signed = dtype_is_signed(ad.ret) || ad.ret.id == QHIP_DATE32 || ad.ret.id == QHIP_DATE64 || (ad.ret.id >= QHIP_TIME32_S && ad.ret.id <= QHIP_TIME64_NS); }
+            else { f.kind = F_MM_INT; f.is_signed = dtype_is_signed(ad.ret) || ad.ret.id == QHIP_DATE32 || ad.ret.id == QHIP_DATE64 || (ad.ret.id >= QHIP_TIME32_S && ad.ret.id <= QHIP_TIMESTAMP_NS); }
         }
       }
       col.values = std::make_shared<DevBuf>(f.kind == F_KEY_UTF8_LEN ? ((size_t)cap_rows + 1) * 4 : (size_t)cap_rows * f.width);
@@ -1056,7 +1056,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
             }
           } else {
             uint64_t o = is_min ? ~vc[0] : vc[0];
-            const bool sgn = dtype_is_signed(t) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 || (t.id >= QHIP_TIME32_S && t.id <= QHIP_TIME64_NS);
+            const bool sgn = dtype_is_signed(t) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 || (t.id >= QHIP_TIME32_S && t.id <= QHIP_TIMESTAMP_NS);
             uint64_t raw = sgn ? (o ^ 0x8000000000000000ULL) : o;
             const int w = dtype_width(t);
             // no non-null value seen (an all-zero cell): the seed of the column's OWN type (i32::MAX, not i64::MAX truncated)

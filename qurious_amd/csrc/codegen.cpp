@@ -36,6 +36,7 @@ std::string ExprGen::ctype(const DType& t) {
     case QHIP_INT16: return "short";
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "int";
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "i64";
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return "i64";
     case QHIP_UINT8: return "u8";
     case QHIP_UINT16: return "u16";
     case QHIP_UINT32: return "u32";
@@ -56,7 +57,8 @@ std::string ExprGen::i128_const(i128 v) {
 
 // (Time32 / Time64 are signed integers as far as key words, MIN / MAX images and sort keys go; the typing in expr.cpp keeps
 // arithmetic and casts away from them)
-static bool timelike(const DType& t) { return t.id >= QHIP_TIME32_S && t.id <= QHIP_TIME64_NS; }
+// (... and so are the Timestamp types, which are not hash keys at all: check_key_type)
+static bool timelike(const DType& t) { return t.id >= QHIP_TIME32_S && t.id <= QHIP_TIMESTAMP_NS; }
 static bool intlike(const DType& t) {
   return (t.id >= QHIP_INT8 && t.id <= QHIP_UINT64) || t.id == QHIP_DATE32 || t.id == QHIP_DATE64 || timelike(t);
 }
@@ -67,6 +69,7 @@ static std::string int_min(const DType& t) {
     case QHIP_INT16: return "(-32768)";
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "(-2147483647-1)";
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "(-9223372036854775807LL-1)";
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return "(-9223372036854775807LL-1)";
     default: return "0";
   }
 }
@@ -76,6 +79,7 @@ static std::string int_max(const DType& t) {
     case QHIP_INT16: return "32767";
     case QHIP_INT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return "2147483647";
     case QHIP_INT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return "9223372036854775807LL";
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return "9223372036854775807LL";
     case QHIP_UINT8: return "255";
     case QHIP_UINT16: return "65535";
     case QHIP_UINT32: return "4294967295U";

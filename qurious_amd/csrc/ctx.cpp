@@ -116,6 +116,10 @@ std::string dtype_name(const DType& t) {
     case QHIP_TIME32_MS: return "Time32(Millisecond)";
     case QHIP_TIME64_US: return "Time64(Microsecond)";
     case QHIP_TIME64_NS: return "Time64(Nanosecond)";
+    case QHIP_TIMESTAMP_S: return "Timestamp(Second, None)";
+    case QHIP_TIMESTAMP_MS: return "Timestamp(Millisecond, None)";
+    case QHIP_TIMESTAMP_US: return "Timestamp(Microsecond, None)";
+    case QHIP_TIMESTAMP_NS: return "Timestamp(Nanosecond, None)";
     case QHIP_DECIMAL128: return "Decimal128(" + std::to_string(t.precision) + ", " + std::to_string(t.scale) + ")";
     case QHIP_UTF8: return "Utf8";
   }
@@ -128,6 +132,7 @@ int dtype_width(const DType& t) {
     case QHIP_INT16: case QHIP_UINT16: return 2;
     case QHIP_INT32: case QHIP_UINT32: case QHIP_FLOAT32: case QHIP_DATE32: case QHIP_TIME32_S: case QHIP_TIME32_MS: return 4;
     case QHIP_INT64: case QHIP_UINT64: case QHIP_FLOAT64: case QHIP_DATE64: case QHIP_TIME64_US: case QHIP_TIME64_NS: return 8;
+    case QHIP_TIMESTAMP_S: case QHIP_TIMESTAMP_MS: case QHIP_TIMESTAMP_US: case QHIP_TIMESTAMP_NS: return 8;
     case QHIP_DECIMAL128: return 16;
     default: return 0;
   }
@@ -156,6 +161,10 @@ std::string dtype_to_format(const DType& t) {
     case QHIP_TIME32_MS: return "ttm";
     case QHIP_TIME64_US: return "ttu";
     case QHIP_TIME64_NS: return "ttn";
+    case QHIP_TIMESTAMP_S: return "tss:";
+    case QHIP_TIMESTAMP_MS: return "tsm:";
+    case QHIP_TIMESTAMP_US: return "tsu:";
+    case QHIP_TIMESTAMP_NS: return "tsn:";
     case QHIP_DECIMAL128: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
     case QHIP_UTF8: return "u";
   }
@@ -182,6 +191,12 @@ DType dtype_from_format(const char* f) {
   if (s == "ttm") return DType(QHIP_TIME32_MS);
   if (s == "ttu") return DType(QHIP_TIME64_US);
   if (s == "ttn") return DType(QHIP_TIME64_NS);
+  if (s == "tss:") return DType(QHIP_TIMESTAMP_S);
+  if (s == "tsm:") return DType(QHIP_TIMESTAMP_MS);
+  if (s == "tsu:") return DType(QHIP_TIMESTAMP_US);
+  if (s == "tsn:") return DType(QHIP_TIMESTAMP_NS);
+  if (s.size() > 4 && s[0] == 't' && s[1] == 's' && s[3] == ':')
+    fail(QHIP_UNSUPPORTED, "timestamp columns with a timezone (" + s + ") are not supported by the HIP backend");
   if (s == "u") return DType(QHIP_UTF8);
   if (s.rfind("d:", 0) == 0) {
     int p = 0, sc = 0, bits = 128;

@@ -12,7 +12,8 @@ from . import _ffi
 
 # qhip_type_id
 (T_NULL, T_BOOL, T_INT8, T_INT16, T_INT32, T_INT64, T_UINT8, T_UINT16, T_UINT32, T_UINT64, T_FLOAT32, T_FLOAT64,
- T_DATE32, T_DATE64, T_DECIMAL128, T_UTF8, T_TIME32_S, T_TIME32_MS, T_TIME64_US, T_TIME64_NS) = range(20)
+ T_DATE32, T_DATE64, T_DECIMAL128, T_UTF8, T_TIME32_S, T_TIME32_MS, T_TIME64_US, T_TIME64_NS,
+ T_TIMESTAMP_S, T_TIMESTAMP_MS, T_TIMESTAMP_US, T_TIMESTAMP_NS) = range(24)
 
 _PA_TO_ID = [
     (pa.types.is_null, T_NULL), (pa.types.is_boolean, T_BOOL), (pa.types.is_int8, T_INT8), (pa.types.is_int16, T_INT16),
@@ -22,6 +23,11 @@ _PA_TO_ID = [
     (pa.types.is_decimal128, T_DECIMAL128), (pa.types.is_string, T_UTF8),
     (lambda t: pa.types.is_time32(t) and t.unit == "s", T_TIME32_S), (lambda t: pa.types.is_time32(t) and t.unit == "ms", T_TIME32_MS),
     (lambda t: pa.types.is_time64(t) and t.unit == "us", T_TIME64_US), (lambda t: pa.types.is_time64(t) and t.unit == "ns", T_TIME64_NS),
+    # Timestamp(unit, None): MIN / MAX / comparison / sort-key type (aggregate/mod.rs:108-111); a timezone-qualified one is unsupported
+    (lambda t: pa.types.is_timestamp(t) and t.tz is None and t.unit == "s", T_TIMESTAMP_S),
+    (lambda t: pa.types.is_timestamp(t) and t.tz is None and t.unit == "ms", T_TIMESTAMP_MS),
+    (lambda t: pa.types.is_timestamp(t) and t.tz is None and t.unit == "us", T_TIMESTAMP_US),
+    (lambda t: pa.types.is_timestamp(t) and t.tz is None and t.unit == "ns", T_TIMESTAMP_NS),
 ]
 
 

@@ -40,6 +40,10 @@ pub const QHIP_TIME32_S: i32 = 16;
 pub const QHIP_TIME32_MS: i32 = 17;
 pub const QHIP_TIME64_US: i32 = 18;
 pub const QHIP_TIME64_NS: i32 = 19;
+pub const QHIP_TIMESTAMP_S: i32 = 20;
+pub const QHIP_TIMESTAMP_MS: i32 = 21;
+pub const QHIP_TIMESTAMP_US: i32 = 22;
+pub const QHIP_TIMESTAMP_NS: i32 = 23;
 
 // ---------------------------------------------------------------- qhip_expr_kind
 pub const QHIP_EXPR_COLUMN: i32 = 0;

@@ -66,6 +66,11 @@ pub fn dtype_of(t: &DataType) -> HipResult<qhip_dtype> {
         DataType::Time32(TimeUnit::Millisecond) => QHIP_TIME32_MS,
         DataType::Time64(TimeUnit::Microsecond) => QHIP_TIME64_US,
         DataType::Time64(TimeUnit::Nanosecond) => QHIP_TIME64_NS,
+        // Timestamp(unit, None): MIN / MAX / comparison / sort keys (physical/expr/aggregate/mod.rs:108-111); with a timezone: CPU node
+        DataType::Timestamp(TimeUnit::Second, None) => QHIP_TIMESTAMP_S,
+        DataType::Timestamp(TimeUnit::Millisecond, None) => QHIP_TIMESTAMP_MS,
+        DataType::Timestamp(TimeUnit::Microsecond, None) => QHIP_TIMESTAMP_US,
+        DataType::Timestamp(TimeUnit::Nanosecond, None) => QHIP_TIMESTAMP_NS,
         DataType::Decimal128(p, s) => {
             return Ok(qhip_dtype { id: QHIP_DECIMAL128, precision: *p as i32, scale: *s as i32 });
         }

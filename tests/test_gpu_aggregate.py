@@ -359,8 +359,10 @@ def test_prepartitioned_aggregate_of_mid_sized_many_group_inputs(ctx, oracle, mo
     _same(q.HashAggregate(None, scan, [col("s", 1)], aggs), oracle)                      # 8 groups: every part but a few empty
     one = pa.RecordBatch.from_arrays([pa.array(np.zeros(5000, dtype=np.int64)), pa.array(np.arange(5000, dtype=np.int64))], names=["k", "v"])
     _same(q.HashAggregate(None, table_scan(one.schema, [one]), [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64)]), oracle)
-    # the automatic choice: 2 M rows of plain columns that produced 200 k groups last time
+    # the automatic choice: 2 M rows of plain columns that produced 200 k groups last time (what the context learnt about this
+    # aggregate — identified by its expressions — in earlier tests is forgotten first)
     monkeypatch.delenv("QHIP_AGG_PARTS")
+    ctx.forget_plans()
     m = 2_000_000
     kk = rng.integers(0, 200_000, m)
     vv = rng.integers(0, 100, m)

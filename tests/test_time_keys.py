@@ -120,3 +120,77 @@ def test_unsupported_operations_on_time_types_are_errors(engine):
     plan = q.Projection(None, table_scan(schema, [batch]), [q.BinaryExpr(col("a", 0), Operator.Add, col("b", 1))])
     with pytest.raises(Exception):
         engine.execute(plan)
+
+
+# ---------------------------------------------------------------- Timestamp(unit, None): MIN / MAX / comparison / sort keys
+# aggregate/mod.rs:108-111 lists the four Timestamp units among the PrimitiveAccumulator types (i64 storage); create_hashes
+# (utils/array.rs:190-205) does NOT — a Timestamp GROUP BY / join key is the reference's "Unsupported data type in hasher".
+TS_TYPES = [pa.timestamp("s"), pa.timestamp("ms"), pa.timestamp("us"), pa.timestamp("ns")]
+
+
+def _ts_array(storage_values, valid, ttype):
+    return pa.array(np.asarray(storage_values), type=pa.int64(), mask=~np.asarray(valid)).cast(ttype)
+
+
+@pytest.mark.parametrize("ttype", TS_TYPES, ids=[str(t) for t in TS_TYPES])
+def test_min_max_over_timestamp_columns(engine, ttype):
+    rng = np.random.default_rng(len(str(ttype)) * 7 + ord(ttype.unit[0]))
+    n = 6000
+    g = rng.integers(0, 25, n)
+    vals = rng.integers(-10**12, 10**15, n)                 # before and after the epoch
+    valid = rng.random(n) > 0.1
+    valid[g == 7] = False                                   # an all-NULL group: MIN / MAX report the type's own seeds (i64::MAX / MIN)
+    schema = pa.schema([pa.field("g", pa.int64()), pa.field("t", ttype)])
+    ts = _ts_array(vals, valid, ttype)
+    cuts = [0, 2500, 2500, n]
+    batches = [pa.RecordBatch.from_arrays([pa.array(g[s:e], pa.int64()), ts.slice(s, e - s)], schema=schema) for s, e in zip(cuts[:-1], cuts[1:])]
+    out_schema = pa.schema([pa.field("g", pa.int64()), pa.field("lo", ttype), pa.field("hi", ttype), pa.field("c", pa.int64())])
+    plan = q.HashAggregate(out_schema, table_scan(schema, batches), [col("g", 0)],
+                           [q.MinAggregateExpr(col("t", 1), ttype), q.MaxAggregateExpr(col("t", 1), ttype), q.CountAggregateExpr(col("t", 1))])
+    got = engine.execute(plan)
+    assert all(b.schema.field(1).type == ttype and b.schema.field(2).type == ttype for b in got)
+    rows = {}
+    for b in got:
+        for k, lo, hi, c in zip(b.column(0).to_pylist(), b.column(1).cast(pa.int64()).to_pylist(), b.column(2).cast(pa.int64()).to_pylist(), b.column(3).to_pylist()):
+            rows[k] = (lo, hi, c)
+    want = {}
+    for k in range(25):
+        m = (g == k) & valid
+        if not (g == k).any():
+            continue
+        want[k] = (int(vals[m].min()), int(vals[m].max()), int(m.sum())) if m.any() else ((1 << 63) - 1, -(1 << 63), 0)
+    assert rows == want
+    # ungrouped (NoGroupingAggregate, no_grouping.rs:30-62)
+    ng = q.NoGroupingAggregate(pa.schema([pa.field("lo", ttype), pa.field("hi", ttype)]), table_scan(schema, batches),
+                               [q.MinAggregateExpr(col("t", 1), ttype), q.MaxAggregateExpr(col("t", 1), ttype)])
+    out = engine.execute(ng)
+    assert [c.cast(pa.int64()).to_pylist() for c in out[0].columns] == [[int(vals[valid].min())], [int(vals[valid].max())]]
+
+
+@pytest.mark.parametrize("ttype", TS_TYPES, ids=[str(t) for t in TS_TYPES])
+def test_filter_and_sort_on_timestamp_columns(engine, ttype):
+    rng = np.random.default_rng(11 + ord(ttype.unit[0]))
+    n = 3000
+    a = rng.integers(-10**9, 10**12, n)
+    b = rng.integers(-10**9, 10**12, n)
+    av, bv = rng.random(n) > 0.04, rng.random(n) > 0.04
+    schema = pa.schema([pa.field("a", ttype), pa.field("b", ttype), pa.field("i", pa.int64())])
+    batch = pa.RecordBatch.from_arrays([_ts_array(a, av, ttype), _ts_array(b, bv, ttype), pa.array(np.arange(n), pa.int64())], schema=schema)
+    kept = engine.execute(q.Filter(table_scan(schema, [batch.slice(0, 1000), batch.slice(1000)]), q.BinaryExpr(col("a", 0), Operator.GtEq, col("b", 1))))
+    assert [i for bt in kept for i in bt.column(2).to_pylist()] == [i for i in range(n) if av[i] and bv[i] and a[i] >= b[i]]
+    top = q.DefaultQueryPlanner().physical_plan_sort(table_scan(schema, [batch]), [(col("a", 0), False), (col("i", 2), True)])
+    order = [i for bt in engine.execute(top) for i in bt.column(2).to_pylist()]
+    want = sorted(range(n), key=lambda i: ((0, 0) if not av[i] else (1, -int(a[i])), i))   # NULLs first, descending a; ties by i ascending
+    assert order == want
+
+
+def test_timestamp_keys_are_the_references_hasher_error(engine):
+    ttype = pa.timestamp("us")
+    schema = pa.schema([pa.field("t", ttype), pa.field("x", pa.int64())])
+    batch = pa.RecordBatch.from_arrays([pa.array([1, 2, 2], pa.int64()).cast(ttype), pa.array([1, 2, 3], pa.int64())], schema=schema)
+    plan = q.HashAggregate(None, table_scan(schema, [batch]), [col("t", 0)], [q.SumAggregateExpr(col("x", 1), pa.int64())])
+    with pytest.raises(Exception, match="Unsupported data type in hasher"):
+        engine.execute(plan)
+    join = q.HashJoinExec.try_new(table_scan(schema, [batch]), table_scan(schema, [batch]), JoinType.Inner, [(col("t", 0), col("t", 0))])
+    with pytest.raises(Exception, match="Unsupported data type in hasher"):
+        engine.execute(join)
