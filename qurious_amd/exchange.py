@@ -300,7 +300,7 @@ def shuffle_tables(inputs) -> List[DeviceTable]:
 
 def _fast_exchange() -> bool:
     """the one-call exchange (qhip_shuffle_tables) needs libqhip's own communicator; QHIP_EXCHANGE_FAST=0 switches it off"""
-    return transport() == "rccl" and os.environ.get("QHIP_EXCHANGE_FAST", "1") != "0"
+    return _engine().fast_exchange and transport() == "rccl" and os.environ.get("QHIP_EXCHANGE_FAST", "1") != "0"
 
 
 def _is_table_access(node) -> bool:
@@ -390,9 +390,10 @@ def exchange_device_tables(parts: Sequence[DeviceTable], schema, group=None) -> 
         out = C.c_void_p()
         ctx.check(ctx.lib.qhip_exchange_tables(ctx.handle, get_comm(ctx), hs, names, dtypes, ncols, C.byref(out)))
         return DeviceTable(ctx, out)
-    packed = [pack_table(p) for p in parts]
+    E = _engine()
+    packed = [E.pack(p) for p in parts]
     got = all_to_all_bytes([img for _, img in packed], group, meta=[m for m, _ in packed])
-    return unpack_concat(parts[0].ctx, schema, got.meta, got)
+    return E.unpack(schema, got.meta, got)
 
 
 def keep_columns(table: DeviceTable, keep: Optional[Sequence[bool]]) -> DeviceTable:
@@ -471,6 +472,78 @@ def _wire_schema(schema, needed: Optional[set]):
 
 def _keep_mask(n_cols: int, needed: Optional[set]):
     return None if needed is None else [c in needed for c in range(n_cols)]
+
+
+class LocalEngine:
+    """What the multi-rank operators of this module ask of the RANK-LOCAL execution engine. The default — this class — is libqhip:
+    tables are device tables in HBM and every method is a call through the C ABI. ``set_local_engine(other)`` installs another
+    one; that is the documented hook through which tests/test_distributed_cpu.py drives DistributedHashJoinExec /
+    BroadcastHashJoinExec / DistributedHashAggregate end to end on CPUs (gloo, world 2) with a pyarrow stub, so that the
+    operators' RANK LOGIC — which side is exchanged, which columns travel, how heavy keys are split, how partial groups are
+    merged — is covered where no GPU is. An engine's tables are opaque to the operators."""
+
+    fast_exchange = True      # qhip_shuffle_tables (the one-call exchange) is available
+
+    def context(self):
+        return get_context()
+
+    def execute(self, node: PhysicalPlan):
+        return node.execute_device()
+
+    def probe_side(self, join: HashJoinExec, fuse: bool):
+        """(table, scan filter to fuse into the local join or None) of a join's probe side that stays on this rank"""
+        return join._side(join.right, fuse)
+
+    def base_table(self, scan):
+        """the unfiltered table behind a Scan (heavy keys are sampled there)"""
+        return scan.datasource.device_table()
+
+    def num_rows(self, table) -> int:
+        return table.num_rows
+
+    def keep_columns(self, table, mask):
+        return keep_columns(table, mask)
+
+    def partition(self, table, keys, n_parts):
+        return partition_filtered(table, keys, n_parts)
+
+    def pack(self, table):
+        return pack_table(table)
+
+    def unpack(self, schema, metas, images):
+        return unpack_concat(get_context(), schema, metas, images)
+
+    def concat(self, tables):
+        return concat_tables(tables)
+
+    def filter(self, table, predicate):
+        from .plan import _filter_device
+        return _filter_device(table, predicate, None)
+
+    def top_keys(self, table, schema, key, dtype):
+        return _local_top_keys(table, schema, key, dtype)
+
+    def join(self, op: HashJoinExec, lt, rt, lpred=None, rpred=None):
+        return op._join_tables(lt, rt, lpred, rpred)
+
+    def aggregate(self, schema, table, keys, aggs):
+        from .plan import HashAggregate
+        return HashAggregate(schema, DeviceSource(schema, table), keys, aggs).execute_device()
+
+
+_ENGINE = LocalEngine()
+
+
+def set_local_engine(engine: Optional[LocalEngine]) -> LocalEngine:
+    """Install the rank-local engine the multi-rank operators use (None: libqhip again); returns the previous one."""
+    global _ENGINE
+    previous = _ENGINE
+    _ENGINE = engine if engine is not None else LocalEngine()
+    return previous
+
+
+def _engine() -> LocalEngine:
+    return _ENGINE
 
 
 class DeviceSource(PhysicalPlan):
@@ -605,7 +678,7 @@ class DistributedHashJoinExec(HashJoinExec):
         world = _exchange_world(_dist())
         if not world:
             return HashJoinExec.execute_device(self)
-        ctx = get_context()
+        ctx = _engine().context()
 
         def once():
             # what this operator received earlier in the SAME execution of the plan (a local retry above it): no collective again
@@ -613,7 +686,7 @@ class DistributedHashJoinExec(HashJoinExec):
             if got is None:
                 got = self._exchange_inputs(world)
                 exchange_cache(ctx)[id(self)] = got
-            return self._join_tables(*got)
+            return _engine().join(self, *got)
         return _retrying(ctx, once)
 
     def _heavy_keys_now(self, world, rs, rw):
@@ -631,7 +704,7 @@ class DistributedHashJoinExec(HashJoinExec):
             return cached[1]
         # (sampled on the UNFILTERED table: a heavy key of the table is what matters for balance; a stale or approximate set
         # costs balance, never correctness)
-        top, n_sample = _local_top_keys(self.right.datasource.device_table(), rs, rkey, rdtype)
+        top, n_sample = _engine().top_keys(_engine().base_table(self.right), rs, rkey, rdtype)
         keys = heavy_keys(top, n_sample)
         self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
         return keys
@@ -654,21 +727,24 @@ class DistributedHashJoinExec(HashJoinExec):
                     return got[0], got[1]
                 except _ffi.UnsupportedError:
                     pass   # (a column kind the fast path does not move — every rank decides alike: the generic path below)
-        with get_context().no_deferred_sizes():   # (the generic path settles its inputs one by one: no sizes left on the device)
+        ctx = _engine().context()
+        if not hasattr(ctx, "no_deferred_sizes"):
+            return self._execute_exchanged(world)
+        with ctx.no_deferred_sizes():   # (the generic path settles its inputs one by one: no sizes left on the device)
             return self._execute_exchanged(world)
 
     def _execute_exchanged(self, world):
+        E = _engine()
         ls, rs = self.left.schema(), self.right.schema()
         lneed, rneed = self._needed_per_side()
         # columns nothing above this join reads are dropped BEFORE the partitioning: never gathered, never sent
-        left = keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed))
-        right = keep_columns(self.right.execute_device(), _keep_mask(len(rs), rneed))
+        left = E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed))
+        right = E.keep_columns(E.execute(self.right), _keep_mask(len(rs), rneed))
         lw, rw = _wire_schema(ls, lneed), _wire_schema(rs, rneed)
         heavy_l = heavy_r = None
         # heavy hitters (one key column, join types in which a result row belongs to exactly one probe row): their probe rows
         # stay on this rank, their build rows go to every rank; everything else is repartitioned by key hash
         if len(self.on) == 1 and self.join_type in (JoinType.Inner, JoinType.Right) and os.environ.get("QHIP_EXCHANGE_NO_HEAVY") != "1":
-            from .plan import _filter_device
             lkey, rkey = self.on[0]
             rdtype = _expr_type(rkey, rs)
             if rdtype is not None:
@@ -680,20 +756,20 @@ class DistributedHashJoinExec(HashJoinExec):
                     keys = cached[1]
                     self._heavy_cache = (world, keys, cached[2] - 1)
                 else:
-                    top, n_sample = _local_top_keys(right, rw, rkey, rdtype)
+                    top, n_sample = E.top_keys(right, rw, rkey, rdtype)
                     keys = heavy_keys(top, n_sample)
                     self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
                 hl, ll = heavy_split_predicates(lkey, _expr_type(lkey, ls), keys) if keys else (None, None)
                 hr, lr = heavy_split_predicates(rkey, rdtype, keys) if keys else (None, None)
                 if hl is not None and hr is not None:
-                    heavy_l, left = all_gather_device_table(_filter_device(left, hl, None), lw), _filter_device(left, ll, None)
-                    heavy_r, right = _filter_device(right, hr, None), _filter_device(right, lr, None)
+                    heavy_l, left = all_gather_device_table(E.filter(left, hl), lw), E.filter(left, ll)
+                    heavy_r, right = E.filter(right, hr), E.filter(right, lr)
                     _STATS["heavy_keys"] = _STATS.get("heavy_keys", 0) + len(keys)
-        lt = exchange_device_tables(partition_filtered(left, [l for l, _ in self.on], world), lw)
-        rt = exchange_device_tables(partition_filtered(right, [r for _, r in self.on], world), rw)
-        _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + rt.num_rows + (heavy_r.num_rows if heavy_r is not None else 0)
+        lt = exchange_device_tables(E.partition(left, [l for l, _ in self.on], world), lw)
+        rt = exchange_device_tables(E.partition(right, [r for _, r in self.on], world), rw)
+        _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + E.num_rows(rt) + (E.num_rows(heavy_r) if heavy_r is not None else 0)
         if heavy_l is not None:
-            lt, rt = concat_tables([lt, heavy_l]), concat_tables([rt, heavy_r])
+            lt, rt = E.concat([lt, heavy_l]), E.concat([rt, heavy_r])
         return lt, rt
 
     @staticmethod
@@ -717,9 +793,10 @@ def all_gather_device_table(table: DeviceTable, schema, group=None) -> DeviceTab
         out = C.c_void_p()
         ctx.check(ctx.lib.qhip_all_gather_table(ctx.handle, get_comm(ctx), table.handle, names, dtypes, ncols, C.byref(out)))
         return DeviceTable(ctx, out)
-    meta, img = pack_table(table)          # packed once, the same image goes to every peer
+    E = _engine()
+    meta, img = E.pack(table)              # packed once, the same image goes to every peer
     got = all_to_all_bytes([img] * world, group, meta=[meta] * world)
-    return unpack_concat(table.ctx, schema, got.meta, got)
+    return E.unpack(schema, got.meta, got)
 
 
 class BroadcastHashJoinExec(HashJoinExec):
@@ -737,15 +814,15 @@ class BroadcastHashJoinExec(HashJoinExec):
             return HashJoinExec.execute_device(self)
         if self.join_type not in (JoinType.Inner, JoinType.Right):
             return DistributedHashJoinExec.execute_device(self)
-        ctx = get_context()
+        ctx = _engine().context()
 
         def once():
             build = exchange_cache(ctx).get(id(self))
             if build is None:
                 build = self._gather_build()
                 exchange_cache(ctx)[id(self)] = build
-            probe, rpred = self._side(self.right, self.join_type == JoinType.Inner)
-            return self._join_tables(build, probe, None, rpred)
+            probe, rpred = _engine().probe_side(self, self.join_type == JoinType.Inner)
+            return _engine().join(self, build, probe, None, rpred)
         return _retrying(ctx, once)
 
     def _gather_build(self) -> DeviceTable:
@@ -759,8 +836,12 @@ class BroadcastHashJoinExec(HashJoinExec):
                 return shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), 3)])[0]
             except _ffi.UnsupportedError:
                 pass
-        with get_context().no_deferred_sizes():
-            return all_gather_device_table(keep_columns(self.left.execute_device(), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
+        E = _engine()
+        ctx = E.context()
+        if not hasattr(ctx, "no_deferred_sizes"):
+            return all_gather_device_table(E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
+        with ctx.no_deferred_sizes():
+            return all_gather_device_table(E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed)), _wire_schema(ls, lneed))
 
     _exchange_inputs = DistributedHashJoinExec._exchange_inputs
     _execute_exchanged = DistributedHashJoinExec._execute_exchanged
@@ -819,18 +900,19 @@ class DistributedHashAggregate(PhysicalPlan):
         from .plan import _retrying, exchange_cache
         world = _exchange_world(_dist())
         if not world:
-            return self.partial.execute_device()
+            return _engine().execute(self.partial)
         ng = len(self.group_exprs)
         pschema = self._schema if self._schema is not None else None
         keys = [Column(f"g{k}", k) for k in range(ng)]
         if pschema is None:
             raise _ffi.InternalError(_ffi.QHIP_INVALID_ARGUMENT, "DistributedHashAggregate needs its output schema (the partials travel)")
-        ctx = get_context()
+        E = _engine()
+        ctx = E.context()
 
         def once():
             mine = exchange_cache(ctx).get(id(self))
             if mine is None:
-                part = self.partial.execute_device()
+                part = E.execute(self.partial)
                 mine = None
                 if _fast_exchange():
                     try:
@@ -838,9 +920,8 @@ class DistributedHashAggregate(PhysicalPlan):
                     except _ffi.UnsupportedError:
                         mine = None   # (string group keys, NULLs among the partials: the generic path)
                 if mine is None:
-                    mine = exchange_device_tables(partition_filtered(part, keys, world), pschema)
+                    mine = exchange_device_tables(E.partition(part, keys, world), pschema)
                 exchange_cache(ctx)[id(self)] = mine
-            merge = HashAggregate(pschema, DeviceSource(pschema, mine), keys, merge_aggregate_exprs(self.aggregate_exprs, ng))
-            return merge.execute_device()
+            return E.aggregate(pschema, mine, keys, merge_aggregate_exprs(self.aggregate_exprs, ng))
         return _retrying(ctx, once)
 

@@ -82,8 +82,10 @@ def numpy_q3(c, o, l, day):
     revenue = price[keep] * (100 - disc[keep])                            # Decimal(38,4) unscaled
     hit = np.zeros(len(okey), dtype=bool)
     hit[oidx[keep]] = True
-    per_order = np.zeros(len(okey), dtype=np.int64)
-    np.add.at(per_order, oidx[keep], revenue) if len(okey) <= 2_000_000 else None   # per-group values at small sizes only
+    # every group's revenue, at any size: bincount sums in float64, exact while a group's sum stays below 2^53 (an order has at
+    # most 7 lines of < 2^40 each)
+    assert len(revenue) == 0 or int(revenue.max()) < (1 << 49)
+    per_order = np.bincount(oidx[keep], weights=revenue.astype(np.float64), minlength=len(okey)).astype(np.int64)
     mix = int((revenue.astype(U64) * lkey[keep].astype(U64)).sum(dtype=U64))
     return hit, int(revenue.sum()), mix, odate, okey, per_order
 

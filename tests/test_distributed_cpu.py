@@ -294,3 +294,183 @@ def test_heavy_split_predicates_partition_every_row():
     run = lambda pred: rows_of(qoracle.execute(q.Filter(table_scan(schema, [batch]), pred)))   # noqa: E731
     assert [r[1] for r in run(heavy)] == [1, 4, 5, 7] and [r[1] for r in run(light)] == [0, 2, 3, 6]
     assert exchange.heavy_split_predicates(col("k", 0), pa.float64(), [1.5]) == (None, None)   # unsupported key type: no split
+
+
+# ---------------------------------------------------------------- the operators themselves, end to end, on CPUs
+# exchange.set_local_engine is the documented hook: the multi-rank operators ask a LocalEngine for everything rank-local
+# (libqhip by default). Here the engine is Arrow batches + the oracle, so DistributedHashJoinExec / BroadcastHashJoinExec /
+# DistributedHashAggregate run THEIR OWN code — which side moves, which columns travel, heavy-key split, exchange cache,
+# merge of the partial groups — over gloo, and the union over ranks must equal the single-process oracle result.
+class _StubContext:
+    """what plan._retrying / exchange_cache need of a context"""
+
+    def allow_deferred_sizes(self, n):
+        pass
+
+
+def _stub_engine():
+    import collections
+    import copy
+    import torch
+    from oracle import qoracle
+    from qurious_amd import exchange
+
+    def one_batch(batches, schema):
+        batches = [b for b in batches if b.num_rows] or list(batches)[:1]
+        if not batches:
+            return pa.RecordBatch.from_arrays([pa.array([], type=f.type) for f in schema], schema=schema)
+        return pa.Table.from_batches(batches).combine_chunks().to_batches()[0] if batches[0].num_rows else batches[0]
+
+    class Engine(exchange.LocalEngine):
+        fast_exchange = False          # (no libqhip communicator on a CPU)
+        log = collections.Counter()
+        _ctx = _StubContext()
+
+        def context(self):
+            return self._ctx
+
+        def execute(self, node):
+            if isinstance(node, (exchange.DistributedHashJoinExec, exchange.BroadcastHashJoinExec, exchange.DistributedHashAggregate)):
+                return node.execute_device()                       # the operator under test: its own rank logic
+            if isinstance(node, q.Scan):
+                return one_batch(qoracle.execute(node), node.schema())
+            clone = copy.copy(node)                                # children first (they may hold exchange operators) ...
+            for name in ("input", "left", "right"):
+                child = getattr(node, name, None)
+                if isinstance(child, q.PhysicalPlan):
+                    got = self.execute(child)
+                    setattr(clone, name, table_scan(got.schema, [got]))
+            return one_batch(qoracle.execute(clone), node.schema())   # ... then this node alone, by the oracle
+
+        def probe_side(self, join, fuse):
+            node = join.right
+            if fuse and isinstance(node, q.Scan) and node.filter is not None and node.projections is None:
+                return self.base_table(node), node.filter
+            return self.execute(node), None
+
+        def base_table(self, scan):
+            return one_batch(scan.datasource.data, scan.datasource.schema())
+
+        def num_rows(self, table):
+            return table.num_rows
+
+        def keep_columns(self, table, mask):
+            if mask is None:
+                return table
+            self.log["columns_dropped"] += sum(1 for m in mask if not m)
+            cols = [c if m else pa.nulls(table.num_rows, type=c.type) for c, m in zip(table.columns, mask)]
+            return pa.RecordBatch.from_arrays(cols, schema=table.schema)
+
+        def partition(self, table, keys, n_parts):
+            pid = qoracle.partition_ids([table.column(k.index) for k in keys], n_parts) if table.num_rows else np.zeros(0, dtype=np.int64)
+            return [table.filter(pa.array(pid == p)) for p in range(n_parts)]
+
+        def pack(self, table):
+            self.log["packed"] += 1
+            return [table.num_rows], torch.frombuffer(bytearray(_ipc(table)), dtype=torch.uint8)
+
+        def unpack(self, schema, metas, images):
+            parts = [_unipc(bytes(t.numpy().tobytes())) for t in images]
+            assert [p.num_rows for p in parts] == [m[0] for m in metas]
+            assert len(schema) == len(parts[0].schema)
+            return one_batch(parts, parts[0].schema)
+
+        def concat(self, tables):
+            return one_batch(list(tables), tables[0].schema)
+
+        def filter(self, table, predicate):
+            return one_batch(qoracle.execute(q.Filter(table_scan(table.schema, [table]), predicate)), table.schema)
+
+        def top_keys(self, table, schema, key, dtype):
+            sample = table.column(key.index).to_pylist()[::8]
+            top = collections.Counter(k for k in sample if k is not None).most_common(exchange.HEAVY_CANDIDATES)
+            return top, len(sample)
+
+        def join(self, op, lt, rt, lpred=None, rpred=None):
+            self.log["joins"] += 1
+            plain = q.HashJoinExec(table_scan(lt.schema, [lt], lpred), table_scan(rt.schema, [rt], rpred), op.join_type, op.on, op.filter,
+                                   op._schema, op.column_indices)
+            return one_batch(qoracle.execute(plain), op.schema())
+
+        def aggregate(self, schema, table, keys, aggs):
+            return one_batch(qoracle.execute(q.HashAggregate(schema, table_scan(table.schema, [table]), keys, aggs)), schema)
+
+    return Engine()
+
+
+def _worker_operators(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import qoracle
+    from qurious_amd import exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    engine = _stub_engine()
+    previous = exchange.set_local_engine(engine)
+    try:
+        assert type(previous) is exchange.LocalEngine
+        cut = lambda b: b.slice(b.num_rows * rank // world, b.num_rows * (rank + 1) // world - b.num_rows * rank // world)   # noqa: E731
+        on = [(col("lk", 0), col("rk", 0))]
+        pred = q.BinaryExpr(col("rv", 1), q.Operator.Lt, q.Literal(q.ScalarValue.Int64(700000)))
+        results = {}
+
+        # (1) repartitioned join, uniform keys, every join type whose rows the exchange co-locates
+        (ls, lb), (rs, rb) = _tables(seed=7, nl=500, nr=3000, nkeys=120)
+        for jt in (JoinType.Inner, JoinType.Left, JoinType.Right, JoinType.Full):
+            plan = exchange.DistributedHashJoinExec.try_new(table_scan(ls, [cut(lb)]), table_scan(rs, [cut(rb)], pred), jt, on)
+            results["repartition-" + jt.name] = rows_of([engine.execute(plan)])
+        # (2) Zipf-skewed probe keys: the heavy keys' probe rows stay, their build rows are broadcast
+        (hs, hb), (ps, pb) = _skew_tables(1.5, n_probe=12000, domain=200)
+        skew = exchange.DistributedHashJoinExec.try_new(table_scan(hs, [cut(hb)]), table_scan(ps, [cut(pb)]), JoinType.Inner, [(col("bk", 0), col("pk", 0))])
+        exchange.exchange_stats(reset=True)
+        results["skew"] = rows_of([engine.execute(skew)])
+        st = exchange.exchange_stats(reset=True)
+        assert st["heavy_keys"] >= 1 and st["heavy_key_rounds"] == 1
+        assert st["probe_rows_received"] <= 1.3 * pb.num_rows / world     # balance: what heavy-hitter handling is for
+        results["skew-again"] = rows_of([engine.execute(skew)])          # the cached heavy-key set: no second sampling round
+        assert exchange.exchange_stats(reset=True)["heavy_key_rounds"] == 0
+        # (3) broadcast join under a distributed aggregate, with column pruning: the build side's value column is not read
+        join = exchange.BroadcastHashJoinExec.try_new(table_scan(ls, [cut(lb)]), table_scan(rs, [cut(rb)], pred), JoinType.Inner, on)
+        aschema = _agg_over(join, _aggs)[1]
+        agg = exchange.DistributedHashAggregate(aschema, join, [col("lk", 0)], _aggs(col("rv", 3)))
+        exchange.prune_exchange_columns(agg)
+        before = engine.log["columns_dropped"]
+        results["broadcast-agg"] = rows_of([engine.execute(agg)])
+        assert engine.log["columns_dropped"] - before >= 1                  # lv never travelled
+        # ... the same plan with the repartitioned join
+        join2 = exchange.DistributedHashJoinExec.try_new(table_scan(ls, [cut(lb)]), table_scan(rs, [cut(rb)], pred), JoinType.Inner, on)
+        agg2 = exchange.DistributedHashAggregate(aschema, join2, [col("lk", 0)], _aggs(col("rv", 3)))
+        results["repartition-agg"] = rows_of([engine.execute(agg2)])
+
+        # every local join went through the engine, every exchange through pack / all_to_all_bytes / unpack
+        assert engine.log["joins"] == 8 and engine.log["packed"] >= 2 * 6 * world + 2 * world
+        gathered = [None] * world
+        dist.all_gather_object(gathered, results)
+        if rank == 0:
+            union = lambda name: sorted((r for g in gathered for r in g[name]), key=repr)   # noqa: E731
+            for jt in (JoinType.Inner, JoinType.Left, JoinType.Right, JoinType.Full):
+                full = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb], pred), jt, on)
+                want = sorted(rows_of(qoracle.execute(full)), key=repr)
+                assert union("repartition-" + jt.name) == want and len(want) > 1000, jt
+            want = sorted(rows_of(qoracle.execute(q.HashJoinExec.try_new(table_scan(hs, [hb]), table_scan(ps, [pb]), JoinType.Inner,
+                                                                         [(col("bk", 0), col("pk", 0))]))), key=repr)
+            assert union("skew") == want and union("skew-again") == want and len(want) > 10000
+            full_join = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb], pred), JoinType.Inner, on)
+            want = sorted(rows_of(qoracle.execute(_agg_over(full_join, _aggs)[0])), key=repr)
+            for name in ("broadcast-agg", "repartition-agg"):
+                got = union(name)
+                assert len({r[0] for r in got}) == len(got)         # every group on exactly one rank after the merge
+                assert got == want and len(want) > 50, name
+            open(os.path.join(out_dir, "ok_operators"), "w").write(str(len(want)))
+    finally:
+        exchange.set_local_engine(None)
+        dist.destroy_process_group()
+
+
+def test_exchange_operators_end_to_end_with_a_stub_local_engine_world2_gloo(tmp_path):
+    """DistributedHashJoinExec (all four join types, heavy hitters, cached heavy keys), BroadcastHashJoinExec and
+    DistributedHashAggregate (with exchange column pruning) executed BY THEIR OWN CODE on two gloo ranks through
+    exchange.set_local_engine; the union of the ranks' results equals the single-process oracle result."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_operators, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(open(tmp_path / "ok_operators").read()) > 50

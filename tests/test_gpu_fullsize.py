@@ -88,7 +88,7 @@ def test_q1_mini_at_100m_rows_equals_exact_numpy(ctx, lineitem_100m):
 def test_q3_at_sf10_group_set_and_checksums_equal_numpy(ctx):
     c, o, l = synth.q3_tables(10.0)
     day = _days(1995, 3, 15)
-    hit, want_total, want_mix, odate, okey, _ = numpy_q3(c, o, l, day)       # independent restatement on the raw buffers
+    hit, want_total, want_mix, odate, okey, per_order = numpy_q3(c, o, l, day)   # independent restatement on the raw buffers
     want_groups = int(hit.sum())
     # ---- the HIP path
     tabs = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
@@ -103,6 +103,7 @@ def test_q3_at_sf10_group_set_and_checksums_equal_numpy(ctx):
     assert int((g_rev.astype(U64) * g_key.astype(U64)).sum(dtype=U64)) == want_mix
     g_idx = order_row_of(g_key)
     assert (out.column(1).cast(pa.int32()).to_numpy() == odate[g_idx]).all() and (out.column(2).to_numpy() == 0).all()
+    assert (g_rev == per_order[g_idx]).all()                                      # every group's revenue, exactly
     # idempotence + the device-resident top-10 agrees with a host-side ordering of the full result
     again = pa.Table.from_batches(plan.execute()).combine_chunks()
     assert int(_dec_lo(again.column(3).chunk(0)).sum()) == want_total and again.num_rows == want_groups

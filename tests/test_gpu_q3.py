@@ -312,3 +312,46 @@ def test_compiled_host_runs_the_metrics_step(ctx):
     want = queries.q3(*tabs).execute_device().num_rows
     assert line["q1_groups"] == 4 and line["q3_groups"] == want > 1000 and line["ms_per_step"] > 0
     assert line["q3_lineitem_rows"] == sum(b.num_rows for b in l)
+    # ... and not only as many groups: EVERY row and column of both results, folded into an order-independent checksum the same
+    # way on both sides (tools/bench_host.cpp result_checksum)
+    li = q.MemoryTable.try_new(synth.LINEITEM_SCHEMA, synth.lineitem(line["q1_rows"], 1 << 20))
+    for name, plan in (("q1", queries.q1_full(li)), ("q3", queries.q3(*tabs))):
+        rows, checksum = _result_checksum(plan.execute())
+        assert rows == line[f"{name}_result_rows"] and str(checksum) == line[f"{name}_result_checksum"], name
+
+
+def _result_checksum(batches):
+    """tools/bench_host.cpp result_checksum in numpy: sum over the rows of mix64-chained column values + the row count"""
+    U = np.uint64
+
+    def mix64(x):
+        x = x ^ (x >> U(33)); x = x * U(0xff51afd7ed558ccd); x = x ^ (x >> U(33)); x = x * U(0xc4ceb9fe1a85ec53); return x ^ (x >> U(33))
+    total, rows = U(0), 0
+    with np.errstate(over="ignore"):
+        for b in batches:
+            n = b.num_rows
+            rows += n
+            h = np.zeros(n, dtype=U)
+            for c in b.columns:
+                valid = np.asarray(c.is_valid().to_numpy(zero_copy_only=False), dtype=bool)
+                t = c.type
+                if pa.types.is_string(t):
+                    x = h.copy()
+                    vals = [v.encode() if v is not None else b"" for v in c.to_pylist()]
+                    for i, v in enumerate(vals):
+                        xi = x[i]
+                        for k in range(0, len(v), 8):
+                            xi = mix64(xi ^ U(int.from_bytes(v[k:k + 8], "little")))
+                        x[i] = mix64(xi ^ U(len(v)))
+                else:
+                    width = 16 if pa.types.is_decimal128(t) else t.bit_width // 8
+                    raw = np.frombuffer(c.buffers()[1], dtype=np.uint8)[c.offset * width:(c.offset + n) * width].reshape(n, width)
+                    w0 = np.zeros((n, 8), dtype=np.uint8)
+                    w0[:, :min(width, 8)] = raw[:, :min(width, 8)]
+                    x = mix64(h ^ w0.view(U).reshape(n))
+                    if width == 16:
+                        x = mix64(x ^ np.ascontiguousarray(raw[:, 8:]).view(U).reshape(n))
+                x = np.where(valid, x, mix64(h ^ U(0x9E3779B97F4A7C15)))
+                h = x
+            total = total + mix64(h).sum(dtype=U)
+    return rows, int(total)

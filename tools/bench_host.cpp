@@ -6,6 +6,7 @@
 // (qhip_synth_*), uploaded once; K timed steps between two stream synchronisations after W warm-up steps.
 //   make -C tools bench_host && tools/bench_host [steps] [warmup] [sf]      (needs an MI355X)
 // Prints one JSON line: ms_per_step, rows/s, and the two queries' group counts (checked by tests/test_gpu_q3.py).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,54 @@ static MemoryTableRef make_table(const ContextRef& ctx, std::vector<Col> cols, i
   return std::make_shared<MemoryTable>(ctx, &schema, std::vector<ArrowArray*>{&arr});   // uploads; the host buffers die with `h`
 }
 static std::vector<uint8_t> bytes(size_t n) { return std::vector<uint8_t>(n ? n : 1); }
+
+// ---------------------------------------------------------------- an order-independent checksum of a WHOLE result
+// sum over the rows of mix64-chained column values (fixed-width values as one or two 64-bit words, strings as their bytes packed
+// into words + the length, NULL as a constant), plus the row count: tests/test_gpu_q3.py computes the same from the Python
+// mirror's batches — every group, every column of both hosts' results must agree, not just the group counts.
+static uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+static uint64_t result_checksum(const std::vector<RecordBatch>& batches, int64_t* rows_out) {
+  uint64_t sum = 0;
+  int64_t rows = 0;
+  for (const RecordBatch& b : batches) {
+    const int64_t n = b.array.length;
+    rows += n;
+    std::vector<uint64_t> h((size_t)n, 0);
+    for (int64_t c = 0; c < b.array.n_children; ++c) {
+      const ArrowArray& a = *b.array.children[c];
+      const std::string fmt = b.schema.children[c]->format;
+      const uint8_t* valid = a.n_buffers > 0 ? (const uint8_t*)a.buffers[0] : nullptr;
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t j = i + a.offset;
+        uint64_t& x = h[(size_t)i];
+        if (valid && a.null_count != 0 && !((valid[j >> 3] >> (j & 7)) & 1)) { x = mix64(x ^ 0x9E3779B97F4A7C15ULL); continue; }
+        if (fmt == "u") {
+          const int32_t* off = (const int32_t*)a.buffers[1];
+          const uint8_t* data = (const uint8_t*)a.buffers[2];
+          const int32_t len = off[j + 1] - off[j];
+          for (int32_t k = 0; k < len; k += 8) {
+            uint64_t w = 0;
+            memcpy(&w, data + off[j] + k, (size_t)std::min<int32_t>(8, len - k));
+            x = mix64(x ^ w);
+          }
+          x = mix64(x ^ (uint64_t)len);
+        } else {
+          const int width = fmt == "l" || fmt == "L" || fmt == "g" || fmt == "tdm" ? 8 : fmt.rfind("d:", 0) == 0 ? 16 : fmt == "i" || fmt == "I" || fmt == "f" || fmt == "tdD" ? 4 : 0;
+          if (!width) throw Error(QHIP_UNSUPPORTED, "result_checksum: column format " + fmt);
+          const uint8_t* v = (const uint8_t*)a.buffers[1] + (size_t)j * (size_t)width;
+          uint64_t w0 = 0, w1 = 0;
+          memcpy(&w0, v, (size_t)std::min(width, 8));
+          if (width == 16) memcpy(&w1, v + 8, 8);
+          x = mix64(x ^ w0);
+          if (width == 16) x = mix64(x ^ w1);
+        }
+      }
+    }
+    for (uint64_t x : h) sum += mix64(x);
+  }
+  if (rows_out) *rows_out = rows;
+  return sum;
+}
 
 static ExprRef col(const char* name, int i) { return std::make_shared<Column>(name, i); }
 static ExprRef date(const char* s) { return std::make_shared<CastExpr>(std::make_shared<Literal>(ScalarValue::Utf8(s)), dtype(QHIP_DATE32)); }
@@ -143,9 +192,14 @@ int main(int argc, char** argv) {
     for (int k = 0; k < steps; ++k) { (void)q1->execute_device(); (void)q3->execute_device(); }
     ctx->check(qhip_ctx_synchronize(ctx->raw()));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // the two queries once more through execute(): host Arrow batches, every row of both results folded into a checksum
+    int64_t r1 = 0, r3 = 0;
+    const uint64_t c1 = result_checksum(q1->execute(), &r1), c3 = result_checksum(q3->execute(), &r3);
     printf("{\"host\": \"C++ mirror (include/qhip_plan.hpp)\", \"steps\": %d, \"warmup\": %d, \"sf\": %g, \"ms_per_step\": %.4f, \"rows_per_s\": %.4g, "
-           "\"q1_rows\": %lld, \"q1_groups\": %lld, \"q3_lineitem_rows\": %lld, \"q3_groups\": %lld}\n",
-           steps, warmup, sf, secs / steps * 1e3, (double)(n_li + n_l3) * steps / secs, (long long)n_li, (long long)g1, (long long)n_l3, (long long)g3);
+           "\"q1_rows\": %lld, \"q1_groups\": %lld, \"q3_lineitem_rows\": %lld, \"q3_groups\": %lld, "
+           "\"q1_result_rows\": %lld, \"q1_result_checksum\": \"%llu\", \"q3_result_rows\": %lld, \"q3_result_checksum\": \"%llu\"}\n",
+           steps, warmup, sf, secs / steps * 1e3, (double)(n_li + n_l3) * steps / secs, (long long)n_li, (long long)g1, (long long)n_l3, (long long)g3,
+           (long long)r1, (unsigned long long)c1, (long long)r3, (unsigned long long)c3);
     return 0;
   } catch (const Error& e) {
     fprintf(stderr, "bench_host: error %d: %s\n", e.code, e.what());
