@@ -50,7 +50,8 @@ Q3_SURVEY_BYTES = {"customer": 21, "orders": 28, "lineitem": 44}
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 XGMI_PEAK_GBS = 7 * 153.0                               # 7 links x ~153 GB/s per GPU
 SF10_LINEITEM_ROWS = 59_986_052
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_summary.json") for r in (4, 3)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r04_pmc_summary.json"))   # this round's PMC passes (tools/pmc_passes.sh); the last round's until they exist
 SETTLE_STEPS = 3   # untimed executions in front of the W warm-up steps: a plan reaches its steady state on its third execution
 
 USE_DIST = False   # set by main(): a torch.distributed process group (RCCL) is up
@@ -158,7 +159,7 @@ def pmc_traffic(workload, kernel, rows, bytes_per_row):
         if k.get("kernel") != kernel:
             continue
         if int(k.get("rows", -1)) == int(rows) and abs(float(k.get("kernel_bytes_per_row", -1)) - float(bytes_per_row)) < 1e-6:
-            return k.get("hbm_bytes_per_launch"), f"{os.path.relpath(PMC_SUMMARY, ROOT)} ({prof.get('collected', 'r03')})"
+            return k.get("hbm_bytes_per_launch"), f"{os.path.relpath(PMC_SUMMARY, ROOT)} ({prof.get('collected', '?')})"
         seen.append(f"rows={k.get('rows')} bytes/row={k.get('kernel_bytes_per_row')}")
     if seen:
         return None, f"profile has {kernel} at {'; '.join(seen)} — this run: rows={rows} bytes/row={bytes_per_row}"
@@ -589,13 +590,24 @@ class PartitionBench:
                          "pass1_ms": k1, "pass2_ms": k2, "device_ms": statistics.median(tot), "host_waits_per_call": 1,
                          "device_ms_is": "first launch .. last launch of a call: the two kernels + the one-workgroup scan of the (part, unit) counters "
                                          "+ the host wait that sizes the parts (~30 us)",
-                         "roofline": roofline("qk_part_ids + k_scan_small + k_part_scatter", k1 + k2, algorithmic, None, "not profiled per launch",
+                         "roofline": roofline("qk_part_ids_wide + " + st["main_kernel_name"], k1 + k2, algorithmic, None, "see pass1 / pass2",
                                               bytes_are="every referenced column read once + the kept rows' kept columns written once",
                                               bytes_moved_per_launch=moved, frac_on_bytes_moved=moved / ((k1 + k2) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                              pass1=roofline("qk_part_ids", k1, rows * (st["build_bytes_per_row"] + 1)),
-                                              pass2=roofline("k_part_scatter", k2, rows * (1 + w_kept) + kept * w_kept))}
+                                              pass1=self._pass(name, "qk_part_ids_wide" if rows >= 2048 else "qk_part_ids", k1, rows, st["build_bytes_per_row"] + 1),
+                                              pass2=self._pass(name, st["main_kernel_name"], k2, rows, (rows * (1 + w_kept) + kept * w_kept) / rows))}
         return {"workload": f"exchange step 1 (SURVEY §8e): Q3's lineitem side, scan filter + partition by mix64(l_orderkey) into {n_parts} parts, "
                             "HBM-resident; no reference counterpart (single process)", "cases": out}
+
+
+def _partition_pass(self, case, kernel, ms, rows, bytes_per_row):
+    """one pass of the partition step: bytes moved by construction per input row (reads + writes) over its mean duration, with
+    the PMC traffic of the same kernel at the same rows when this round's profile has it"""
+    traffic, source = pmc_traffic("partition_" + case, kernel, rows, round(bytes_per_row, 6))
+    return roofline(kernel, ms, rows * bytes_per_row, traffic, source, rows_per_launch=rows, kernel_bytes_per_row=round(bytes_per_row, 6),
+                    bytes_are="column bytes read + part byte written (pass 1) / part byte + kept columns read, kept rows written (pass 2)")
+
+
+PartitionBench._pass = _partition_pass
 
 
 def pa_width(t):

@@ -844,6 +844,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     G = (uint32_t)pre_host[0];
     plan.last_dense = G;
     const uint32_t total_slots = cap * replicas;
+    // (the speculative assembly holds what fitted the buffer it was enqueued with: after a re-compaction its columns are short —
+    // a plan whose remembered group count came from a much smaller table, the same plan key at another scale factor)
+    const bool spec_fits = G <= guess;
     if (G > guess) {
       // more groups than the speculative buffer holds: compact again with the exact size
       guess = G;
@@ -853,7 +856,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       QHIP_HIP_CHECK(sync_stream(ctx->stream));
       pre_copied = 0;
     }
-    if (spec_enqueued && replicas == 1 && G >= dev_threshold && G <= guess) {
+    if (spec_enqueued && spec_fits && replicas == 1 && G >= dev_threshold) {
       // the speculative device-side assembly is the result
       plan.last_groups = G; plan.learnt_at = ++g_learn_tick;
       if (ctx->agg_group_hints.size() > 4096) ctx->agg_group_hints.clear();

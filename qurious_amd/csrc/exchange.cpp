@@ -370,7 +370,8 @@ void partition_filtered(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, 
   for (size_t c = 0; c < in->cols.size(); ++c)
     if ((!keep || keep[c]) && in->cols[c].type.id != QHIP_NULL) moved += dtype_width(in->cols[c].type);
   ctx->stats.bytes_per_row_read = moved;
-  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "k_part_scatter");
+  snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s",
+           w.wg_units ? "qk_part_scatter_wg" : env_int("QHIP_PART_SCATTER_JIT", 1) != 0 ? "qk_part_scatter" : "k_part_scatter");
 }
 
 // One destination column assembled from n source sections on the device (shared by qhip_table_concat and the unpacking of

@@ -377,3 +377,31 @@ def test_prepartitioned_aggregate_of_mid_sized_many_group_inputs(ctx, oracle, mo
     cnt = np.bincount(kk, minlength=200_000)
     sm = np.bincount(kk, weights=vv, minlength=200_000)
     assert [(r[0], r[1], r[2]) for r in first] == [(int(g), int(sm[g]), int(cnt[g])) for g in np.nonzero(cnt)[0]]
+
+
+def test_remembered_group_count_from_a_smaller_table_does_not_truncate_the_result(ctx):
+    """What the context learns about an aggregate is keyed by its expressions, not by its table: the same query over a much
+    bigger table starts with the small table's group count. The dense buffer is then too small, the slots are compacted again
+    with the exact size — and the output columns the speculative device-side assembly prepared for the OLD size must not be
+    taken as the result (round 4: found by Q3 at SF 0.5 followed by Q3 at SF 10 in one process)."""
+    rng = np.random.default_rng(7)
+    schema = pa.schema([pa.field("k", I64), pa.field("v", I64)])
+
+    def plan_over(n, groups):
+        k, v = rng.integers(0, groups, n), rng.integers(0, 1000, n)
+        batch = pa.RecordBatch.from_arrays([pa.array(k, type=I64), pa.array(v, type=I64)], schema=schema)
+        want = np.bincount(k, weights=v.astype(np.float64), minlength=groups)
+        return q.HashAggregate(None, table_scan(schema, [batch]), [col("k", 0)], [q.SumAggregateExpr(col("v", 1), I64)]), k, want
+
+    ctx.forget_plans()
+    small, _, _ = plan_over(200_000, 6_000)
+    for _ in range(2):                      # learnt: ~6 000 groups, assembled on the device from the second execution on
+        assert len(rows_of(small.execute())) == 6_000
+    big, k, want = plan_over(3_000_000, 150_000)
+    for _ in range(2):
+        got = rows_of(big.execute())
+        present = np.unique(k)
+        assert len(got) == len(present)
+        got_k = np.array([r[0] for r in got]); got_v = np.array([r[1] for r in got], dtype=np.float64)
+        assert (np.sort(got_k) == present).all() and (got_v == want[got_k]).all()
+    assert len(rows_of(small.execute())) == 6_000     # ... and back: a remembered count far above the truth

@@ -34,7 +34,9 @@ def main():
     src, out_path = sys.argv[1], sys.argv[2]
     label = sys.argv[3] if len(sys.argv) > 3 else "r03"
     summary = {}
-    for tag in ("q1_mini", "q1_full", "q3"):
+    for tag in ("q1_mini", "q1_full", "q3", "partition"):
+        if tag == "partition" and not os.path.isdir(os.path.join(src, "pmc_partition_0")):
+            continue
         pmc_json = os.path.join(src, f"{tag}_pmc.json")
         if not os.path.exists(pmc_json):
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), src, tag, pmc_json], stdout=subprocess.DEVNULL)
@@ -45,6 +47,12 @@ def main():
             for k in line["records"]["q3"]["kernels"]:
                 if k["kernel"].startswith("qk_join_probe") or k["kernel"] == "qk_filter_agg":
                     wanted.append((k["kernel"], k["rows_per_launch"], k.get("kernel_bytes_per_row"), k.get("operator")))
+        elif tag == "partition":
+            # both cases (the whole SF10 table and a 1/8 slice) run in one process: same kernels, two grid sizes
+            for case, rec in line["records"]["partition"]["cases"].items():
+                for p in ("pass1", "pass2"):
+                    r = rec["roofline"][p]
+                    wanted.append((r["kernel"], r["rows_per_launch"], r["kernel_bytes_per_row"], f"partition_{case}"))
         else:
             r = line["roofline"]
             wanted.append((r["kernel"], r["rows_per_launch"], r["kernel_bytes_per_row"], tag))
@@ -54,6 +62,10 @@ def main():
             want = sorted([w for w in wanted if w[0] == name], key=lambda w: w[1])
             # the profiled process also launches the kernel on small inputs (CPU-sample checks are off in these passes, but the
             # aggregate of a join output is small): pair the LARGEST grids with the wanted launches, ascending
+            # (a kernel's FIRST launches may run another variant of the same name on a bigger grid — a probe before the key's narrow
+            # copy exists: keep the grids that were launched repeatedly)
+            most = max((h["launches_seen"] for h in have), default=0)
+            have = [h for h in have if h["launches_seen"] * 2 >= most]
             have = have[-len(want):]
             for h, w in zip(have, want):
                 kernels.append({"kernel": name, "operator": w[3], "grid_size": h["grid_size"], "rows": w[1], "kernel_bytes_per_row": w[2],
@@ -66,6 +78,10 @@ def main():
                                                            "separate --pmc passes (MI355X_MICROARCH.md)",
                         "command": f"tools/pmc_passes.sh <dir> {tag} --workload {tag} ... (rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py)",
                         "kernels": kernels}
+    if "partition" in summary:
+        whole = summary.pop("partition")
+        for case in sorted(set(k["operator"] for k in whole["kernels"])):
+            summary[case] = dict(whole, kernels=[k for k in whole["kernels"] if k["operator"] == case])
     with open(out_path, "w") as f:
         json.dump(summary, f, indent=1)
         f.write("\n")
