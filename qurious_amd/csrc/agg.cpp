@@ -389,7 +389,10 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   ctx->agg_slot_words[hint_key] = plan.slot_words;
   const size_t lds_bytes = (size_t)l_nslots * slot_bytes;
   const int block = wide ? 1024 : 256;
-  const int64_t tile_rows = (int64_t)block * plan.R;
+  // the consecutive-rows form (a lane owns RC adjacent rows: one wide load per column; plan.RC > 0 = every referenced column is
+  // plain and narrow): a table of at least a few tiles per workgroup, the 256-thread shape, a row count known on the host
+  const bool cons = plan.RC > 0 && !parts && !wide && !in->rows_dev && N >= (int64_t)256 * plan.RC * 64 && env_int("QHIP_AGG_CONS", 1) != 0;
+  const int64_t tile_rows = (int64_t)block * (cons ? plan.RC : plan.R);
   const int64_t ntiles = (N + tile_rows - 1) / tile_rows;
   const bool merge_heavy_grid = plan.W > 0 && plan.last_groups > 4096 && N > 2 * (int64_t)256 * ctx->num_cus * 8 && N <= (int64_t)1 << 22;
   const int bpc = env_int("QHIP_AGG_BLOCKS_PER_CU", N <= 2 * (int64_t)256 * ctx->num_cus * 8 ? 8 : merge_heavy_grid ? 1 : 4);
@@ -750,6 +753,9 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       if (wide) {
         std::shared_ptr<Module> wmod = get_module(ctx, plan.source, "qk_filter_agg_wide");
         QHIP_HIP_CHECK(hipModuleLaunchKernel(wmod->fn, grid, 1, 1, 1024, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
+      } else if (cons) {
+        std::shared_ptr<Module> cmod = get_module(ctx, plan.source, "qk_filter_agg_cons");
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(cmod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
       } else {
         QHIP_HIP_CHECK(hipModuleLaunchKernel(mod->fn, grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, ctx->stream, args, nullptr));
       }
@@ -875,7 +881,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
       ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
       ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : plan.kernel_name.c_str());
+      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
       return result;
     }
     if (replicas == 1 && G >= dev_threshold) {
@@ -953,7 +959,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
     ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : plan.kernel_name.c_str());
+    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
   };
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe

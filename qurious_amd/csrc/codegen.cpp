@@ -169,7 +169,9 @@ void ExprGen::emit(int k, std::string& out) {
             // load per row instead of 64 overlapping 8-byte windows per wavefront)
             const int maxlen = in_[(size_t)n.column].utf8_max_len;
             for (int w2 = 0; w2 < it->second; ++w2) {
-              const std::string at = "(a.c[" + S + "].d + w.b" + K + " + " + std::to_string(8 * w2) + ")";
+              // (one-byte values: addressed by the 64-bit row, so that a lane's consecutive rows are provably adjacent bytes)
+              const std::string at = in_[(size_t)n.column].utf8_fixed1 ? "(a.c[" + S + "].d + " + row_ + " + " + std::to_string(8 * w2) + ")"
+                                                                       : "(a.c[" + S + "].d + w.b" + K + " + " + std::to_string(8 * w2) + ")";
               const int left = maxlen >= 0 ? maxlen - 8 * w2 : 8;
               if (it->second == 1 && left <= 1) ld << "    w.k" << K << "[0] = (u64)" << (nt_ ? "__builtin_nontemporal_load((const u8*)" + at + ")" : "*(const u8*)" + at) << ";\n";
               else if (it->second == 1 && left <= 2) ld << "    w.k" << K << "[0] = (u64)*(const qh_u16_unaligned*)" << at << ";\n";
@@ -504,7 +506,8 @@ static int utf8_key_words(const ExprSet& es, const std::vector<InputCol>& input,
   if (nd.kind == QHIP_EXPR_COLUMN && input[(size_t)nd.column].utf8_max_len >= 0) maxlen = input[(size_t)nd.column].utf8_max_len;
   else if (nd.kind == QHIP_EXPR_LITERAL) maxlen = (int)nd.s.size();
   const int words = std::max(1, (maxlen + 1 + 7) / 8);
-  if (words > 4) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than 31 bytes is not accelerated");
+  // (up to 7 words = 55 bytes + the length byte per Utf8 key — round 4; rounds 1-3: 4 words — inside the 8 words a whole key may have)
+  if (words > 7) fail(QHIP_UNSUPPORTED, "Utf8 group/join key longer than 55 bytes is not accelerated");
   return words;
 }
 
@@ -726,6 +729,43 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   P.part_pr = std::min(4, (int)((163840 - 4096 * 12 - 1024) / (1024 * ((P.slot_words - 1) * 8 + 2))));
   if (const char* e = getenv("QHIP_AGG_PART_PR")) P.part_pr = std::min(P.part_pr, std::max(1, atoi(e)));   // (experiments)
   s << "  static constexpr int PART_PR = " << P.part_pr << ";\n";
+  // The consecutive-rows form (qh_filter_agg_body<.., CONS>): for inputs whose referenced columns are all plain (no index
+  // vectors, no validity bitmaps, no Booleans, strings only as one-byte flags) and at most 8 bytes wide in the layout that is
+  // streamed — a lane's RC values of a column are then adjacent bytes and load as one instruction.
+  P.RC = 0;
+  if (!dev_rows && env_int("QHIP_AGG_CONS", 1) != 0) {
+    bool ok = !input.empty();
+    int widest = 0;
+    std::vector<char> used(es.nodes.size(), 0);
+    std::vector<int> todo;
+    if (predicate_root >= 0) todo.push_back(predicate_root);
+    for (int k = 0; k < n_groups; ++k) todo.push_back(group_roots[k]);
+    for (int k = 0; k < n_aggs; ++k) todo.push_back(aggs[k].expr);
+    while (!todo.empty()) {
+      const int k = todo.back();
+      todo.pop_back();
+      if (k < 0 || k >= (int)es.nodes.size() || used[(size_t)k]) continue;
+      used[(size_t)k] = 1;
+      todo.push_back(es.nodes[(size_t)k].left); todo.push_back(es.nodes[(size_t)k].right); todo.push_back(es.nodes[(size_t)k].third);
+    }
+    for (size_t c = 0; c < es.nodes.size(); ++c) {
+      const ENode& nd = es.nodes[c];
+      if (!used[c] || nd.kind != QHIP_EXPR_COLUMN || nd.type.id == QHIP_NULL) continue;
+      const InputCol& ic = input[(size_t)nd.column];
+      if (ic.indirect || nd.nullable || nd.type.id == QHIP_BOOL) ok = false;
+      else if (nd.type.id == QHIP_UTF8) { if (!ic.utf8_fixed1) ok = false; else widest = std::max(widest, 1); }
+      else {
+        const int nb = (nd.type.id == QHIP_DECIMAL128 || (nd.type.id == QHIP_INT64 && ic.narrow_bytes == 4)) ? ic.narrow_bytes : 0;
+        const int w = nb ? nb : dtype_width(nd.type);
+        if (w <= 0 || w > 8) ok = false;
+        widest = std::max(widest, w);
+      }
+    }
+    if (ok && widest > 0) P.RC = std::max(1, std::min(8, env_int("QHIP_AGG_CONS_R", 4)));
+  }
+  s << "  static constexpr int RC = " << std::max(1, P.RC) << ";\n";
+  s << "  static constexpr int CSB = " << std::max(1, std::min(4, env_int("QHIP_AGG_CONS_SB", 1))) << ";\n";
+  s << "  static constexpr int CPIPE = " << (env_int("QHIP_AGG_CONS_PIPE", 1) != 0 ? 1 : 0) << ";\n";
   s << "  static constexpr int KC = " << KC << ";\n";
   s << "  struct Row {\n    bool pass;\n    u64 key[" << KW << "];\n";
   for (size_t a = 0; a < P.args.size(); ++a) {
@@ -903,6 +943,9 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (P.W > 0)
       s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_wide(KArgs a, AggLaunch L) { qh_filter_agg_body<P, " << (dev_rows ? "true" : "false")
         << ", 1024>(a, L); }\n";
+    // ... a lane owning RC consecutive rows (narrow plain layouts: wide loads)
+    if (P.RC > 0)
+      s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_filter_agg_cons(KArgs a, AggLaunch L) { qh_filter_agg_body<P, false, QH_BLOCK, false, true>(a, L); }\n";
     // ... and over an input pre-partitioned by key hash, one part per workgroup (AggLaunch::part_runs; agg.cpp)
     if (P.W > 0 && !dev_rows)
       s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_parts(KArgs a, AggLaunch L) { qh_filter_agg_body<P, false, 1024, true>(a, L); }\n";

@@ -85,6 +85,7 @@ struct AggPlan {
   int KC = 0;                  // wave-resident hot keys
   int slot_words = 0;          // 1 + W + cell words
   int part_pr = 0;             // partitioned path: rows per thread of the LDS-staged scatter (0: records too wide for it)
+  int RC = 0;                  // rows per lane of the consecutive-rows form (qk_filter_agg_cons); 0 = the plan has no such entry point
   std::vector<KeyDesc> keys;
   std::vector<ArgDesc> args;
   std::vector<CellDesc> cells;

@@ -460,10 +460,17 @@ __device__ __forceinline__ u32 qh_merge_lds_table(u64* ltable, const AggLaunch& 
 // are workgroups (the exchange's partition kernels over the row numbers, agg.cpp); what made that size slow was the END of the
 // kernel — every workgroup merging its few thousand LDS groups into the shared HBM table, ~9 memory-side operations per
 // (workgroup, group), a group living in as many workgroups as it has rows — and the rows that found their LDS table full.
-template <class P, bool DEVROWS = false, int TB = QH_BLOCK, bool PARTS = false>
+// CONS (round 4, qk_filter_agg_cons): a lane owns RC CONSECUTIVE rows of a tile (row = tile + tid * RC + r) instead of rows
+// r * TB + tid. Over a narrow layout (Q1's 22 bytes per row in 1- and 4-byte columns) the rows-r*TB+tid form issues one 4- or
+// 1-byte load per lane, column and row — 7.5 load instructions per 64 rows, 2.8 KB in flight per wavefront — and the fraction of
+// the HBM peak fell with the bytes per row (70 B: 0.78, 22 B: 0.63, 9 B: 0.50). Consecutive rows make a column's RC values ONE
+// 16-byte (4-byte columns) or 4-byte (1-byte columns) load: a quarter of the load instructions, twice the bytes in flight out of
+// the same registers. Plain tables of at least one tile only (the last, partial tile is shifted back to end at the last row and
+// the rows it shares with the tile before are masked out, like qh_part_load's).
+template <class P, bool DEVROWS = false, int TB = QH_BLOCK, bool PARTS = false, bool CONS = false>
 __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaunch& L0) {
   constexpr int W = P::W;
-  constexpr int R = P::R;
+  constexpr int R = CONS ? P::RC : P::R;
   u64* ltable = (u64*)qh_dyn_lds;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -558,17 +565,96 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
     const bool inb = (TBASE) + (i64)o < (NROWS);                            \
     P::load(a, (TBASE), inb ? o : (u32)((NROWS) - 1 - (TBASE)), RAW[r]);    \
   }
-  if (P::PIPE == 0 || PARTS) {
+  if (CONS) {
+    // the R rows of a lane are evaluated and accumulated SB at a time out of the raw registers (all R at once would hold R Row
+    // structs: Q1's four rows 60 VGPRs)
+    constexpr int SB = P::CSB < R ? P::CSB : R;
+    // every load unconditional and at (shifted tile base) + tid * R + r: the compiler merges a column's R loads into one
+#define QH_CONS_BASE(T) ((T) * tile_rows + tile_rows <= a.nrows ? (T) * tile_rows : a.nrows - tile_rows)
+#define QH_CONS_ISSUE(RAW, TBS)                                             \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) P::load(a, (TBS), (u32)tid * (u32)R + (u32)r, RAW[r]);
+    if ((i64)blockIdx.x < ntiles) {
+      if (P::CPIPE == 0) {
+        for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+          const u32 overflowed = QH_OVERFLOWED();
+          const i64 tbn = t * tile_rows, tbs = QH_CONS_BASE(t);
+          typename P::Raw raw[R];
+          QH_CONS_ISSUE(raw, tbs)
+#define QH_TILE_R SB
+#define QH_TILE_RAW (raw + sb)
+#define QH_TILE_INB(r) (tbs + (i64)((u32)tid * (u32)R + (u32)(sb + (r))) >= tbn)
+          _Pragma("unroll") for (int sb = 0; sb < R; sb += SB) {
+#include "qhip_agg_tile.inc"
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the sub-batches one after the other: their Row structs share registers)
+          }
+#undef QH_TILE_RAW
+#undef QH_TILE_INB
+#undef QH_TILE_R
+          if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
+        }
+      } else {
+        typename P::Raw rawA[R], rawB[R];
+        i64 t = blockIdx.x;
+        i64 tbsA = QH_CONS_BASE(t);
+        QH_CONS_ISSUE(rawA, tbsA)
+        for (;;) {
+          u32 overflowed = QH_OVERFLOWED();
+          const i64 tbnA = t * tile_rows;
+          const i64 t1 = t + gridDim.x;
+          const bool more1 = t1 < ntiles;
+          const i64 tbnB = t1 * tile_rows;
+          const i64 tbsB = more1 ? QH_CONS_BASE(t1) : 0;     // (behind the last tile: the table's first tile once more, never evaluated)
+          QH_CONS_ISSUE(rawB, tbsB)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#define QH_TILE_R SB
+#define QH_TILE_RAW (rawA + sb)
+#define QH_TILE_INB(r) (tbsA + (i64)((u32)tid * (u32)R + (u32)(sb + (r))) >= tbnA)
+          _Pragma("unroll") for (int sb = 0; sb < R; sb += SB) {
+#include "qhip_agg_tile.inc"
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the sub-batches one after the other: their Row structs share registers)
+          }
+#undef QH_TILE_RAW
+#undef QH_TILE_INB
+#undef QH_TILE_R
+          if (!more1 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
+          overflowed = QH_OVERFLOWED();
+          const i64 t2 = t1 + gridDim.x;
+          const bool more2 = t2 < ntiles;
+          tbsA = more2 ? QH_CONS_BASE(t2) : 0;
+          QH_CONS_ISSUE(rawA, tbsA)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#define QH_TILE_R SB
+#define QH_TILE_RAW (rawB + sb)
+#define QH_TILE_INB(r) (tbsB + (i64)((u32)tid * (u32)R + (u32)(sb + (r))) >= tbnB)
+          _Pragma("unroll") for (int sb = 0; sb < R; sb += SB) {
+#include "qhip_agg_tile.inc"
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the sub-batches one after the other: their Row structs share registers)
+          }
+#undef QH_TILE_RAW
+#undef QH_TILE_INB
+#undef QH_TILE_R
+          if (!more2 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
+          t = t2;
+        }
+      }
+    }
+#undef QH_CONS_BASE
+#undef QH_CONS_ISSUE
+  } else if (P::PIPE == 0 || PARTS) {
     for (i64 t = PARTS ? 0 : blockIdx.x; t < ntiles; t += PARTS ? 1 : gridDim.x) {
       const u32 overflowed = QH_OVERFLOWED();
       const i64 tb = part_lo + t * tile_rows;
       typename P::Raw raw[R];
       QH_ISSUE(raw, tb, QH_NROWS)
 #define QH_TILE_RAW raw
-#define QH_TILE_TB tb
+#define QH_TILE_INB(r) (tb + (i64)((u32)(r) * TB + (u32)tid) < QH_NROWS)
+#define QH_TILE_R R
 #include "qhip_agg_tile.inc"
+#undef QH_TILE_R
 #undef QH_TILE_RAW
-#undef QH_TILE_TB
+#undef QH_TILE_INB
       if (__builtin_amdgcn_readfirstlane((int)overflowed)) break;
     }
   } else if ((i64)blockIdx.x < ntiles) {
@@ -589,10 +675,12 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #define QH_TILE_RAW rawA
-#define QH_TILE_TB tbA
+#define QH_TILE_INB(r) (tbA + (i64)((u32)(r) * TB + (u32)tid) < QH_NROWS)
+#define QH_TILE_R R
 #include "qhip_agg_tile.inc"
+#undef QH_TILE_R
 #undef QH_TILE_RAW
-#undef QH_TILE_TB
+#undef QH_TILE_INB
       if (!more1 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
       overflowed = QH_OVERFLOWED();
       const i64 t2 = t1 + gridDim.x;
@@ -602,10 +690,12 @@ __device__ __forceinline__ void qh_filter_agg_body(const KArgs& a, const AggLaun
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #define QH_TILE_RAW rawB
-#define QH_TILE_TB tbB
+#define QH_TILE_INB(r) (tbB + (i64)((u32)(r) * TB + (u32)tid) < QH_NROWS)
+#define QH_TILE_R R
 #include "qhip_agg_tile.inc"
+#undef QH_TILE_R
 #undef QH_TILE_RAW
-#undef QH_TILE_TB
+#undef QH_TILE_INB
       if (!more2 || __builtin_amdgcn_readfirstlane((int)overflowed)) break;
       t = t2;
     }

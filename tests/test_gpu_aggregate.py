@@ -32,7 +32,7 @@ def test_q1_mini_config0_matches_oracle(ctx, oracle):
     assert out[0].schema.field(1).type == pa.decimal128(15, 2)
     st = ctx.last_stats()
     # (QHIP_AGG_PARTITION=2 in the environment forces the partitioned kernels on every grouped aggregate)
-    assert st["main_kernel_name"] in ("qk_filter_agg", "qk_agg_part_hist+scatter+reduce") and st["rows_in"] == 1_000_000
+    assert st["main_kernel_name"] in ("qk_filter_agg", "qk_filter_agg_cons", "qk_agg_part_hist+scatter+reduce") and st["rows_in"] == 1_000_000
 
 
 def test_q1_full_matches_oracle(ctx, oracle):

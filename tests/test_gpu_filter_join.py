@@ -244,7 +244,7 @@ def test_join_then_aggregate_stays_on_device(ctx, oracle, join_layout):
 
 
 def test_utf8_keys_longer_than_one_word(ctx, oracle, join_layout):
-    """Utf8 group / join keys are packed into 1..4 key words sized from the column's longest value (<= 31 bytes)"""
+    """Utf8 group / join keys are packed into key words sized from the column's longest value"""
     rng = np.random.default_rng(77)
     segs = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY", "", "4-NOT SPECIFIED", "x" * 31, "y" * 16, "ab"]
     n = 20000
@@ -261,6 +261,33 @@ def test_utf8_keys_longer_than_one_word(ctx, oracle, join_layout):
         plan = q.HashJoinExec.try_new(table_scan(rs, [rb]), scan, jt, [(col("name", 0), col("seg", 0))], None)
         _batches_equal(plan.execute(), oracle.execute(plan))
     long_schema = pa.schema([pa.field("s", pa.string())])
-    long_scan = table_scan(long_schema, [pa.RecordBatch.from_arrays([pa.array(["z" * 32, "a"])], schema=long_schema)])
-    with pytest.raises(q.UnsupportedError, match="longer than 31 bytes"):
+    long_scan = table_scan(long_schema, [pa.RecordBatch.from_arrays([pa.array(["z" * 56, "a"])], schema=long_schema)])
+    with pytest.raises(q.UnsupportedError, match="longer than 55 bytes"):
         q.HashAggregate(None, long_scan, [col("s", 0)], [q.CountAggregateExpr(lit_i64(1))]).execute()
+
+
+def test_utf8_keys_of_32_to_55_bytes(ctx, oracle, join_layout):
+    """Round 4: a Utf8 key packs into up to 7 words (55 bytes + the length byte; TPC-H's names, addresses and l_comment fit) —
+    values that differ only in their last byte, at every word boundary, NULLs and the empty string; GROUP BY alone and next to
+    an Int64 key (1 + 7 = the 8 words a whole key may have), both sides of a join, every join layout."""
+    rng = np.random.default_rng(91)
+    base = "Customer#000000001 lives at 1 Long Street, Springfield!"          # 55 bytes
+    assert len(base) == 55
+    vals = [base, base[:-1] + "?", base[:54], base[:48], base[:47] + "x", base[:47] + "y", base[:40], base[:39], base[:32], base[:31], base[:33] + "é",
+            "", "short", "héllo wörld " * 3]
+    assert max(len(v.encode()) for v in vals) == 55
+    n = 30000
+    schema = pa.schema([pa.field("name", pa.string()), pa.field("k", I64), pa.field("v", I64)])
+    batch = pa.RecordBatch.from_arrays([pa.array([vals[i] for i in rng.integers(0, len(vals), n)], type=pa.string(), mask=rng.random(n) < 0.04),
+                                        pa.array(rng.integers(0, 3, n), type=I64), pa.array(rng.integers(-1000, 1000, n), type=I64)], schema=schema)
+    scan = table_scan(schema, [batch.slice(0, 12000), batch.slice(12000)])
+    aggs = [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(lit_i64(1)), q.MinAggregateExpr(col("v", 2), I64)]
+    for keys in ([col("name", 0)], [col("k", 1), col("name", 0)]):
+        agg = q.HashAggregate(None, scan, keys, aggs)
+        got = sorted(rows_of(agg.execute()), key=repr)
+        assert got == sorted(rows_of(oracle.execute(agg)), key=repr) and len(got) >= len(vals)
+    rs = pa.schema([pa.field("who", pa.string()), pa.field("w", I64)])
+    rb = pa.RecordBatch.from_arrays([pa.array([base, base[:54], base[:47] + "y", "nobody " * 7, None, base, "short"]), pa.array(range(7), type=I64)], schema=rs)
+    for jt in (JoinType.Inner, JoinType.Left, JoinType.Right, JoinType.Full, JoinType.LeftSemi, JoinType.LeftAnti):
+        plan = q.HashJoinExec.try_new(table_scan(rs, [rb]), scan, jt, [(col("who", 0), col("name", 0))], None)
+        _batches_equal(plan.execute(), oracle.execute(plan))
