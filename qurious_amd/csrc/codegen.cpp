@@ -695,17 +695,17 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   for (auto& ic : input) if (ic.narrow_bytes > 0 && !ic.indirect) narrow_copies = true;
   if (all_narrow && narrow_copies && part_regs > 0) P.KC = std::max(1, std::min(4, 48 / part_regs));
   if (const char* kc = getenv("QHIP_AGG_KC")) { if (*kc && P.W > 0) P.KC = atoi(kc); }   // tuning experiments only
+  int row_regs = 1 + 2 * P.W;   // VGPRs of one evaluated row: pass flag, key words, argument dwords
+  for (size_t a = 0; a < P.args.size(); ++a) {
+    bool value_needed = false;
+    for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
+    if (value_needed) row_regs += arg64[a] ? 2 : std::max(1, dtype_width(P.args[a].type) / 4);
+    if (P.args[a].nullable) row_regs += 1;
+  }
   if (P.R <= 0) {
     // rows per thread per tile: all loads of a tile are in flight together, so more rows = more memory-level
     // parallelism, until registers cut the occupancy. One Row costs 1 + 2 W + (argument dwords) VGPRs, the cache
     // KC x part_regs. Measured on MI355X: q1_mini (7 regs/row) best at R = 4, Q1 (25 regs/row, 80 cache regs) at R = 2.
-    int row_regs = 1 + 2 * P.W;
-    for (size_t a = 0; a < P.args.size(); ++a) {
-      bool value_needed = false;
-      for (auto& c : P.cells) if (c.arg == (int)a && c.kind != CELL_CNT) value_needed = true;
-      if (value_needed) row_regs += arg64[a] ? 2 : std::max(1, dtype_width(P.args[a].type) / 4);
-      if (P.args[a].nullable) row_regs += 1;
-    }
     P.R = std::max(1, std::min(4, ((all_narrow ? 72 : 144) - P.KC * part_regs) / row_regs));   // (narrow Q1: R = 3, 0.641 ms; 2: 0.666; 4: 0.659)
   }
 
@@ -733,7 +733,15 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
   // vectors, no validity bitmaps, no Booleans, strings only as one-byte flags) and at most 8 bytes wide in the layout that is
   // streamed — a lane's RC values of a column are then adjacent bytes and load as one instruction.
   P.RC = 0;
-  if (!dev_rows && env_int("QHIP_AGG_CONS", 1) != 0) {
+  // QHIP_AGG_CONS: 0 never, 1 (default) when the registers allow, 2 whenever the columns allow. Measured on MI355X, one box
+  // (profiles/r04_q1_consecutive_rows.txt): q1_mini (100 M rows, 9 B per row, one narrow SUM: 84-120 VGPRs) rows r*256+tid 0.225 ms,
+  // consecutive rows x 4 with two register sets 0.200 ms (0.50 -> 0.56 of the HBM peak); TPC-H Q1's list at SF10 (22 B per row,
+  // five SUMs x four cached keys) 0.268 ms against 0.291-0.368 ms — a quarter of the load instructions and twice the bytes in
+  // flight per wavefront do not pay for 147-235 VGPRs against 127 (three or two wavefronts per SIMD instead of four). Hence the
+  // rule: the cached keys' accumulators + four evaluated rows within 64 VGPRs.
+  const int cons_mode = env_int("QHIP_AGG_CONS", 1);
+  const bool cons_fits = KC * part_regs + 4 * row_regs <= 64;
+  if (!dev_rows && (cons_mode == 2 || (cons_mode == 1 && cons_fits))) {
     bool ok = !input.empty();
     int widest = 0;
     std::vector<char> used(es.nodes.size(), 0);
@@ -764,7 +772,7 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (ok && widest > 0) P.RC = std::max(1, std::min(8, env_int("QHIP_AGG_CONS_R", 4)));
   }
   s << "  static constexpr int RC = " << std::max(1, P.RC) << ";\n";
-  s << "  static constexpr int CSB = " << std::max(1, std::min(4, env_int("QHIP_AGG_CONS_SB", 1))) << ";\n";
+  s << "  static constexpr int CSB = " << std::max(1, std::min(4, env_int("QHIP_AGG_CONS_SB", 4))) << ";\n";
   s << "  static constexpr int CPIPE = " << (env_int("QHIP_AGG_CONS_PIPE", 1) != 0 ? 1 : 0) << ";\n";
   s << "  static constexpr int KC = " << KC << ";\n";
   s << "  struct Row {\n    bool pass;\n    u64 key[" << KW << "];\n";

@@ -405,3 +405,46 @@ def test_remembered_group_count_from_a_smaller_table_does_not_truncate_the_resul
         got_k = np.array([r[0] for r in got]); got_v = np.array([r[1] for r in got], dtype=np.float64)
         assert (np.sort(got_k) == present).all() and (got_v == want[got_k]).all()
     assert len(rows_of(small.execute())) == 6_000     # ... and back: a remembered count far above the truth
+
+
+def test_consecutive_rows_form_of_the_fused_kernel(ctx, oracle, monkeypatch):
+    """QHIP_AGG_CONS=2 (forced; automatic only for register-light plans: measured slower on Q1): a lane owns four consecutive rows of a tile and
+    loads a column's four values at once; the last, partial tile is shifted back and the rows it shares with the tile before
+    are masked out. Q1's shape (two one-byte string keys, narrow decimal copies, a date filter) over row counts around the
+    tile size, evaluated 1 / 2 / 4 rows at a time, with and without the second register set."""
+    import decimal
+    rng = np.random.default_rng(3)
+    schema = pa.schema([pa.field("f", pa.string()), pa.field("s", pa.string()), pa.field("d", pa.date32()), pa.field("q", pa.decimal128(15, 2)),
+                        pa.field("p", pa.decimal128(15, 2)), pa.field("i", pa.int32())])
+
+    def batch_of(n):
+        return pa.RecordBatch.from_arrays([
+            pa.array([("A", "N", "R")[v] for v in rng.integers(0, 3, n)]), pa.array([("F", "O")[v] for v in rng.integers(0, 2, n)]),
+            pa.array(rng.integers(9000, 10600, n).astype(np.int32), type=pa.int32()).cast(pa.date32()),
+            pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(100, 5001, n)], type=pa.decimal128(15, 2)),
+            pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-90000, 10**7, n)], type=pa.decimal128(15, 2)),
+            pa.array(rng.integers(-5, 5, n), type=pa.int32())], schema=schema)
+
+    D = pa.decimal128(15, 2)
+    pred = q.BinaryExpr(col("d", 2), Operator.LtEq, q.CastExpr(q.Literal(q.ScalarValue.Int32(10400)), pa.date32()))
+    monkeypatch.setenv("QHIP_AGG_CONS", "2")
+    monkeypatch.setenv("QHIP_STATS_MIN_ROWS", "1")          # narrow copies from the first read on
+    for sb, pipe in (("1", "0"), ("2", "1"), ("4", "0"), ("4", "1")):
+        monkeypatch.setenv("QHIP_AGG_CONS_SB", sb)
+        monkeypatch.setenv("QHIP_AGG_CONS_PIPE", pipe)
+        ctx.forget_plans()
+        for n in (65_536, 65_537, 70_000, 262_144 + 1023, 300_001):
+            b = batch_of(n)
+            scan = table_scan(schema, [b.slice(0, n // 3), b.slice(n // 3)], pred)
+            plan = q.HashAggregate(None, scan, [col("f", 0), col("s", 1)],
+                                   [q.SumAggregateExpr(col("q", 3), D), q.SumAggregateExpr(col("p", 4), D), q.CountAggregateExpr(lit_i64(1)),
+                                    q.SumAggregateExpr(q.BinaryExpr(col("q", 3), Operator.Mul, col("p", 4)), pa.decimal128(31, 4))])
+            for _ in range(2):
+                got = _same(plan, oracle)
+            assert ctx.last_stats()["main_kernel_name"] == "qk_filter_agg_cons" and len(got) == 6, (sb, pipe, n)
+        # an Int32 key next to the flags (three key words), MIN / MAX cells
+        plan = q.HashAggregate(None, table_scan(schema, [batch_of(100_000)]), [col("i", 5), col("f", 0)],
+                               [q.MinAggregateExpr(col("p", 4), D), q.MaxAggregateExpr(col("q", 3), D), q.CountAggregateExpr(col("p", 4))])
+        _same(plan, oracle)
+        assert ctx.last_stats()["main_kernel_name"] == "qk_filter_agg_cons"
+    ctx.forget_plans()
