@@ -441,7 +441,11 @@ class Q3:
             kernels.append(dict(roofline(pname, j["main_kernel_ms"], pb, t, src, kernel_bytes_per_row=j["bytes_per_row_read"],
                                          rows_per_launch=j["rows_in"]), operator=f"join {k + 1} probe", pairs=j["groups"],
                                 table_layout="dense: exact bitmap over the key range + row_of[key - min]" if dense else "hashed: open addressing + blocked filter"))
-            if dense:   # key columns read + bitmap cleared and set + one row_of entry written per build row
+            if dense and os.environ.get("QHIP_JOIN_DENSE_BYTEMAP", "0") not in ("0", ""):
+                # key columns read + one stamp byte and one row_of entry written per build row + the byte map read and the bitmap written
+                bb = j["build_rows"] * (j["build_bytes_per_row"] + 5.0) + j["table_capacity"] * (1.0 + 1.0 / 8.0)
+                bname = "qk_join_dense_build + k_bytes_to_bits"
+            elif dense:   # key columns read + bitmap cleared and set + one row_of entry written per build row
                 bb = j["build_rows"] * (j["build_bytes_per_row"] + 4.0) + j["table_capacity"] / 8.0 * 2
                 bname = "memset + qk_join_dense_build"
             else:       # key columns read + table and filter written

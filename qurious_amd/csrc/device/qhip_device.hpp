@@ -1819,19 +1819,22 @@ __device__ __forceinline__ void qh_join_probe_body(const KArgs& a, const ProbeLa
 // reference's ascending chains); NULL keys and rows rejected by a fused scan filter have no valid key and are never
 // inserted or probed.
 struct DenseBuildLaunch {
-  u32* bits;        // zero-filled bitmap, 32-bit words
+  u32* bits;        // zero-filled bitmap, 32-bit words (byte-map form: written afterwards by k_bytes_to_bits, not touched here)
   u32* row_of;      // uninitialised; row_of[key - kmin] = build row for every inserted key
   u32* status;
   u64 kmin;
   u32 n;            // keys in the range
-  u32 pad_;
+  u32 gen;          // byte-map form: the stamp of this execution (1..255)
+  u8* bytes;        // byte-map form (round 4), else null: bytes[key - kmin] = gen — a PLAIN store where the bitmap needs an atomic
+  u32* counters;    // byte-map form: [0] += rows inserted (k_bytes_to_bits counts the stamped bytes: fewer = a duplicate key)
 };
 template <class P, bool DEVROWS = false>
 __device__ __forceinline__ void qh_join_dense_build_body(const KArgs& a, const DenseBuildLaunch& L) {
   constexpr int R = 4;
   const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
   const i64 tile = (i64)QH_BLOCK * R;
-  u32 err = 0, dup = 0, out_of_range = 0;
+  u32 err = 0, dup = 0, out_of_range = 0, inserted = 0;
+  const bool bytemap = L.bytes != nullptr;   // (uniform over the grid)
   for (i64 tb = (i64)blockIdx.x * tile; tb < nrows; tb += (i64)gridDim.x * tile) {
     u64 k[R][P::W];
     bool ok[R];
@@ -1851,15 +1854,28 @@ __device__ __forceinline__ void qh_join_dense_build_body(const KArgs& a, const D
       const u64 idx = k[r][0] - L.kmin;
       if (ok[r]) {
         if (idx < (u64)L.n) {
-          const u32 bit = 1u << ((u32)idx & 31u);
-          const u32 old = __hip_atomic_fetch_or(&L.bits[(u32)idx >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dup |= (old & bit) ? 1u : 0u;
+          if (bytemap) {
+            // no atomic: a stamp byte per key value; two rows with one key stamp the same byte, which the packing kernel's count
+            // of stamped bytes against the rows inserted here reveals (the memory side serves ~32 G scattered atomics per second —
+            // join 2's 1.46 M bitmap atomics were its whole 52 us — but plain stores are absorbed by the L2s)
+            L.bytes[(u32)idx] = (u8)L.gen;
+            ++inserted;
+          } else {
+            const u32 bit = 1u << ((u32)idx & 31u);
+            const u32 old = __hip_atomic_fetch_or(&L.bits[(u32)idx >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dup |= (old & bit) ? 1u : 0u;
+          }
           L.row_of[(u32)idx] = (u32)(tb + (i64)r * QH_BLOCK + threadIdx.x);
         } else out_of_range = 1u;   // (cannot happen: the range comes from the column's own values; reported, never ignored)
       }
     }
   }
   qh_report(L.status, err | (out_of_range << QS_OVERFLOW));
+  if (bytemap) {
+    const u32 wave_rows = (u32)qh_wave_sum_u64((u64)inserted);
+    if (qh_lane() == 0 && wave_rows) atomicAdd(&L.counters[0], wave_rows);
+    return;
+  }
   // duplicate build keys: status[QS_MAXCOUNT] = 2 (one atomic per wavefront that saw one, none when it is already up)
   if (__builtin_amdgcn_readfirstlane((int)(qh_ballot(dup != 0) != 0)) && qh_lane() == 0 &&
       __hip_atomic_load(&L.status[QS_MAXCOUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)

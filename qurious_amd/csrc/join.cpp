@@ -186,7 +186,12 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     const int v[5] = {lpred, rpred, want_regions ? 1 : 0, L->rows_dev ? 1 : 0, dense ? 1 : 0};
     put(v, sizeof v);
   }
-  struct JoinPlan { KeysPlan lkp, rkp; std::shared_ptr<Module> lmod; std::map<std::string, std::shared_ptr<Module>> rmods; DevBuf lstr, rstr; };   // (+ the string literals, uploaded once)
+  struct JoinPlan {
+    KeysPlan lkp, rkp; std::shared_ptr<Module> lmod; std::map<std::string, std::shared_ptr<Module>> rmods; DevBuf lstr, rstr;   // (+ the string literals, uploaded once)
+    // the dense build's byte map, kept between executions: bytes[key - min] = the execution's stamp (1..255), so that it is
+    // cleared once in 255 executions instead of every time (8x the bitmap's bytes: 60 MB for Q3's join 2)
+    std::shared_ptr<DevBuf> bytemap; uint64_t bytemap_n = 0; uint32_t bytemap_gen = 0;
+  };
   std::shared_ptr<JoinPlan> jp;
   {
     auto cached = ctx->plan_cache.find(pkey);
@@ -273,14 +278,48 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
     if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);
     HKArgs ka;
     fill_kargs(ctx, L, lkp.bind, ka, jp->lstr);
-    QHIP_HIP_CHECK(hipMemsetAsync(bloom, 0, bloom_bytes, s));
+    // Byte-map form (round 4, QHIP_JOIN_DENSE_BYTEMAP=1; OFF by default): the build stamps one byte per key with a plain store,
+    // a second kernel packs the bytes into the bitmap the probe reads and detects duplicate keys by counting — built to get
+    // rid of the bitmap's scattered atomics (~32 G/s at the memory side) and measured SIX TIMES SLOWER on Q3 at SF10 (A/B on one
+    // box, profiles/r04_dense_build_bytemap.txt): join 2's build 61 -> 352 us, join 1's 39 -> 86 us. A scattered ONE-BYTE store is
+    // the worst thing one can ask of this memory system: every one becomes a read-modify-write of its ECC word at the memory
+    // side (~5 G per second), where a scattered 4-byte atomic OR is served at ~32 G/s. Kept as a tested switch, not as a path.
+    bool bytemap = env_int("QHIP_JOIN_DENSE_BYTEMAP", 0) != 0 && dense_n <= (1ull << std::max(10, std::min(30, env_int("QHIP_JOIN_DENSE_BYTEMAP_MAX_BITS", 27))));
     HDenseBuildLaunch dl;
     dl.bits = (uint32_t*)bloom; dl.row_of = (uint32_t*)table; dl.status = dstat;
     dl.kmin = (uint64_t)kmin; dl.n = (uint32_t)dense_n;
+    if (bytemap) {
+      const size_t map_bytes = (size_t)dense_words * 32;   // (whole bitmap words: the packing kernel reads 32 bytes per word)
+      if (!jp->bytemap || jp->bytemap_n != dense_n || jp->bytemap_gen >= 255) {
+        if (!jp->bytemap || jp->bytemap_n != dense_n) {
+          jp->bytemap.reset();
+          jp->bytemap_n = 0;
+          try {
+            jp->bytemap = std::make_shared<DevBuf>(map_bytes);
+          } catch (const Error& e) {
+            if (e.code != QHIP_OUT_OF_MEMORY) throw;
+            bytemap = false;   // (the map stays with the plan between executions: when HBM is short, the atomic form needs no such buffer)
+          }
+        }
+        if (bytemap) {
+          QHIP_HIP_CHECK(hipMemsetAsync(jp->bytemap->ptr, 0, map_bytes, s));
+          jp->bytemap_n = dense_n;
+          jp->bytemap_gen = 0;
+        }
+      }
+    }
+    if (bytemap) {
+      dl.gen = ++jp->bytemap_gen;
+      dl.bytes = jp->bytemap->as<uint8_t>();
+      dl.counters = zeroed_block(ctx);
+    } else {
+      QHIP_HIP_CHECK(hipMemsetAsync(bloom, 0, bloom_bytes, s));
+    }
     void* args[] = {&ka, &dl};
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((B + 1023) / 1024, (uint64_t)ctx->num_cus * 8));
     trace_point("join: first launch");
     QHIP_HIP_CHECK(hipModuleLaunchKernel(jp->lmod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    if (bytemap) launch_bytes_to_bits(dl.bytes, dl.gen, dl.bits, dense_words, dl.counters, dstat, s);
     trace_point("join: first launch done");
   } else if (region_build) {
     if (!jp->lmod) jp->lmod = get_module(ctx, lkp.source, lkp.kernel_name);

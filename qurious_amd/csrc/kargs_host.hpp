@@ -92,9 +92,11 @@ struct HDenseBuildLaunch {
   uint32_t* status;
   uint64_t kmin;
   uint32_t n;
-  uint32_t pad_ = 0;
+  uint32_t gen = 0;
+  uint8_t* bytes = nullptr;
+  uint32_t* counters = nullptr;
 };
-static_assert(sizeof(HDenseBuildLaunch) == 40, "DenseBuildLaunch layout");
+static_assert(sizeof(HDenseBuildLaunch) == 56, "DenseBuildLaunch layout");
 
 struct HPartIdsLaunch {
   uint8_t* ids;

@@ -68,6 +68,7 @@ struct GatherBatch { GatherDesc d[kGatherBatch]; };
 void launch_gather_multi(const GatherBatch& b, int n, hipStream_t s);
 void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint32_t* out, uint64_t m, hipStream_t s);
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s);
+void launch_bytes_to_bits(const uint8_t* bytes, uint32_t gen, uint32_t* bits, uint32_t nwords, uint32_t* counters, uint32_t* status, hipStream_t s);
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
                       const uint32_t* start, const uint32_t* rows, const uint32_t* row_of, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
                       uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish,

@@ -572,6 +572,46 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_full_counts(const u64* table,
     if (table[(size_t)s * (1 + W)] >= QH_READY) count[s] += 1u;
 }
 
+// The dense join build's byte map -> its bitmap (round 4): thread w turns bytes[32 w .. 32 w + 31] into bitmap word w (bit i =
+// "byte i carries this execution's stamp") and the grid counts the stamped bytes; the LAST workgroup to finish compares the
+// count with the rows the build kernel inserted — fewer stamped bytes = two rows stamped the same byte = a duplicate build key
+// (status[QS_MAXCOUNT] = 2, the same signal the atomic form raises; the join is then re-run with the chained layout).
+// counters: [0] rows inserted (build kernel), [1] stamped bytes, [2] workgroups done. The byte map is padded to whole words.
+__global__ __launch_bounds__(QH_BLOCK) void k_bytes_to_bits(const u8* bytes, u32 gen, u32* bits, u32 nwords, u32* counters, u32* status) {
+  const u32 w = blockIdx.x * QH_BLOCK + threadIdx.x;
+  u32 word = 0;
+  if (w < nwords) {
+    typedef u32 v4 __attribute__((ext_vector_type(4)));
+    const v4* src = (const v4*)(bytes + (size_t)w * 32);
+    const v4 a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 1);
+    const u32 d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const u32 g4 = gen * 0x01010101u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 t = d[k] ^ g4;                                                     // a zero byte = a stamped one
+      const u32 eq = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;        // exact per byte: 0x80 where the byte of t is zero
+      word |= (((eq >> 7) * 0x10204080u) >> 28) << (4 * k);                         // bytes 0..3 -> bits 0..3
+    }
+    bits[w] = word;
+  }
+  const u32 mine = (u32)qh_wave_sum_u64((u64)__builtin_popcount(word));
+  __shared__ u32 wg_total;
+  if (threadIdx.x == 0) wg_total = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&wg_total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (wg_total) atomicAdd(&counters[1], wg_total);
+    __threadfence();
+    const u32 ticket = atomicAdd(&counters[2], 1u);
+    if (ticket == gridDim.x - 1) {
+      const u32 stamped = __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 inserted = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (stamped < inserted) atomicMax(&status[QS_MAXCOUNT], 2u);
+    }
+  }
+}
+
 // probe pass 2 (get_matches_indices + probe_hash_table's index vectors, hash_join.rs:70-107,177-216): turn the
 // (slot, probe row) entries that pass 1 (qk_join_probe, device/qhip_device.hpp) compacted per tile into (build row,
 // probe row) pairs — probe-row major, build rows ascending (hash_join.rs:475-512 pins that order). A wavefront owns the
@@ -1254,6 +1294,11 @@ void launch_gather_u32_nullable(const uint32_t* inner, const uint32_t* idx, uint
 }
 void launch_lower_bound_u32(const uint32_t* a, uint64_t m, const uint32_t* m_dev, const uint64_t* bound, uint32_t nb, uint32_t* pos, hipStream_t s) {
   if (nb) hipLaunchKernelGGL(k_lower_bound_u32, dim3((nb + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u32*)a, (u64)m, (const u32*)m_dev, (const u64*)bound, nb, (u32*)pos);
+}
+void launch_bytes_to_bits(const uint8_t* bytes, uint32_t gen, uint32_t* bits, uint32_t nwords, uint32_t* counters, uint32_t* status, hipStream_t s) {
+  if (!nwords) return;
+  hipLaunchKernelGGL(k_bytes_to_bits, dim3((nwords + QH_BLOCK - 1) / QH_BLOCK), dim3(QH_BLOCK), 0, s, (const u8*)bytes, (u32)gen, (u32*)bits, (u32)nwords,
+                     (u32*)counters, (u32*)status);
 }
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
                       const uint32_t* start, const uint32_t* rows, const uint32_t* row_of, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,

@@ -282,10 +282,14 @@ def test_utf8_keys_of_32_to_55_bytes(ctx, oracle, join_layout):
                                         pa.array(rng.integers(0, 3, n), type=I64), pa.array(rng.integers(-1000, 1000, n), type=I64)], schema=schema)
     scan = table_scan(schema, [batch.slice(0, 12000), batch.slice(12000)])
     aggs = [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(lit_i64(1)), q.MinAggregateExpr(col("v", 2), I64)]
-    for keys in ([col("name", 0)], [col("k", 1), col("name", 0)]):
-        agg = q.HashAggregate(None, scan, keys, aggs)
+    # (a whole key has at most 8 words: 7 of the name + the NULL-mask word here, 7 + the Int64 key over the NULL-free copy below)
+    dense = pa.RecordBatch.from_arrays([pa.array([vals[i] for i in rng.integers(0, len(vals), n)], type=pa.string()), batch.column(1), batch.column(2)], schema=schema)
+    for src, keys in ((scan, [col("name", 0)]), (table_scan(schema, [dense]), [col("k", 1), col("name", 0)])):
+        agg = q.HashAggregate(None, src, keys, aggs)
         got = sorted(rows_of(agg.execute()), key=repr)
         assert got == sorted(rows_of(oracle.execute(agg)), key=repr) and len(got) >= len(vals)
+    with pytest.raises(q.UnsupportedError, match="wider than 8 words"):
+        q.HashAggregate(None, scan, [col("k", 1), col("name", 0)], aggs).execute()
     rs = pa.schema([pa.field("who", pa.string()), pa.field("w", I64)])
     rb = pa.RecordBatch.from_arrays([pa.array([base, base[:54], base[:47] + "y", "nobody " * 7, None, base, "short"]), pa.array(range(7), type=I64)], schema=rs)
     for jt in (JoinType.Inner, JoinType.Left, JoinType.Right, JoinType.Full, JoinType.LeftSemi, JoinType.LeftAnti):

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qurious_amd as q
 from qurious_amd import synth
 ctx = q.get_context()
-t = time.perf_counter(); batches = synth.lineitem(100_000_000, 1 << 20); print("generate s", time.perf_counter() - t, flush=True)
+t = time.perf_counter(); batches = synth.lineitem(int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000, 1 << 20); print("generate s", time.perf_counter() - t, flush=True)
 nbytes = sum(b.nbytes for b in batches)
 for it in range(3):
     t = time.perf_counter()
