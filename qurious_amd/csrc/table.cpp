@@ -310,7 +310,7 @@ struct PinnedPool {
   size_t cached = 0, out = 0;
   void* take(size_t n, int& cls) {
     cls = -1;
-    if (n < kMin || getenv("QHIP_EXPORT_PAGEABLE")) return nullptr;
+    if (n < kMin || env_int("QHIP_EXPORT_PAGEABLE", 0) != 0) return nullptr;
     int k = 0;
     size_t c = kMin;
     while (c < n && k < 15) { c <<= 1; ++k; }
