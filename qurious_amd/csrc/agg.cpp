@@ -563,6 +563,65 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   uint64_t* table_dev = nullptr;
   uint64_t* dense_dev = nullptr;    // [counter | dense slots]
   bool ran_partitioned = false;
+  // ---- an input whose equal keys are adjacent (qh_agg_runs_body): no table, no compaction — the kernel writes the dense slots.
+  // Tried when the plan produced many SHORT runs' worth of groups last time (>= 4096 groups, on average <= 16 rows each) and no
+  // execution has found its input unsorted; the kernel verifies the order and the host falls through to the hashed path when
+  // it does not hold. QHIP_AGG_RUNS: 0 never, 1 (default) by that rule, 2 whenever the plan has the entry point (tests).
+  bool ran_runs = false;
+  {
+    const int runs_mode = env_int("QHIP_AGG_RUNS", 1);
+    const bool eligible = plan.has_runs && !parts && plan.W > 0 && N > 0 && N < ((int64_t)1 << 31) && (uint64_t)N * slot_bytes <= (256ull << 20) && !plan.not_sorted;
+    const bool worth = plan.last_groups >= 4096 && (uint64_t)plan.last_groups * 16 >= (uint64_t)N;
+    if (eligible && (runs_mode == 2 || (runs_mode == 1 && worth))) {
+      guess = (uint32_t)N;                          // one slot per row at worst: nothing can be lost
+      dense.alloc((size_t)guess * slot_bytes + 8);
+      dense_dev = dense.as<uint64_t>();
+      const int ncols = n_groups + n_aggs;
+      uint32_t* status_dev = zeroed_block(ctx, (32 + QS_WORDS + ncols + 31) / 32);
+      uint32_t* const counter_dev = status_dev + 16;
+      HRunsLaunch rl;
+      rl.dense_out = dense_dev + 1; rl.counter = counter_dev; rl.status = status_dev; rl.flags = status_dev + 20;
+      rl.cap = guess; rl.max_run = (uint32_t)std::max(16, env_int("QHIP_AGG_RUNS_MAX", 256));
+      void* rargs[] = {&ka, &rl};
+      std::shared_ptr<Module> rmod = get_module(ctx, plan.source, "qk_agg_runs");
+      const unsigned rgrid = (unsigned)((N + 1023) / 1024);
+      time_mark(ctx, 0);
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(rmod->fn, rgrid, 1, 1, 256, 1, 1, 0, ctx->stream, rargs, nullptr));
+      time_mark(ctx, 1);
+      bool utf8_key = false;
+      for (auto& kd : plan.keys) utf8_key = utf8_key || kd.type.id == QHIP_UTF8;
+      const bool will_spec = plan.last_groups >= dev_threshold && !utf8_key && env_int("QHIP_AGG_NO_SPECULATIVE_FINALIZE", 0) == 0;
+      if (will_spec) {
+        spec = DevFinal();
+        enqueue_device_finalize(spec, dense_dev + 1, guess, counter_dev, status_dev + 32, status_pinned + 32);
+        spec_enqueued = true;
+      }
+      // ONE read-back: status + counter + the order flags (word 20) + the finalisation's status and null counts
+      QHIP_HIP_CHECK(hipMemcpyAsync(status_pinned, status_dev, (size_t)(32 + QS_WORDS + ncols) * 4, hipMemcpyDeviceToHost, ctx->stream));
+      QHIP_HIP_CHECK(sync_stream(ctx->stream));
+      memcpy(status, status_pinned, sizeof(status));
+      verify_pending_sizes(ctx);
+      if (in->rows_dev && in->deferred_count() == 0 && n_groups > 0) return no_batches_out();
+      if (ctx->timing) QHIP_HIP_CHECK(hipEventElapsedTime(&main_ms, ctx->ev[0], ctx->ev[1]));
+      if (status_pinned[20] == 0) {
+        check_status_words(status);
+        ran_runs = true;
+        replicas = 1;
+        cap = guess;
+        grid = rgrid;
+        l_nslots = 0;
+      } else {
+        // not that kind of input (or a few long runs): remember, and aggregate it through the table
+        plan.not_sorted = true;
+        spec = DevFinal();
+        spec_enqueued = false;
+        dense = DevBuf();
+        dense_dev = nullptr;
+        ++retries;
+      }
+    }
+  }
+  if (!ran_runs)
   for (;;) {
     const size_t table_bytes = (size_t)cap * replicas * slot_bytes;
     const uint32_t total_slots = cap * replicas;
@@ -881,7 +940,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
       ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
       ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
+      snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : ran_runs ? "qk_agg_runs" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
       return result;
     }
     if (replicas == 1 && G >= dev_threshold) {
@@ -959,7 +1018,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
     ctx->stats.lds_spilled = lds_spilled ? 1 : 0;
     ctx->stats.hbm_table_load = cap ? (double)G / ((double)cap * replicas) : 0.0;
     ctx->stats.lds_occupancy = (env_int("QHIP_AGG_STATS", 0) && l_nslots) ? (double)lds_used / ((double)grid * l_nslots) : -1.0;
-    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
+    snprintf(ctx->stats.main_kernel_name, sizeof ctx->stats.main_kernel_name, "%s", ran_partitioned ? "qk_agg_part_hist+scatter+reduce" : parts ? "qk_part_ids+qk_part_scatter+qk_filter_agg_parts" : ran_runs ? "qk_agg_runs" : cons ? "qk_filter_agg_cons" : plan.kernel_name.c_str());
   };
   if (dense_keep.ptr) {
     // ---- many groups: assemble the output columns on the device (k_agg_finalize), nothing crosses PCIe

@@ -951,6 +951,11 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     if (P.W > 0)
       s << "extern \"C\" __global__ __launch_bounds__(1024) void qk_filter_agg_wide(KArgs a, AggLaunch L) { qh_filter_agg_body<P, " << (dev_rows ? "true" : "false")
         << ", 1024>(a, L); }\n";
+    // ... an input whose equal keys are adjacent (checked on the device): runs instead of a hash table
+    if (P.W > 0 && predicate_root < 0) {
+      P.has_runs = true;
+      s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_agg_runs(KArgs a, RunsLaunch L) { qh_agg_runs_body<P" << dr << ">(a, L); }\n";
+    }
     // ... a lane owning RC consecutive rows (narrow plain layouts: wide loads)
     if (P.RC > 0)
       s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) " << wattr << "void qk_filter_agg_cons(KArgs a, AggLaunch L) { qh_filter_agg_body<P, false, QH_BLOCK, false, true>(a, L); }\n";

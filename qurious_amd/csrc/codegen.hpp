@@ -85,6 +85,8 @@ struct AggPlan {
   int KC = 0;                  // wave-resident hot keys
   int slot_words = 0;          // 1 + W + cell words
   int part_pr = 0;             // partitioned path: rows per thread of the LDS-staged scatter (0: records too wide for it)
+  bool has_runs = false;       // the source has the sorted-run entry point qk_agg_runs (grouped, no scan filter)
+  mutable bool not_sorted = false;   // ... and an execution found this plan's input not to be of that kind (never tried again)
   int RC = 0;                  // rows per lane of the consecutive-rows form (qk_filter_agg_cons); 0 = the plan has no such entry point
   std::vector<KeyDesc> keys;
   std::vector<ArgDesc> args;

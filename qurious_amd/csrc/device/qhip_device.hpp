@@ -961,6 +961,129 @@ __device__ __forceinline__ void qh_agg_part_stage_body(const KArgs& a, const Par
   }
 }
 
+// ---- aggregation of an input whose equal keys are ADJACENT (round 4: qk_agg_runs). A join output in probe order over a probe
+// side stored in key order — TPC-H Q3: lineitem is in l_orderkey order, so the three rows of an order arrive side by side — needs
+// no hash table: a group is a RUN of rows. A thread evaluates four consecutive rows and the row in front of them; where a row's key
+// differs from its predecessor's a run starts, and the thread that owns the start folds the run (on into the next threads' rows
+// when it is longer: they skip rows that do not start a run) and writes the group as a dense slot [READY | key words | cells] —
+// the format the compaction of the hashed path produces, so everything behind it is shared. Whether the input IS of that kind is
+// checked here, not assumed: the key-word tuples must be non-decreasing (under the unsigned word order — any total order will do)
+// from every row to the next, which makes equal keys adjacent; a violation, or a run longer than L.max_run (a few-group input:
+// one thread would fold millions of rows), raises a flag and the host runs the hashed kernel instead and remembers (agg.cpp).
+// No scan filter (a rejected row between two rows of one key would split its run), no NULL handling beyond the key's mask word.
+struct RunsLaunch {
+  u64* dense_out;     // cap slots
+  u32* counter;       // += runs written
+  u32* status;        // QS_WORDS words
+  u32* flags;         // |= 1: keys not non-decreasing, |= 2: a run longer than max_run
+  u32 cap, max_run;
+};
+template <class P, bool DEVROWS = false>
+__device__ __forceinline__ void qh_agg_runs_body(const KArgs& a, const RunsLaunch& L) {
+  constexpr int W = P::W > 0 ? P::W : 1, R = 4;
+  const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
+  const i64 tb = (i64)blockIdx.x * (QH_BLOCK * R);
+  if (tb >= nrows) return;                       // (workgroup-uniform)
+  const int lane = qh_lane();
+  const u32 o0 = threadIdx.x * (u32)R;
+  const i64 base = tb + (i64)o0;
+  u32 err = 0, bad = 0;
+  typename P::Raw raw[R], rawp;
+  typename P::Row row[R], rowp;
+  const bool have_prev = base > 0 && base < nrows;
+  P::load(a, have_prev ? base - 1 : 0, 0u, rawp);
+#pragma unroll
+  for (int r = 0; r < R; ++r) P::load(a, tb, base + r < nrows ? o0 + (u32)r : (u32)(nrows - 1 - tb), raw[r]);
+  {
+    u32 e = 0;
+    P::eval(a, rawp, rowp, e);
+    err |= have_prev ? e : 0u;
+  }
+  bool start[R];
+  u32 nstart = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool inb = base + r < nrows;
+    u32 e = 0;
+    P::eval(a, raw[r], row[r], e);
+    err |= inb ? e : 0u;
+    const u64* pk = r == 0 ? rowp.key : row[r - 1].key;
+    const bool has = r == 0 ? have_prev : true;
+    bool same = has, less = false, decided = false;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const u64 x = row[r].key[w], y = pk[w];
+      same = same && x == y;
+      if (!decided && x != y) { less = x < y; decided = true; }
+    }
+    if (inb && has && less) bad |= 1u;
+    start[r] = inb && !same;
+    nstart += start[r] ? 1u : 0u;
+  }
+  // one reservation per wavefront for the runs its lanes start
+  const u32 incl = qh_wave_incl_scan_u32(nstart, lane);
+  const u32 wave_total = qh_readlane32(incl, 63);
+  u32 wave_base = 0;
+  if (wave_total) {
+    if (lane == 0) wave_base = atomicAdd(L.counter, wave_total);
+    wave_base = qh_readlane32(wave_base, 0);
+  }
+  u32 at = wave_base + incl - nstart;
+  // (statically unrolled: rows in front of this thread's first start belong to a run of a thread before it)
+  typename P::Part part;
+  u64 fk[W];
+  bool open = false;
+  auto flush = [&]() {
+    if (at < L.cap) {
+      u64* o = L.dense_out + (size_t)at * P::SLOT_WORDS;
+      o[0] = QH_READY;
+#pragma unroll
+      for (int w = 0; w < W; ++w) o[1 + w] = fk[w];
+      P::part_to_slot(o, part);
+    }
+    ++at;
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (start[r]) {
+      if (open) flush();
+      P::part_init(part);
+#pragma unroll
+      for (int w = 0; w < W; ++w) fk[w] = row[r].key[w];
+      open = true;
+      P::template part_add<true>(part, row[r], true);
+    } else if (open && base + r < nrows) {
+      P::template part_add<true>(part, row[r], true);
+    }
+  }
+  if (open) {
+    // the run may go on in the rows of the threads behind this one
+    u32 steps = 0;
+    for (i64 x = base + R; x < nrows; ++x) {
+      typename P::Raw rx;
+      typename P::Row qx;
+      P::load(a, tb, (u32)(x - tb), rx);
+      u32 e = 0;
+      P::eval(a, rx, qx, e);
+      bool same = true;
+#pragma unroll
+      for (int w = 0; w < W; ++w) same = same && qx.key[w] == fk[w];
+      if (!same) break;
+      err |= e;
+      P::template part_add<true>(part, qx, true);
+      if (++steps > L.max_run) { bad |= 2u; break; }
+    }
+    flush();
+  }
+  qh_report(L.status, err);
+  if (qh_ballot(bad != 0) != 0) {
+    u32 all = bad;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) all |= (u32)__shfl_xor((int)all, d, 64);
+    if (lane == 0) atomicOr(L.flags, all);
+  }
+}
+
 struct ReduceLaunch {
   const u64* records;
   const u32* item_first;   // work item k = records [item_first[k], item_first[k + 1]), all of one bin — or nullptr:

@@ -60,6 +60,15 @@ struct HReduceLaunch {
 };
 static_assert(sizeof(HReduceLaunch) == 48, "ReduceLaunch layout");
 
+struct HRunsLaunch {
+  uint64_t* dense_out;
+  uint32_t* counter;
+  uint32_t* status;
+  uint32_t* flags;
+  uint32_t cap, max_run;
+};
+static_assert(sizeof(HRunsLaunch) == 40, "RunsLaunch layout");
+
 struct HProjOut {
   void* v[kMaxCols];
   uint64_t* n[kMaxCols];

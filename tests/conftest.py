@@ -78,24 +78,22 @@ def engine(request):
     return _HipEngine()
 
 
-@pytest.fixture(params=["auto", "regions", "hashed", "dense", "dense_lds", "dense_bytemap"])
+@pytest.fixture(params=["auto", "regions", "hashed", "dense", "dense_lds"])
 def join_layout(request, monkeypatch):
     """Every join test runs under each table layout of csrc/join.cpp: the one libqhip picks by itself (`auto`: the dense
     direct-address layout for one integer key of a small value range, else one hashed table filled with atomics / the
     LDS-staged region build for big build sides), the region build forced on every join (QHIP_JOIN_REGION=2) and the hashed
     layouts only (QHIP_JOIN_DENSE=0), the dense layout wherever the key qualifies whatever the range-to-rows ratio
-    (QHIP_JOIN_DENSE=2), the dense layout with its bitmap staged in LDS whatever the pays-rule says (QHIP_JOIN_DENSE_LDS=2), and the
-    dense layout with its bitmap packed from a byte map of plain stores instead of set by atomics (QHIP_JOIN_DENSE_BYTEMAP=1: built in
-    round 4, measured slower, off by default)."""
+    (QHIP_JOIN_DENSE=2), and the dense layout with its bitmap staged in LDS whatever the pays-rule says (QHIP_JOIN_DENSE_LDS=2).
+    (The byte-map form of the dense build, QHIP_JOIN_DENSE_BYTEMAP=1 — built in round 4, measured slower, off by default — is a
+    layout of tests/test_gpu_dense_join.py.)"""
     if request.param == "regions":
         monkeypatch.setenv("QHIP_JOIN_REGION", "2")
         monkeypatch.setenv("QHIP_JOIN_DENSE", "0")
     elif request.param == "hashed":
         monkeypatch.setenv("QHIP_JOIN_DENSE", "0")
-    elif request.param in ("dense", "dense_lds", "dense_bytemap"):
+    elif request.param in ("dense", "dense_lds"):
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
-        if request.param == "dense_bytemap":
-            monkeypatch.setenv("QHIP_JOIN_DENSE_BYTEMAP", "1")
         if request.param == "dense_lds":
             monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "2")
     return request.param

@@ -6,7 +6,7 @@ import pyarrow as pa
 import pytest
 
 import qurious_amd as q
-from qurious_amd import Operator, queries, synth
+from qurious_amd import JoinType, Operator, queries, synth
 from qurious_amd import ScalarValue as S
 
 from .helpers import col, lit_i64, rows_of, sorted_rows, table_scan
@@ -448,3 +448,122 @@ def test_consecutive_rows_form_of_the_fused_kernel(ctx, oracle, monkeypatch):
         _same(plan, oracle)
         assert ctx.last_stats()["main_kernel_name"] == "qk_filter_agg_cons"
     ctx.forget_plans()
+
+
+def _runs_table(rng, n, max_run, with_nulls=True):
+    """keys in non-decreasing order with runs of 1..max_run rows; a second key column that depends on the first; values of every kind"""
+    import decimal
+    lens = rng.integers(1, max_run + 1, n)
+    k = np.repeat(np.arange(len(lens)), lens)[:n] * 3 + 5
+    schema = pa.schema([pa.field("k", I64), pa.field("d", pa.date32()), pa.field("v", I64), pa.field("p", pa.decimal128(15, 2)), pa.field("f", pa.float64()),
+                        pa.field("s", pa.string())])
+    vmask = (rng.random(n) < 0.1) if with_nulls else None
+    batch = pa.RecordBatch.from_arrays([
+        pa.array(k, type=I64), pa.array((9000 + k % 700).astype(np.int32), type=pa.int32()).cast(pa.date32()),
+        pa.array(rng.integers(-10**6, 10**6, n), type=I64, mask=vmask),
+        pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(-10**9, 10**9, n)], type=pa.decimal128(15, 2), mask=vmask),
+        pa.array(rng.integers(-500, 500, n).astype(np.float64), type=pa.float64()),
+        pa.array(["k%07d" % x for x in k], type=pa.string())], schema=schema)
+    return schema, batch
+
+
+def _runs_aggs():
+    D = pa.decimal128(15, 2)
+    return [q.SumAggregateExpr(col("v", 2), I64), q.CountAggregateExpr(col("v", 2)), q.CountAggregateExpr(lit_i64(1)), q.MinAggregateExpr(col("v", 2), I64),
+            q.MaxAggregateExpr(col("p", 3), D), q.SumAggregateExpr(col("p", 3), D), q.AvgAggregateExpr(col("p", 3), D, pa.decimal128(19, 6)),
+            q.SumAggregateExpr(col("f", 4), pa.float64())]
+
+
+def test_sorted_run_aggregate(ctx, oracle, monkeypatch):
+    """Round 4 (qk_agg_runs): an input whose equal keys are adjacent is aggregated as RUNS — no table, no compaction; the kernel
+    checks the order itself. Forced here (QHIP_AGG_RUNS=2): runs of 1..7 rows over sizes around the thread / workgroup tiles, one-
+    and multi-column keys (Int64 + Date32, a string), every cell kind, NULL values, NULL keys as a run of their own, ragged batches;
+    then inputs that are NOT of that kind — unsorted keys, runs longer than the kernel folds — which must fall back to the hashed
+    kernel with the same result and be remembered; then the automatic choice on the second execution of a many-group plan."""
+    rng = np.random.default_rng(17)
+    monkeypatch.setenv("QHIP_AGG_RUNS", "2")
+    ctx.forget_plans()
+    for n in (1, 3, 4, 5, 1023, 1024, 1025, 4097, 50_000):
+        schema, batch = _runs_table(rng, n, 7)
+        scan = table_scan(schema, [batch.slice(0, n // 3), batch.slice(n // 3)])
+        for keys in ([col("k", 0)], [col("k", 0), col("d", 1)], [col("s", 5)]):
+            plan = q.HashAggregate(None, scan, keys, _runs_aggs())
+            _same(plan, oracle)
+            assert ctx.last_stats()["main_kernel_name"] == "qk_agg_runs", (n, len(keys))
+    # NULL keys: adjacent NULLs are one group (their key words are zero, the mask word tells them apart from a real zero)
+    schema, batch = _runs_table(rng, 20_000, 5)
+    kk = batch.column(0).to_numpy(zero_copy_only=False).astype(np.int64)
+    nullrun = (kk > kk[5000]) & (kk <= kk[5600])
+    nb = pa.RecordBatch.from_arrays([pa.array(kk, type=I64, mask=nullrun)] + batch.columns[1:], schema=schema)
+    plan = q.HashAggregate(None, table_scan(schema, [nb]), [col("k", 0)], _runs_aggs())
+    _same(plan, oracle)
+    assert ctx.last_stats()["main_kernel_name"] == "qk_agg_runs"
+    # runs longer than the kernel folds (QHIP_AGG_RUNS_MAX, default 256): flagged, hashed kernel, remembered
+    schema, batch = _runs_table(rng, 30_000, 900)
+    plan = q.HashAggregate(None, table_scan(schema, [batch]), [col("k", 0)], _runs_aggs()[:3])
+    for _ in range(2):
+        _same(plan, oracle)
+        assert ctx.last_stats()["main_kernel_name"] != "qk_agg_runs"
+    # unsorted keys
+    ctx.forget_plans()
+    schema, batch = _runs_table(rng, 30_000, 4)
+    perm = rng.permutation(batch.num_rows)
+    shuffled = batch.take(pa.array(perm))
+    plan = q.HashAggregate(None, table_scan(schema, [shuffled]), [col("k", 0)], _runs_aggs())
+    for _ in range(2):
+        _same(plan, oracle)
+        assert ctx.last_stats()["main_kernel_name"] != "qk_agg_runs"
+    # ... one swap of two neighbouring runs is enough
+    kk = batch.column(0).to_numpy(zero_copy_only=False).astype(np.int64).copy()
+    a, b = kk[100], kk[20_000]
+    kk[kk == a], kk[kk == b] = b, a
+    swapped = pa.RecordBatch.from_arrays([pa.array(kk, type=I64)] + batch.columns[1:], schema=schema)
+    ctx.forget_plans()
+    plan = q.HashAggregate(None, table_scan(schema, [swapped]), [col("k", 0)], _runs_aggs()[:3])
+    _same(plan, oracle)
+    assert ctx.last_stats()["main_kernel_name"] != "qk_agg_runs"
+    # the automatic choice: first execution through the table (nothing known), second as runs
+    monkeypatch.delenv("QHIP_AGG_RUNS")
+    ctx.forget_plans()
+    schema, batch = _runs_table(rng, 120_000, 5)
+    plan = q.HashAggregate(None, table_scan(schema, [batch]), [col("k", 0), col("d", 1)], _runs_aggs())
+    names = []
+    for _ in range(3):
+        _same(plan, oracle)
+        names.append(ctx.last_stats()["main_kernel_name"])
+    assert names[0] != "qk_agg_runs" and names[1] == names[2] == "qk_agg_runs", names
+    # a scan filter in the aggregate: no such entry point (a rejected row would split a run)
+    pred = q.BinaryExpr(col("v", 2), Operator.Gt, lit_i64(0))
+    monkeypatch.setenv("QHIP_AGG_RUNS", "2")
+    plan = q.HashAggregate(None, table_scan(schema, [batch], pred), [col("k", 0)], _runs_aggs()[:3])
+    _same(plan, oracle)
+    assert ctx.last_stats()["main_kernel_name"] != "qk_agg_runs"
+    ctx.forget_plans()
+
+
+def test_sorted_run_aggregate_over_a_join_output(ctx, oracle, monkeypatch):
+    """Q3's shape: the probe side is stored in key order, the join output keeps probe order, the aggregate above it groups by the
+    probe key and columns of the build side — its input is a join output of deferred size read through index vectors."""
+    rng = np.random.default_rng(23)
+    n_orders, n_items = 30_000, 100_000
+    os_ = pa.schema([pa.field("o_key", I64), pa.field("o_date", pa.date32()), pa.field("o_prio", pa.int32())])
+    ls_ = pa.schema([pa.field("l_key", I64), pa.field("l_price", pa.decimal128(15, 2)), pa.field("l_disc", pa.decimal128(15, 2))])
+    import decimal
+    ob = pa.RecordBatch.from_arrays([pa.array(np.arange(n_orders) * 4 + 1, type=I64),
+                                     pa.array(rng.integers(9000, 9400, n_orders).astype(np.int32), type=pa.int32()).cast(pa.date32()),
+                                     pa.array(rng.integers(0, 3, n_orders), type=pa.int32())], schema=os_)
+    lk = np.sort(rng.integers(0, n_orders, n_items)) * 4 + 1
+    lb = pa.RecordBatch.from_arrays([pa.array(lk, type=I64),
+                                     pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(100, 10**7, n_items)], type=pa.decimal128(15, 2)),
+                                     pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in rng.integers(0, 11, n_items)], type=pa.decimal128(15, 2))], schema=ls_)
+    opred = q.BinaryExpr(col("o_date", 1), Operator.Lt, q.CastExpr(q.Literal(q.ScalarValue.Int32(9200)), pa.date32()))
+    join = q.HashJoinExec.try_new(table_scan(os_, [ob], opred), table_scan(ls_, [lb.slice(0, 40_000), lb.slice(40_000)]), JoinType.Inner,
+                                  [(col("o_key", 0), col("l_key", 0))], None)
+    rev = q.BinaryExpr(col("l_price", 4), Operator.Mul, col("l_disc", 5))
+    plan = q.HashAggregate(None, join, [col("l_key", 3), col("o_date", 1), col("o_prio", 2)],
+                           [q.SumAggregateExpr(rev, pa.decimal128(31, 4)), q.CountAggregateExpr(lit_i64(1))])
+    names = []
+    for _ in range(4):
+        _same(plan, oracle)
+        names.append(ctx.last_stats()["main_kernel_name"])
+    assert names[-1] == "qk_agg_runs" and names[0] != "qk_agg_runs", names

@@ -2,7 +2,8 @@
 qh_join_probe_dense_body): for ONE integer key column whose build-side values span a small range the join table is an
 exact bitmap over the range plus row_of[key - min]. JoinHashMap's semantics (hash_join.rs:39-108, 177-216) must not change:
 every test compares with the CPU oracle, batch structure and row order included, with the layout chosen automatically,
-forced on (QHIP_JOIN_DENSE=2), staged in LDS (QHIP_JOIN_DENSE_LDS=1) and forced off (QHIP_JOIN_DENSE=0)."""
+forced on (QHIP_JOIN_DENSE=2), staged in LDS (QHIP_JOIN_DENSE_LDS=2), forced off (QHIP_JOIN_DENSE=0) and built from a byte map
+(QHIP_JOIN_DENSE_BYTEMAP=1)."""
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -26,10 +27,13 @@ def _layout_of(ctx):
     return ctx.last_stats()["main_kernel_name"]
 
 
-@pytest.fixture(params=["auto", "forced", "lds", "off"])
+@pytest.fixture(params=["auto", "forced", "lds", "off", "bytemap"])
 def dense(request, monkeypatch):
     if request.param == "forced":
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
+    elif request.param == "bytemap":   # (round 4: the bitmap packed from a byte map of plain stores; measured slower, off by default)
+        monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
+        monkeypatch.setenv("QHIP_JOIN_DENSE_BYTEMAP", "1")
     elif request.param == "lds":
         monkeypatch.setenv("QHIP_JOIN_DENSE", "2")
         monkeypatch.setenv("QHIP_JOIN_DENSE_LDS", "2")
@@ -85,7 +89,7 @@ def test_dense_layout_every_key_type_and_range(ctx, oracle, dense, key_type, lo,
     for jt in JoinType:
         plan = q.HashJoinExec.try_new(left, right, jt, on, None)
         _same(plan.execute(), oracle.execute(plan))
-        if dense in ("forced", "lds"):
+        if dense in ("forced", "lds", "bytemap"):
             assert _layout_of(ctx).startswith("qk_join_probe_dense"), (jt, _layout_of(ctx))
         elif dense == "off":
             assert _layout_of(ctx) in ("qk_join_probe", "qk_join_probe_onetable")
