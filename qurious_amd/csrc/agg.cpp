@@ -582,11 +582,16 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
       HRunsLaunch rl;
       rl.dense_out = dense_dev + 1; rl.counter = counter_dev; rl.status = status_dev; rl.flags = status_dev + 20;
       rl.cap = guess; rl.max_run = (uint32_t)std::max(16, env_int("QHIP_AGG_RUNS_MAX", 256));
+      // dynamic LDS: the evaluated rows of a workgroup's four wavefronts + their look-ahead (4 x 320 Row structs; a Row is at
+      // most 8 + 8 W + 24 bytes per argument — the kernel sizes the look-ahead from what it gets and gives up below 264 rows)
+      const size_t row_bound = 8 + 8 * (size_t)plan.W + 24 * plan.args.size();
+      const int lds_kb = env_int("QHIP_AGG_RUNS_LDS_KB", (int)std::min<size_t>(160, std::max<size_t>(32, (4 * 320 * row_bound + 16383) / 16384 * 16)));
+      rl.lds_bytes = (uint32_t)std::max(16, std::min(160, lds_kb)) * 1024u;
       void* rargs[] = {&ka, &rl};
       std::shared_ptr<Module> rmod = get_module(ctx, plan.source, "qk_agg_runs");
       const unsigned rgrid = (unsigned)((N + 1023) / 1024);
       time_mark(ctx, 0);
-      QHIP_HIP_CHECK(hipModuleLaunchKernel(rmod->fn, rgrid, 1, 1, 256, 1, 1, 0, ctx->stream, rargs, nullptr));
+      QHIP_HIP_CHECK(hipModuleLaunchKernel(rmod->fn, rgrid, 1, 1, 256, 1, 1, rl.lds_bytes, ctx->stream, rargs, nullptr));
       time_mark(ctx, 1);
       bool utf8_key = false;
       for (auto& kd : plan.keys) utf8_key = utf8_key || kd.type.id == QHIP_UTF8;
@@ -612,6 +617,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
         l_nslots = 0;
       } else {
         // not that kind of input (or a few long runs): remember, and aggregate it through the table
+        if (env_int("QHIP_AGG_RUNS_DEBUG", 0)) fprintf(stderr, "[qhip agg runs] rows %lld: flags %u (1 = order, 2 = run too long), runs counted %u\n", (long long)N, status_pinned[20], status_pinned[16]);
         plan.not_sorted = true;
         spec = DevFinal();
         spec_enqueued = false;

@@ -771,6 +771,19 @@ void plan_aggregate(const ExprSet& es, const std::vector<InputCol>& input, int p
     }
     if (ok && widest > 0) P.RC = std::max(1, std::min(8, env_int("QHIP_AGG_CONS_R", 4)));
   }
+  {
+    // how the sorted-run kernel orders two key words (any total order makes "non-decreasing" imply "equal keys adjacent"; these
+    // make the usual sort orders — signed integers, bytewise strings — pass): Utf8 words compare byte-swapped (the bytes are packed
+    // little-endian), signed integer words with the sign bit flipped
+    unsigned long long swap_mask = 0, sign_mask = 0;
+    for (auto& kd : P.keys) {
+      for (int w2 = 0; w2 < kd.words; ++w2) {
+        if (kd.type.id == QHIP_UTF8) swap_mask |= 1ull << (kd.word_off + w2);
+        else if (kd.words == 1 && kd.type.id != QHIP_UINT8) sign_mask |= 1ull << (kd.word_off + w2);
+      }
+    }
+    s << "  static constexpr unsigned long long KEY_SWAP_MASK = " << swap_mask << "ULL, KEY_SIGN_MASK = " << sign_mask << "ULL;\n";
+  }
   s << "  static constexpr int RC = " << std::max(1, P.RC) << ";\n";
   s << "  static constexpr int CSB = " << std::max(1, std::min(4, env_int("QHIP_AGG_CONS_SB", 4))) << ";\n";
   s << "  static constexpr int CPIPE = " << (env_int("QHIP_AGG_CONS_PIPE", 1) != 0 ? 1 : 0) << ";\n";

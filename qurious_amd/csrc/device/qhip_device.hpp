@@ -975,29 +975,48 @@ struct RunsLaunch {
   u64* dense_out;     // cap slots
   u32* counter;       // += runs written
   u32* status;        // QS_WORDS words
-  u32* flags;         // |= 1: keys not non-decreasing, |= 2: a run longer than max_run
+  u32* flags;         // |= 1: keys not non-decreasing, |= 2: a run longer than max_run, |= 4: a Row too big for the LDS given
   u32 cap, max_run;
+  u32 lds_bytes, pad_;   // dynamic LDS of the launch
 };
+// Every load of the kernel is issued in ONE batch: a wavefront's 256 rows (four per lane), the row in front of each lane's four,
+// and one LOOK-AHEAD row per lane (the rows behind the wavefront's 256). The evaluated rows go to LDS; the lane that owns a run's
+// start folds the run out of LDS — its own rows, the next lanes', the look-ahead rows — so that no load depends on a compare.
+// (The first version followed a run with a load per row: 54 us for Q3's 0.3 M rows, every step a chain of index load -> gather
+// over tables of GB — TLB misses in series.) Only a run that outlives the look-ahead is followed with loads.
 template <class P, bool DEVROWS = false>
 __device__ __forceinline__ void qh_agg_runs_body(const KArgs& a, const RunsLaunch& L) {
-  constexpr int W = P::W > 0 ? P::W : 1, R = 4;
+  constexpr int W = P::W > 0 ? P::W : 1, R = 4, WROWS = 64 * R;
+  typedef typename P::Row Row;
   const i64 nrows = DEVROWS ? qh_rows(a) : a.nrows;
   const i64 tb = (i64)blockIdx.x * (QH_BLOCK * R);
   if (tb >= nrows) return;                       // (workgroup-uniform)
   const int lane = qh_lane();
-  const u32 o0 = threadIdx.x * (u32)R;
+  const int wv = (int)(threadIdx.x >> 6);
+  // rows of a wavefront staged in LDS: its 256 + a look-ahead of up to 64, as many as the launch's LDS holds
+  const u32 per_wave = (L.lds_bytes / (QH_BLOCK / 64)) / (u32)sizeof(Row);
+  const u32 LA = per_wave >= (u32)WROWS + 64u ? 64u : per_wave > (u32)WROWS ? per_wave - (u32)WROWS : 0u;   // (uniform)
+  if (per_wave < (u32)WROWS + 8u) { if (threadIdx.x == 0) atomicOr(L.flags, 4u); return; }
+  Row* srow = (Row*)qh_dyn_lds + (size_t)wv * per_wave;
+  const i64 wb = tb + (i64)wv * WROWS;           // the wavefront's first row
+  const u32 o0 = (u32)wv * WROWS + (u32)lane * (u32)R;
   const i64 base = tb + (i64)o0;
   u32 err = 0, bad = 0;
-  typename P::Raw raw[R], rawp;
-  typename P::Row row[R], rowp;
+  typename P::Raw raw[R], rawp, rawx;
+  Row row[R], rowp, rowx;
   const bool have_prev = base > 0 && base < nrows;
+  const i64 xrow = wb + WROWS + lane;            // this lane's look-ahead row
+  const bool have_x = (u32)lane < LA && xrow < nrows;
   P::load(a, have_prev ? base - 1 : 0, 0u, rawp);
 #pragma unroll
   for (int r = 0; r < R; ++r) P::load(a, tb, base + r < nrows ? o0 + (u32)r : (u32)(nrows - 1 - tb), raw[r]);
+  P::load(a, tb, have_x ? (u32)(xrow - tb) : (u32)(nrows - 1 - tb), rawx);
   {
     u32 e = 0;
     P::eval(a, rawp, rowp, e);
     err |= have_prev ? e : 0u;
+    e = 0;
+    P::eval(a, rawx, rowx, e);     // (its errors are reported by the wavefront that owns the row)
   }
   bool start[R];
   u32 nstart = 0;
@@ -1014,12 +1033,20 @@ __device__ __forceinline__ void qh_agg_runs_body(const KArgs& a, const RunsLaunc
     for (int w = 0; w < W; ++w) {
       const u64 x = row[r].key[w], y = pk[w];
       same = same && x == y;
-      if (!decided && x != y) { less = x < y; decided = true; }
+      if (!decided && x != y) {
+        const bool sw = (P::KEY_SWAP_MASK >> w) & 1ULL, sg = (P::KEY_SIGN_MASK >> w) & 1ULL;   // (compile-time per word)
+        const u64 xo = sw ? __builtin_bswap64(x) : sg ? x ^ (1ULL << 63) : x, yo = sw ? __builtin_bswap64(y) : sg ? y ^ (1ULL << 63) : y;
+        less = xo < yo;
+        decided = true;
+      }
     }
     if (inb && has && less) bad |= 1u;
     start[r] = inb && !same;
     nstart += start[r] ? 1u : 0u;
+    srow[(u32)lane * R + r] = row[r];
   }
+  if ((u32)lane < LA) srow[WROWS + lane] = rowx;
+  __syncthreads();                               // (the wavefront's rows are in LDS; a workgroup barrier keeps the code simple)
   // one reservation per wavefront for the runs its lanes start
   const u32 incl = qh_wave_incl_scan_u32(nstart, lane);
   const u32 wave_total = qh_readlane32(incl, 63);
@@ -1057,21 +1084,35 @@ __device__ __forceinline__ void qh_agg_runs_body(const KArgs& a, const RunsLaunc
     }
   }
   if (open) {
-    // the run may go on in the rows of the threads behind this one
-    u32 steps = 0;
-    for (i64 x = base + R; x < nrows; ++x) {
-      typename P::Raw rx;
-      typename P::Row qx;
-      P::load(a, tb, (u32)(x - tb), rx);
-      u32 e = 0;
-      P::eval(a, rx, qx, e);
+    // the run may go on behind this lane's rows: the next lanes' rows and the look-ahead rows, out of LDS ...
+    u32 k = (u32)lane * R + R, steps = 0;
+    bool ended = false;
+    const u32 staged = (u32)WROWS + LA;
+    for (; k < staged && wb + (i64)k < nrows; ++k) {
+      const Row& qx = srow[k];
       bool same = true;
 #pragma unroll
       for (int w = 0; w < W; ++w) same = same && qx.key[w] == fk[w];
-      if (!same) break;
-      err |= e;
+      if (!same) { ended = true; break; }
       P::template part_add<true>(part, qx, true);
-      if (++steps > L.max_run) { bad |= 2u; break; }
+      ++steps;
+    }
+    // ... and with a load per row behind those (a run of more than the look-ahead)
+    if (!ended) {
+      for (i64 x = wb + (i64)k; x < nrows; ++x) {
+        typename P::Raw rx;
+        Row qx;
+        P::load(a, tb, (u32)(x - tb), rx);
+        u32 e = 0;
+        P::eval(a, rx, qx, e);
+        bool same = true;
+#pragma unroll
+        for (int w = 0; w < W; ++w) same = same && qx.key[w] == fk[w];
+        if (!same) break;
+        err |= e;
+        P::template part_add<true>(part, qx, true);
+        if (++steps > L.max_run) { bad |= 2u; break; }
+      }
     }
     flush();
   }

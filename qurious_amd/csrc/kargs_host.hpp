@@ -66,8 +66,9 @@ struct HRunsLaunch {
   uint32_t* status;
   uint32_t* flags;
   uint32_t cap, max_run;
+  uint32_t lds_bytes = 0, pad_ = 0;
 };
-static_assert(sizeof(HRunsLaunch) == 40, "RunsLaunch layout");
+static_assert(sizeof(HRunsLaunch) == 48, "RunsLaunch layout");
 
 struct HProjOut {
   void* v[kMaxCols];

@@ -490,12 +490,20 @@ def test_sorted_run_aggregate(ctx, oracle, monkeypatch):
             plan = q.HashAggregate(None, scan, keys, _runs_aggs())
             _same(plan, oracle)
             assert ctx.last_stats()["main_kernel_name"] == "qk_agg_runs", (n, len(keys))
-    # NULL keys: adjacent NULLs are one group (their key words are zero, the mask word tells them apart from a real zero)
+    # NULL keys: adjacent NULLs are one group (their key words are zero, the mask word tells them apart from a real zero). Sorted
+    # NULLS LAST is "non-decreasing" for the kernel (the mask word leads the key); a NULL run in the MIDDLE is not — it falls back
     schema, batch = _runs_table(rng, 20_000, 5)
     kk = batch.column(0).to_numpy(zero_copy_only=False).astype(np.int64)
-    nullrun = (kk > kk[5000]) & (kk <= kk[5600])
-    nb = pa.RecordBatch.from_arrays([pa.array(kk, type=I64, mask=nullrun)] + batch.columns[1:], schema=schema)
-    plan = q.HashAggregate(None, table_scan(schema, [nb]), [col("k", 0)], _runs_aggs())
+    for nullrun, runs in ((kk > kk[19_990], True), ((kk > kk[5000]) & (kk <= kk[5010]), False)):
+        nb = pa.RecordBatch.from_arrays([pa.array(kk, type=I64, mask=nullrun)] + batch.columns[1:], schema=schema)
+        ctx.forget_plans()
+        plan = q.HashAggregate(None, table_scan(schema, [nb]), [col("k", 0)], _runs_aggs())
+        _same(plan, oracle)
+        assert (ctx.last_stats()["main_kernel_name"] == "qk_agg_runs") == runs
+    # negative and positive keys in signed order, strings in bytewise order
+    neg = pa.RecordBatch.from_arrays([pa.array(kk - kk[10_000], type=I64)] + batch.columns[1:], schema=schema)
+    ctx.forget_plans()
+    plan = q.HashAggregate(None, table_scan(schema, [neg]), [col("k", 0)], _runs_aggs()[:3])
     _same(plan, oracle)
     assert ctx.last_stats()["main_kernel_name"] == "qk_agg_runs"
     # runs longer than the kernel folds (QHIP_AGG_RUNS_MAX, default 256): flagged, hashed kernel, remembered
