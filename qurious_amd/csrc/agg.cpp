@@ -121,6 +121,14 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
       if (!indirect_eligible(c0)) fail(QHIP_HIP_ERROR, "a column planned as an indirect read has been gathered meanwhile (internal error)");
       a.c[s].v = c0.deferred->src.values->ptr;
       a.c[s].d = (const uint8_t*)c0.deferred->idx->ptr;
+      if (s < b.narrow.size() && b.narrow[s]) {   // ... from the source's narrow copy (the object every copy of the column shares)
+        const DevColumn& src = c0.deferred->src;
+        const ColRange& sh = *src.range;
+        if (sh.narrow_buf && sh.narrow_bytes == (int)b.narrow[s] && sh.narrow_src == src.values->ptr && sh.narrow_rows == src.length) a.c[s].v = sh.narrow_buf->ptr;
+        else if (src.narrow && src.narrow->buf && src.narrow->bytes == (int)b.narrow[s] && src.narrow->src == src.values->ptr && src.narrow->rows == src.length)
+          a.c[s].v = src.narrow->buf->ptr;
+        else fail(QHIP_HIP_ERROR, "an indirect column planned with a narrow copy has none of that width (internal error)");
+      }
       continue;
     }
     const DevColumn& c = resolved(ctx, c0);
@@ -351,7 +359,7 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   for (int c : plan.bind.cols) {
     const DevColumn& dc = in->cols[(size_t)c];
     const int w = dtype_width(dc.type);
-    if (w > 0) bytes_per_row += icols[(size_t)c].narrow_bytes && !icols[(size_t)c].indirect ? icols[(size_t)c].narrow_bytes : w;
+    if (w > 0) bytes_per_row += icols[(size_t)c].narrow_bytes ? icols[(size_t)c].narrow_bytes : w;
     else if (dc.type.id == QHIP_BOOL) bytes_per_row += 0.125;
     else if (dc.type.id == QHIP_UTF8) bytes_per_row += icols[(size_t)c].utf8_fixed1 ? 1.0 : 4.0 + (N > 0 ? (double)dc.data_bytes / (double)N : 0.0);
     if (dc.null_count > 0) bytes_per_row += 0.125;

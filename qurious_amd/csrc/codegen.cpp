@@ -107,7 +107,7 @@ int ExprGen::col_slot(int table_col) {
   if (bind.cols.size() >= 24) fail(QHIP_UNSUPPORTED, "expression references more than 24 distinct columns");
   bind.cols.push_back(table_col);
   bind.indirect.push_back(table_col >= 0 && table_col < (int)in_.size() && in_[(size_t)table_col].indirect ? 1 : 0);
-  bind.narrow.push_back(table_col >= 0 && table_col < (int)in_.size() && !in_[(size_t)table_col].indirect ? (char)in_[(size_t)table_col].narrow_bytes : (char)0);
+  bind.narrow.push_back(table_col >= 0 && table_col < (int)in_.size() ? (char)in_[(size_t)table_col].narrow_bytes : (char)0);
   return (int)bind.cols.size() - 1;
 }
 
@@ -191,7 +191,8 @@ void ExprGen::emit(int k, std::string& out) {
         o << "    const int " << v << " = 0;\n";
       } else {
         // a Decimal128 column with a narrow copy (InputCol::narrow_bytes): the kernel loads 4 / 8 bytes per value and widens
-        const int nb = (n.type.id == QHIP_DECIMAL128 || (n.type.id == QHIP_INT64 && in_[(size_t)n.column].narrow_bytes == 4)) && !in_[(size_t)n.column].indirect
+        // (an indirect column — read through an index vector — gathers from its SOURCE's narrow copy: ColRange::narrow_buf)
+        const int nb = (n.type.id == QHIP_DECIMAL128 || (n.type.id == QHIP_INT64 && in_[(size_t)n.column].narrow_bytes == 4))
                            ? in_[(size_t)n.column].narrow_bytes : 0;
         const std::string LT = nb == 4 ? "int" : nb == 8 ? "i64" : ctype(n.type);   // the type in memory
         field(LT, v);

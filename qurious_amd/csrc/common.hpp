@@ -96,7 +96,16 @@ inline void copy_sync(hipStream_t s, void* dst, const void* src, size_t n, hipMe
   QHIP_HIP_CHECK(sync_stream(s));
 }
 
-struct ColRange { bool known = false; int64_t min = 0, max = 0; };
+struct ColRange {
+  bool known = false; int64_t min = 0, max = 0;
+  // (round 4) ... and, for readers that reach the column through a deferred gather's COPY of it (DeferredGather::src — an
+  // aggregate over a join output reads lineitem's prices through the join's index vector and never sees the table's own column
+  // object): the magnitude bound and the 4- / 8-byte narrow copy of a Decimal128 column, made at the second such read, valid for
+  // exactly the buffer and length they were made from. Same meaning as DevColumn::value_maxabs / ::narrow.
+  uint64_t maxabs = 0;
+  int reads = 0;
+  std::shared_ptr<DevBuf> narrow_buf; int narrow_bytes = 0; const void* narrow_src = nullptr; int64_t narrow_rows = 0;
+};
 // One column of a device table, concatenated over all batches, Arrow layout.
 struct DevColumn {
   DType type;

@@ -401,6 +401,14 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   std::string probe_name = dense ? "qk_join_probe_dense" : "qk_join_probe";   // (the entry point launched, for the statistics)
   uint64_t M = 0;
   const uint32_t* deferred_slot = nullptr;
+  // The join key of every output row, written by pass 2 for nothing (dense layout: a matching entry holds key - min): an Inner
+  // join on ONE Int64 column with unique build keys hands its key columns on as PLAIN columns instead of deferred gathers, so
+  // that a GROUP BY over them (Q3 groups by l_orderkey) streams 8 bytes per row instead of gathering through the index vector —
+  // one of the aggregate's five random reads per row gone (QHIP_JOIN_KEY_MATERIALIZE=0: gathers like every other column)
+  const bool mat_key = dense && unique_keys && join_type == QHIP_JOIN_INNER && froot < 0 && n_on == 1 && rex[on_r[0]].kind == QHIP_EXPR_COLUMN &&
+                       rex[on_r[0]].column >= 0 && rex[on_r[0]].column < (int)R->cols.size() && R->cols[(size_t)rex[on_r[0]].column].type.id == QHIP_INT64 &&
+                       env_int("QHIP_JOIN_KEY_MATERIALIZE", 1) != 0;
+  std::shared_ptr<DevBuf> key_vals;
   std::shared_ptr<DevBuf> rows_blk;
   std::shared_ptr<uint64_t> rows_final;
   bool probe_timed = false;
@@ -500,9 +508,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
       b_idx.alloc((M + 1) * 4);
       p_idx.alloc((M + 1) * 4);
       rows_blk = std::make_shared<DevBuf>(64);   // the output table's device-side row count
+      if (mat_key) key_vals = std::make_shared<DevBuf>((M + 1) * 8);
       // pass 2 also pads the index vectors up to the capacity, publishes the status block to `slot` and the total to rows_blk
       launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, dense ? (const uint32_t*)table : nullptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
-                       nullptr, nullptr, nullptr, (uint32_t)M, dstat, slot, rows_blk->as<uint32_t>(), s);
+                       nullptr, nullptr, nullptr, (uint32_t)M, dstat, slot, rows_blk->as<uint32_t>(), s, key_vals ? key_vals->as<int64_t>() : nullptr, (uint64_t)kmin);
       deferred_slot = slot;
     } else {
     // ONE read-back: build status (needed only now under speculation), probe status and the pair total
@@ -531,9 +540,10 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
         pair_off.alloc((P + 1) * 4);
         QHIP_HIP_CHECK(hipMemsetAsync(cnt.ptr, 0, cnt.bytes, s));   // pass 2 only visits matching probe rows
       }
+      if (mat_key) key_vals = std::make_shared<DevBuf>((M + 1) * 8);
       launch_join_emit(ent_slot.as<uint32_t>(), ent_row.as<uint32_t>(), tile_nent.as<uint32_t>(), tile_tot.as<uint32_t>(), count, start_ptr, rows_ptr, dense ? (const uint32_t*)table : nullptr, nchunks, tiles_per_wave * kProbeTileRows, b_idx.as<uint32_t>(), p_idx.as<uint32_t>(),
                        pad_right ? pair_off.as<uint32_t>() : nullptr, pad_right ? cnt.as<uint32_t>() : nullptr,
-                       mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, nullptr, nullptr, nullptr, s);
+                       mark_in_probe ? visited.as<uint32_t>() : nullptr, 0xFFFFFFFFu, nullptr, nullptr, nullptr, s, key_vals ? key_vals->as<int64_t>() : nullptr, (uint64_t)kmin);
     }
     }
     visited_done = mark_in_probe;
@@ -654,6 +664,24 @@ qhip_table* hash_join(Ctx* ctx, const qhip_table* L, const qhip_table* R, int jo
   };
   add_side(L, b_all, left_nullable);
   if (!semi_anti) add_side(R, p_all, right_nullable);
+  if (key_vals) {
+    auto plain = [&](const DevColumn& src) {
+      DevColumn c;
+      c.type = src.type;
+      c.length = (int64_t)total_rows;
+      c.values = key_vals;
+      c.value_maxabs = src.value_maxabs;
+      c.range = src.range;             // (a subset of the source's values: its bounds hold)
+      c.range_inherited = true;
+      return c;
+    };
+    const size_t rc = (size_t)rex[on_r[0]].column;
+    out->cols[L->cols.size() + rc] = plain(R->cols[rc]);
+    // ... and the build side's key column holds the same values row for row
+    if (lex[on_l[0]].kind == QHIP_EXPR_COLUMN && lex[on_l[0]].column >= 0 && lex[on_l[0]].column < (int)L->cols.size() &&
+        L->cols[(size_t)lex[on_l[0]].column].type.id == QHIP_INT64)
+      out->cols[(size_t)lex[on_l[0]].column] = plain(L->cols[(size_t)lex[on_l[0]].column]);
+  }
   out->num_rows = (int64_t)total_rows;
   if (deferred_slot) {   // total_rows is the capacity; the count is what pass 2 left in rows_blk
     out->rows_blk = rows_blk;

@@ -72,7 +72,7 @@ void launch_bytes_to_bits(const uint8_t* bytes, uint32_t gen, uint32_t* bits, ui
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
                       const uint32_t* start, const uint32_t* rows, const uint32_t* row_of, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
                       uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish,
-                      uint32_t* rows_out, hipStream_t s);
+                      uint32_t* rows_out, hipStream_t s, int64_t* key_out = nullptr, uint64_t key_min = 0);
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s);
 void launch_join_out_counts(const uint32_t* cnt, uint64_t np, uint32_t* out_cnt, hipStream_t s);
 void launch_join_adjust_right(const uint32_t* b_in, const uint32_t* cnt, const uint32_t* in_off, const uint32_t* out_off, uint64_t np,

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(QH_BLOCK) void k_bytes_to_bits(const u8* bytes, u32
 __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, const u32* ent_row, const u32* chunk_nent, const u32* chunk_off,
                                                        const u32* count, const u32* start, const u32* rows, const u32* row_of, u64 nchunks, u64 chunk_rows, u32* b_idx,
                                                        u32* p_idx, u32* pair_off, u32* cnt_out, u32* visited, u32 cap, const u32* stat_block,
-                                                       u32* publish, u32* rows_out) {
+                                                       u32* publish, u32* rows_out, i64* key_out, u64 key_min) {
   // a join of deferred size (cap = the room its output has; stat_block = [build status | probe status | pair total]): rows
   // [total, cap) of the index vectors repeat row 0 of both sides (valid to gather, never counted), the total goes to the
   // output table's device-side row count and the status block to page-locked host memory, where the consumer's
@@ -654,6 +654,15 @@ __global__ __launch_bounds__(QH_BLOCK) void k_join_emit(const u32* ent_slot, con
           live[u] = j < n;
           sid[u] = live[u] ? ent_slot[e0 + j] : 0u;
           p[u] = live[u] ? ent_row[e0 + j] : 0u;
+        }
+        // (dense layout, Int64 key: the entry IS key - min — the join key of every output row is written here for nothing, so that
+        // an aggregate grouping by it streams a plain column instead of gathering lineitem.l_orderkey through p_idx)
+        if (key_out) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const u32 o = base + j0 + (u32)u * 64u + (u32)lane;
+            if (live[u] && o < cap) key_out[o] = (i64)(key_min + (u64)sid[u]);
+          }
         }
         if (row_of) {
 #pragma unroll
@@ -1303,12 +1312,12 @@ void launch_bytes_to_bits(const uint8_t* bytes, uint32_t gen, uint32_t* bits, ui
 void launch_join_emit(const uint32_t* ent_slot, const uint32_t* ent_row, const uint32_t* chunk_nent, const uint32_t* chunk_off, const uint32_t* count,
                       const uint32_t* start, const uint32_t* rows, const uint32_t* row_of, uint64_t nchunks, uint64_t chunk_rows, uint32_t* b_idx, uint32_t* p_idx,
                       uint32_t* pair_off, uint32_t* cnt_out, uint32_t* visited, uint32_t cap, const uint32_t* stat_block, uint32_t* publish,
-                      uint32_t* rows_out, hipStream_t s) {
+                      uint32_t* rows_out, hipStream_t s, int64_t* key_out, uint64_t key_min) {
   if (!nchunks) return;
   hipLaunchKernelGGL(k_join_emit, dim3(grid_for(nchunks * 64, QH_BLOCK)), dim3(QH_BLOCK), 0, s, (const u32*)ent_slot, (const u32*)ent_row,
                      (const u32*)chunk_nent, (const u32*)chunk_off, (const u32*)count, (const u32*)start, (const u32*)rows, (const u32*)row_of, (u64)nchunks,
                      (u64)chunk_rows, (u32*)b_idx, (u32*)p_idx, (u32*)pair_off, (u32*)cnt_out, (u32*)visited, (u32)cap, (const u32*)stat_block,
-                     (u32*)publish, (u32*)rows_out);
+                     (u32*)publish, (u32*)rows_out, (i64*)key_out, (u64)key_min);
 }
 void launch_join_mark(const uint32_t* b_idx, const uint32_t* p_idx, uint64_t m, uint32_t* visited_bits, uint32_t* cnt_per_probe, hipStream_t s) {
   if (!m) return;

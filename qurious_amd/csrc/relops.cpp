@@ -134,23 +134,34 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   // column), and — Decimal128 columns — the 4-byte narrow copy written speculatively by the same pass (round 3: a second pass
   // over the column at its second big read). Adopted below when the maximum fits 31 bits, dropped otherwise.
   {
-    struct Pending { const DevColumn* col; std::shared_ptr<DevBuf> spec; size_t at; };
+    struct Pending { const DevColumn* col; std::shared_ptr<DevBuf> spec; size_t at; bool shared; };
     std::vector<Pending> pend;
     std::vector<char> seen0(t->cols.size(), 0);
+    const bool narrow_indirect = narrow_ok && env_int("QHIP_NARROW_INDIRECT", 1) != 0;
     for (int k = 0; k < n_exprs; ++k) {
       const qhip_expr& e = exprs[k];
       if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size() || seen0[(size_t)e.column]) continue;
       if (t->cols[(size_t)e.column].type.id != QHIP_DECIMAL128 && t->cols[(size_t)e.column].type.id != QHIP_INT64) continue;
       seen0[(size_t)e.column] = 1;
-      const DevColumn& col = icols[(size_t)e.column].indirect ? t->cols[(size_t)e.column] : resolved(ctx, t->cols[(size_t)e.column]);
-      if (col.value_maxabs == 0 && col.length >= min_rows && col.values) pend.push_back(Pending{&col, nullptr, pend.size() * 2});
+      if (icols[(size_t)e.column].indirect) {
+        // read through an index vector: the statistics and the narrow copy belong to the SOURCE column and live in the object
+        // all its copies share (ColRange); made at the second read of a big Decimal128 source
+        const DevColumn& src = t->cols[(size_t)e.column].deferred->src;
+        ColRange& sh = *src.range;
+        if (narrow_indirect && src.type.id == QHIP_DECIMAL128 && src.values && src.length >= min_rows && !src.range_inherited &&
+            (sh.maxabs == 0 || (sh.narrow_src != src.values->ptr && sh.maxabs != ~0ULL && sh.maxabs < (1ULL << 31))) && ++sh.reads >= 2)
+          pend.push_back(Pending{&src, nullptr, pend.size() * 2, true});
+        continue;
+      }
+      const DevColumn& col = resolved(ctx, t->cols[(size_t)e.column]);
+      if (col.value_maxabs == 0 && col.length >= min_rows && col.values) pend.push_back(Pending{&col, nullptr, pend.size() * 2, false});
     }
     if (!pend.empty()) {
       DevBuf out(pend.size() * 16);
       QHIP_HIP_CHECK(hipMemsetAsync(out.ptr, 0, out.bytes, ctx->stream));
       for (Pending& p : pend) {
         const DevColumn& col = *p.col;
-        const bool spec = narrow_ok && col.type.id == QHIP_DECIMAL128 && !col.deferred && env_int("QHIP_NARROW_SPECULATIVE", 1) != 0;
+        const bool spec = narrow_ok && col.type.id == QHIP_DECIMAL128 && !col.deferred && (p.shared || env_int("QHIP_NARROW_SPECULATIVE", 1) != 0);
         if (spec) p.spec = std::make_shared<DevBuf>((size_t)col.length * 4);
         launch_value_maxabs(col.values->ptr, (uint64_t)col.length, col.type.id == QHIP_DECIMAL128 ? 2 : 1, out.as<uint64_t>() + p.at, ctx->stream,
                             spec ? p.spec->as<uint32_t>() : nullptr);
@@ -159,6 +170,12 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
       copy_sync(ctx->stream, h.data(), out.ptr, h.size() * 8, hipMemcpyDeviceToHost);
       for (Pending& p : pend) {
         const DevColumn& col = *p.col;
+        if (p.shared) {
+          ColRange& sh = *col.range;
+          sh.maxabs = h[p.at + 1] ? ~0ULL : std::max<uint64_t>(h[p.at], 1);
+          if (p.spec && sh.maxabs < (1ULL << 31)) { sh.narrow_buf = p.spec; sh.narrow_bytes = 4; sh.narrow_src = col.values->ptr; sh.narrow_rows = col.length; }
+          continue;
+        }
         col.value_maxabs = h[p.at + 1] ? ~0ULL : std::max<uint64_t>(h[p.at], 1);
         if (p.spec && col.value_maxabs < (1ULL << 31)) {
           auto nc = std::make_shared<DevColumn::NarrowCopy>();
@@ -179,6 +196,17 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
     // the bound enters lowered-plan cache keys: rounded up to a whole number of bits so that plans are shared by data
     // of the same magnitude
     uint64_t m = col.value_maxabs;
+    if (icols[(size_t)e.column].indirect) {
+      const DevColumn& src = col.deferred->src;
+      const ColRange& sh = *src.range;
+      if (m == 0 && sh.maxabs != 0 && !src.range_inherited) m = sh.maxabs;
+      // ... and its source's narrow copy: the gathers then touch a quarter of the address range
+      if (narrow_ok && m != 0 && m != ~0ULL && src.type.id == QHIP_DECIMAL128 && src.values && env_int("QHIP_NARROW_INDIRECT", 1) != 0) {
+        if (sh.narrow_buf && sh.narrow_src == src.values->ptr && sh.narrow_rows == src.length) icols[(size_t)e.column].narrow_bytes = sh.narrow_bytes;
+        // (... or the copy the table's own column had when the gather was deferred: made by a direct reader)
+        else if (src.narrow && src.narrow->buf && src.narrow->src == src.values->ptr && src.narrow->rows == src.length) icols[(size_t)e.column].narrow_bytes = src.narrow->bytes;
+      }
+    }
     if (m != 0 && m != ~0ULL) { int bits = 1; while (bits < 63 && (m >> bits)) ++bits; m = (1ULL << bits) - 1; }
     icols[(size_t)e.column].value_maxabs = m;
     // every value fits 32 / 64 bits: the kernel reads the column's narrow copy (DevColumn::narrow), made here once per column

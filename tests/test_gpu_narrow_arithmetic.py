@@ -14,7 +14,7 @@ import qurious_amd as q
 from qurious_amd import JoinType, Operator
 from qurious_amd import ScalarValue as S
 
-from .helpers import col, table_scan
+from .helpers import col, rows_of, table_scan
 
 pytestmark = pytest.mark.gpu
 N = (1 << 22) + 4321          # >= 2^22 rows: the value statistics engage (agg.cpp: ensure_value_bounds min_rows)
@@ -293,3 +293,33 @@ def test_narrow_copies_of_decimal_columns(ctx, monkeypatch, extreme, width):
     keep = q.Filter(scan, q.BinaryExpr(col("a", 1), Operator.Gt, q.CastExpr(q.Literal(S.Int64(60000)), a.type)))
     kept = [v for b in keep.execute() for v in _i128_of(b.column(1))]
     assert sorted(kept) == sorted(v for r, v in ext.items() if v > 60000)
+
+
+def test_narrow_copy_for_columns_only_ever_read_through_an_index_vector(ctx, oracle, monkeypatch):
+    """Round 4: Q3's aggregate reads lineitem's prices and discounts only through the join's index vector — the table's own
+    column objects are never streamed, so they never got statistics or narrow copies. Those now live in the object all copies of
+    a column share (ColRange) and are made at the second such read: the third execution gathers 4-byte values (and multiplies in
+    64 bits) instead of 16-byte ones. Results must not change; columns whose values do not fit 31 bits keep their 16 bytes."""
+    import decimal
+    monkeypatch.setenv("QHIP_STATS_MIN_ROWS", "1")
+    rng = np.random.default_rng(11)
+    nb, npr = 3000, 200_000
+    D = pa.decimal128(15, 2)
+    ls = pa.schema([pa.field("bk", I64, False), pa.field("bg", pa.int32(), False)])
+    lb = pa.RecordBatch.from_arrays([pa.array(np.arange(nb) * 2, I64), pa.array(rng.integers(0, 40, nb), pa.int32())], schema=ls)
+    dec = lambda v: pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in v], type=D)   # noqa: E731
+    big = rng.integers(-10**6, 10**6, npr).astype(object)
+    big[7] = 1 << 40                                                                     # does not fit 31 bits
+    rs = pa.schema([pa.field("pk", I64, False), pa.field("price", D, False), pa.field("disc", D, False), pa.field("wide", D, False)])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 2 * nb, npr), I64), dec(rng.integers(100, 10**7, npr)), dec(rng.integers(0, 11, npr)), dec(big)], schema=rs)
+    join = q.HashJoinExec.try_new(table_scan(ls, [lb]), table_scan(rs, [rb.slice(0, 70_000), rb.slice(70_000)]), JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
+    one = q.CastExpr(q.Literal(S.Int64(1)), pa.decimal128(20, 0))                        # what the reference's planner makes of `1 - l_discount`
+    rev = q.BinaryExpr(col("price", 3), Operator.Mul, q.BinaryExpr(one, Operator.Sub, col("disc", 4)))   # Decimal128(38, 4)
+    plan = q.HashAggregate(None, join, [col("bg", 1)], [q.SumAggregateExpr(rev, pa.decimal128(38, 4)),
+                                                        q.SumAggregateExpr(col("wide", 5), D), q.MinAggregateExpr(col("price", 3), D)])
+    want = sorted(map(repr, rows_of(oracle.execute(plan))))
+    read = []
+    for _ in range(4):
+        assert sorted(map(repr, rows_of(plan.execute()))) == want
+        read.append(ctx.last_stats()["bytes_per_row_read"])
+    assert read[-1] < read[0] - 20, read          # price and disc: 16 -> 4 bytes each; wide stays 16
