@@ -45,7 +45,7 @@ def main():
         wanted = []   # (kernel name, rows, bytes per row, operator)
         if tag == "q3":
             for k in line["records"]["q3"]["kernels"]:
-                if k["kernel"].startswith("qk_join_probe") or k["kernel"] in ("qk_filter_agg", "qk_filter_agg_cons"):
+                if k["kernel"].startswith("qk_join_probe") or k["kernel"] in ("qk_filter_agg", "qk_filter_agg_cons", "qk_agg_runs"):
                     wanted.append((k["kernel"], k["rows_per_launch"], k.get("kernel_bytes_per_row"), k.get("operator")))
         elif tag == "partition":
             # both cases (the whole SF10 table and a 1/8 slice) run in one process: same kernels, two grid sizes
