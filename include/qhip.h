@@ -335,6 +335,20 @@ int qhip_partition_filtered(qhip_ctx* ctx, const qhip_table* input,
                             const int32_t* key_roots, int32_t n_keys,
                             int32_t predicate_root, const int32_t* keep_columns,
                             int32_t n_parts, qhip_table** out_parts /* n_parts entries */);
+/* ... with the part of a row chosen by KEY RANGE instead of by hash (round 4; DESIGN.md §7 "routing by key range"): ONE
+ * integer-like key; upper_bounds = n_parts - 1 ascending values, part p takes the keys in (upper_bounds[p - 1], upper_bounds[p]],
+ * the last part everything above (a NULL key goes where 0 goes). Both sides of a join and every rank must use the SAME bounds —
+ * then the join is correct whatever they are; bounds taken from the ranks' own key ranges (qhip_table_column_range) keep the
+ * rows of tables sliced in key order where they are. upper_bounds == NULL: by hash, i.e. qhip_partition_filtered. */
+int qhip_partition_filtered_by_range(qhip_ctx* ctx, const qhip_table* input,
+                                     const qhip_expr* exprs, int32_t n_exprs,
+                                     const int32_t* key_roots, int32_t n_keys,
+                                     int32_t predicate_root, const int32_t* keep_columns,
+                                     const int64_t* upper_bounds /* n_parts - 1, or NULL */,
+                                     int32_t n_parts, qhip_table** out_parts /* n_parts entries */);
+/* [min, max] of an integer-like column's values (NULL slots included as stored), computed once per base column and cached; a
+ * column that is a deferred gather answers with its SOURCE's range (a superset). QHIP_UNSUPPORTED for other column types. */
+int qhip_table_column_range(qhip_ctx* ctx, const qhip_table* t, int64_t col, int64_t* out_min, int64_t* out_max);
 /* Concatenate tables with identical schemas (batches appended in order). */
 int qhip_table_concat(qhip_ctx* ctx, const qhip_table* const* tables, int32_t n, qhip_table** out);
 
@@ -436,6 +450,9 @@ typedef struct qhip_shuffle_input {
                                                   * column travels with it (found once per base column: one reduction + wait) so
                                                   * that the join can address its table by the key without reducing what it received */
   const int32_t* keep_columns;                   /* per input column, NULL = all */
+  const int64_t* range_bounds;                   /* NULL: rows go to rank hash(key) % world; else world - 1 ascending upper bounds of
+                                                  * ONE integer-like key, identical on every rank and for both sides of the join
+                                                  * (qhip_partition_filtered_by_range) */
 } qhip_shuffle_input;
 int qhip_shuffle_tables(qhip_ctx* ctx, qhip_comm* comm, const qhip_shuffle_input* inputs, int32_t n_inputs, qhip_table** outs);
 

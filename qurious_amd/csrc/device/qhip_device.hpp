@@ -1224,7 +1224,20 @@ struct PartIdsLaunch {
   u32 rows_per_unit;  // a multiple of 4 tiles (a tile = 64 * PART_R rows)
   u32 wg_units;       // 0: a unit is a WAVEFRONT (pass 2's wavefront form needs every wavefront's runs); 1: a unit is a WORKGROUP
   u32 pad_;           //    whose four wavefronts take a quarter of its rows each (big inputs: a quarter of the counters to scan)
+  // Partition by KEY RANGE instead of by hash (round 4, §7 "routing by key range"): NP - 1 ascending upper bounds of ONE integer
+  // key — part p takes the keys in (bounds[p - 1], bounds[p]], the last part everything above. Both sides of a join and every rank
+  // use the same bounds, so whatever they are the join stays correct; bounds taken from the ranks' own key ranges make the rows of
+  // tables sliced in key order (TPC-H's orders and lineitem) stay where they are. nullptr: by hash.
+  const i64* bounds;
 };
+template <int NP_>
+__device__ __forceinline__ u32 qh_part_range(u64 key_word, bool valid, const i64* bounds) {
+  const i64 k = valid ? (i64)key_word : (i64)0;     // (integer key words are sign-extended; a NULL key goes where 0 goes: it matches nothing)
+  u32 p = 0;
+#pragma unroll 1
+  for (int b = 0; b < NP_ - 1; ++b) p += k > bounds[b] ? 1u : 0u;   // (wave-uniform loads)
+  return p;
+}
 template <class P>
 struct QhPartTile {
   typename P::Raw raw[P::PART_R];
@@ -1307,7 +1320,7 @@ __device__ __forceinline__ void qh_part_ids_body(const KArgs& a, const PartIdsLa
         u32 e = 0;                                                                     \
         const u32 code = P::keys(a, X.raw[r], k, e);                                   \
         err |= inb ? e : 0u;                                                           \
-        const u32 id = (inb && (code & 2u)) ? qh_part_of<P>(k, (code & 1u) != 0) : 0xFFu;   \
+        const u32 id = (inb && (code & 2u)) ? (L.bounds ? qh_part_range<NP>(k[0], (code & 1u) != 0, L.bounds) : qh_part_of<P>(k, (code & 1u) != 0)) : 0xFFu;   \
         idr[r] = id;                                                                   \
         if (!WIDE && inb) L.ids[row] = (u8)id;                                         \
         if (SMALL) {                                                                   \

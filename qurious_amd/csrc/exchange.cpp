@@ -109,7 +109,7 @@ bool scatter_wg_form(int64_t rows) {
 
 
 void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
-                     int n_parts, PartitionWork& w) {
+                     int n_parts, PartitionWork& w, const int64_t* range_bounds) {
   hipStream_t s = ctx->stream;
   const uint64_t N = (uint64_t)in->num_rows;
   resolve_referenced(ctx, in, exprs, n_exprs, true);
@@ -183,7 +183,19 @@ void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int
   w.dstat = zeroed_block(ctx);
   HKArgs ka;
   fill_kargs(ctx, in, pp->kp.bind, ka, pp->strlit);
-  HPartIdsLaunch pl = {w.ids.as<uint8_t>(), hist.as<uint32_t>(), w.dstat, w.n_units, w.rows_per_unit, w.wg_units ? 1u : 0u, 0u};
+  HPartIdsLaunch pl = {w.ids.as<uint8_t>(), hist.as<uint32_t>(), w.dstat, w.n_units, w.rows_per_unit, w.wg_units ? 1u : 0u, 0u, nullptr};
+  if (range_bounds && n_parts > 1) {
+    // by key range: ONE integer-like key (its word is the sign-extended value)
+    if (n_keys != 1) fail(QHIP_INVALID_ARGUMENT, "partitioning by key range takes exactly one key");
+    const KeyDesc& kd = pp->kp.keys.at(0);
+    if (kd.words != 1 || kd.type.id == QHIP_UTF8 || kd.type.id == QHIP_DECIMAL128) fail(QHIP_UNSUPPORTED, "partitioning by key range needs an integer-like key, not " + dtype_name(kd.type));
+    for (int b = 1; b < n_parts - 1; ++b)
+      if (range_bounds[b] < range_bounds[b - 1]) fail(QHIP_INVALID_ARGUMENT, "partitioning by key range: the bounds must be ascending");
+    w.bounds_host.assign(range_bounds, range_bounds + (n_parts - 1));
+    w.bounds_dev.alloc((size_t)(n_parts - 1) * 8);
+    QHIP_HIP_CHECK(hipMemcpyAsync(w.bounds_dev.ptr, w.bounds_host.data(), (size_t)(n_parts - 1) * 8, hipMemcpyHostToDevice, s));
+    pl.bounds = w.bounds_dev.as<int64_t>();
+  }
   void* args[] = {&ka, &pl};
   time_mark(ctx, 0);
   // (the wide form needs whole tiles to shift a partial last tile back over: an exact row count of at least one tile)
@@ -337,7 +349,7 @@ void partition_pass2(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_
 }
 
 void partition_filtered(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
-                        const int32_t* keep, int n_parts, qhip_table** out_parts) {
+                        const int32_t* keep, int n_parts, qhip_table** out_parts, const int64_t* range_bounds = nullptr) {
   QHIP_HIP_CHECK(hipSetDevice(ctx->device));
   if (n_parts <= 0 || n_parts > 255 || n_keys <= 0) fail(QHIP_INVALID_ARGUMENT, "qhip_partition_filtered: bad arguments (1 .. 255 parts)");
   if (in->num_rows >= (int64_t)kNullIdx) fail(QHIP_UNSUPPORTED, "tables of 2^32 - 1 rows or more are not supported");
@@ -345,7 +357,7 @@ void partition_filtered(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, 
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->stats_timing_pending = 0;
   PartitionWork w;
-  partition_pass1(ctx, in, exprs, n_exprs, roots, n_keys, pred_root, n_parts, w);   // (HIP events 0 / 4 around its kernel)
+  partition_pass1(ctx, in, exprs, n_exprs, roots, n_keys, pred_root, n_parts, w, range_bounds);   // (HIP events 0 / 4 around its kernel)
   uint32_t* const back = (uint32_t*)ctx->pinned;   // [status words | parts' first positions + total]
   if ((size_t)(QS_WORDS + n_parts + 1) * 4 > ctx->pinned_bytes) fail(QHIP_UNSUPPORTED, "qhip_partition_filtered: too many parts for the read-back scratch");
   QHIP_HIP_CHECK(hipMemcpyAsync(back, w.dstat, QS_WORDS * 4, hipMemcpyDeviceToHost, s));
@@ -870,7 +882,7 @@ void comm_shuffle(Ctx* ctx, qhip_comm* c, const qhip_shuffle_input* ins, int n_i
     Side& sd = sides[(size_t)k];
     const qhip_shuffle_input& I = ins[k];
     if (sd.in->rows_dev) deferred_in = true;
-    partition_pass1(ctx, sd.in, I.exprs, I.n_exprs, I.key_roots, I.n_keys, I.predicate_root, sd.np, sd.w);
+    partition_pass1(ctx, sd.in, I.exprs, I.n_exprs, I.key_roots, I.n_keys, I.predicate_root, sd.np, sd.w, sd.np > 1 ? I.range_bounds : nullptr);
     // (NULLs in a kept column: known once the column is resolved — a deferred gather through a nullable index vector is made now)
     for (size_t j = 0; j < sd.cols.size(); ++j) {
       const DevColumn& c0 = sd.in->cols[sd.cols[j]];
@@ -1115,11 +1127,29 @@ int qhip_partition_by_key(qhip_ctx* ctx, const qhip_table* input, const qhip_exp
   return rc;
 }
 
+int qhip_table_column_range(qhip_ctx* ctx, const qhip_table* t, int64_t col, int64_t* out_min, int64_t* out_max) {
+  if (!ctx || !t || !out_min || !out_max || col < 0 || col >= (int64_t)t->cols.size()) return QHIP_INVALID_ARGUMENT;
+  return guarded(ctx, [&] {
+    QHIP_HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t mn = 0, mx = 0;
+    if (!key_range_of(ctx, t->cols[(size_t)col], mn, mx)) fail(QHIP_UNSUPPORTED, "qhip_table_column_range: not an integer-like column with values (" + dtype_name(t->cols[(size_t)col].type) + ")");
+    *out_min = mn; *out_max = mx;
+  });
+}
+
 int qhip_partition_filtered(qhip_ctx* ctx, const qhip_table* input, const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots,
                             int32_t n_keys, int32_t predicate_root, const int32_t* keep_columns, int32_t n_parts, qhip_table** out_parts) {
+  return qhip_partition_filtered_by_range(ctx, input, exprs, n_exprs, key_roots, n_keys, predicate_root, keep_columns, nullptr, n_parts, out_parts);
+}
+
+int qhip_partition_filtered_by_range(qhip_ctx* ctx, const qhip_table* input, const qhip_expr* exprs, int32_t n_exprs, const int32_t* key_roots,
+                                     int32_t n_keys, int32_t predicate_root, const int32_t* keep_columns, const int64_t* upper_bounds,
+                                     int32_t n_parts, qhip_table** out_parts) {
   if (!ctx || !input || !out_parts || !key_roots) return QHIP_INVALID_ARGUMENT;
   for (int p = 0; p < n_parts; ++p) out_parts[p] = nullptr;
   int rc = guarded(ctx, [&] {
+    if (upper_bounds && (n_parts > 255 || env_int("QHIP_PARTITION_FUSED", 1) == 0))
+      fail(QHIP_UNSUPPORTED, "partitioning by key range needs the fused path (<= 255 parts)");
     if (n_parts > 255 || env_int("QHIP_PARTITION_FUSED", 1) == 0) {
       // more parts than a byte names (or the switch): the generic sort-based path, which takes no filter and moves every column
       if (predicate_root >= 0) fail(QHIP_UNSUPPORTED, "qhip_partition_filtered: a fused scan filter needs the fused path (<= 255 parts)");
@@ -1131,7 +1161,7 @@ int qhip_partition_filtered(qhip_ctx* ctx, const qhip_table* input, const qhip_e
       return;
     }
     settle_rows(input);
-    partition_filtered(ctx, input, exprs, n_exprs, key_roots, n_keys, predicate_root, keep_columns, n_parts, out_parts);
+    partition_filtered(ctx, input, exprs, n_exprs, key_roots, n_keys, predicate_root, keep_columns, n_parts, out_parts, upper_bounds);
   });
   if (rc != QHIP_OK)
     for (int p = 0; p < n_parts; ++p) { if (out_parts[p]) { delete out_parts[p]; out_parts[p] = nullptr; } }

@@ -116,8 +116,9 @@ struct HPartIdsLaunch {
   uint32_t rows_per_unit;
   uint32_t wg_units;
   uint32_t pad_;
+  const int64_t* bounds = nullptr;
 };
-static_assert(sizeof(HPartIdsLaunch) == 40, "PartIdsLaunch layout");
+static_assert(sizeof(HPartIdsLaunch) == 48, "PartIdsLaunch layout");
 
 constexpr int kPartMaxCols = 8;   // QH_PART_MAXC
 struct HPartScatterLaunch {

@@ -64,12 +64,14 @@ struct PartitionWork {       // what pass 1 leaves on the device for pass 2
   DevBuf ids, runs, starts;  // part byte per row | scanned hist [n_parts * n_units] + total | the parts' first positions (n_parts + 1)
   uint32_t n_units = 0, rows_per_unit = 0;
   bool wg_units = false;     // a unit is a workgroup of pass 1 (pass 2 then runs its workgroup form)
+  DevBuf bounds_dev;         // partition by key range: the n_parts - 1 upper bounds (PartIdsLaunch::bounds)
+  std::vector<int64_t> bounds_host;
   uint32_t* dstat = nullptr;
   double pass1_bytes_per_row = 0;   // column bytes the filter + key expressions read per row
 };
 struct MovedColumn { size_t col; std::shared_ptr<DevBuf> out; int width; };   // a column's values of all parts, part after part
 void partition_pass1(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int n_exprs, const int32_t* roots, int n_keys, int pred_root,
-                     int n_parts, PartitionWork& w);
+                     int n_parts, PartitionWork& w, const int64_t* range_bounds = nullptr);
 void partition_scatter(Ctx* ctx, const qhip_table* in, const int32_t* keep, int n_parts, PartitionWork& w, uint64_t total,
                        std::vector<MovedColumn>& moved, std::vector<size_t>& odd, std::shared_ptr<DevBuf>& sel, bool rows_only);
 

@@ -132,7 +132,7 @@ def _comm_stats_into(reset: bool):
 
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
 _STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0, "heavy_keys": 0, "probe_rows_received": 0,
-          "transport_waits": 0, "heavy_key_rounds": 0}
+          "transport_waits": 0, "heavy_key_rounds": 0, "range_rounds": 0}
 
 
 def exchange_stats(reset: bool = True) -> dict:
@@ -142,7 +142,7 @@ def exchange_stats(reset: bool = True) -> dict:
     out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
     if reset:
         _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0, heavy_keys=0, probe_rows_received=0,
-                      transport_waits=0, heavy_key_rounds=0)
+                      transport_waits=0, heavy_key_rounds=0, range_rounds=0)
     return out
 
 
@@ -247,10 +247,12 @@ def partition_by_key(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts: 
 
 
 def partition_filtered(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts: int, predicate: Optional[PhysicalExpr] = None,
-                       keep: Optional[Sequence[bool]] = None) -> List[DeviceTable]:
+                       keep: Optional[Sequence[bool]] = None, range_bounds: Optional[Sequence[int]] = None) -> List[DeviceTable]:
     """qhip_partition_filtered: the split by key hash fused with the join side's scan filter (`predicate`: rows it rejects are
     in no part) and with the projection pushdown of the exchange (`keep`: only these columns are moved, the others become
-    NULL-typed placeholders) — two streaming passes over the columns involved, one host wait."""
+    NULL-typed placeholders) — two streaming passes over the columns involved, one host wait.
+    ``range_bounds`` (n_parts - 1 ascending upper bounds of ONE integer key): by key range instead of by hash
+    (qhip_partition_filtered_by_range)."""
     ctx = table.ctx
     ea = ExprArray()
     roots = [ea.lower(k) for k in keys]
@@ -258,13 +260,34 @@ def partition_filtered(table: DeviceTable, keys: Sequence[PhysicalExpr], n_parts
     arr, n = ea.c_array()
     outs = (C.c_void_p * n_parts)()
     keep_arr = None if keep is None else int32_array([1 if k else 0 for k in keep])
-    ctx.check(ctx.lib.qhip_partition_filtered(ctx.handle, table.handle, arr, n, int32_array(roots), len(roots), proot, keep_arr, n_parts, outs))
+    if range_bounds is not None:
+        assert len(range_bounds) == n_parts - 1
+        bounds = (C.c_int64 * max(1, n_parts - 1))(*[int(b) for b in range_bounds])
+        fn = ctx.lib.qhip_partition_filtered_by_range
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        ctx.check(fn(ctx.handle, table.handle, C.cast(arr, C.c_void_p), n, C.cast(int32_array(roots), C.c_void_p), len(roots), proot,
+                     None if keep_arr is None else C.cast(keep_arr, C.c_void_p), C.cast(bounds, C.c_void_p), n_parts, C.cast(outs, C.c_void_p)))
+    else:
+        ctx.check(ctx.lib.qhip_partition_filtered(ctx.handle, table.handle, arr, n, int32_array(roots), len(roots), proot, keep_arr, n_parts, outs))
     return [DeviceTable(ctx, C.c_void_p(outs[p])) for p in range(n_parts)]
+
+
+def column_range(table: DeviceTable, col: int) -> Tuple[int, int]:
+    """qhip_table_column_range: [min, max] of an integer-like column (a deferred gather answers with its source's range)"""
+    ctx = table.ctx
+    fn = ctx.lib.qhip_table_column_range
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lo, hi = C.c_int64(), C.c_int64()
+    ctx.check(fn(ctx.handle, table.handle, int(col), C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
 
 
 class qhip_shuffle_input(C.Structure):
     _fields_ = [("table", C.c_void_p), ("exprs", C.POINTER(_ffi.qhip_expr)), ("n_exprs", C.c_int32), ("key_roots", C.POINTER(C.c_int32)),
-                ("n_keys", C.c_int32), ("predicate_root", C.c_int32), ("all_gather", C.c_int32), ("keep_columns", C.POINTER(C.c_int32))]
+                ("n_keys", C.c_int32), ("predicate_root", C.c_int32), ("all_gather", C.c_int32), ("keep_columns", C.POINTER(C.c_int32)),
+                ("range_bounds", C.POINTER(C.c_int64))]
 
 
 def shuffle_tables(inputs) -> List[DeviceTable]:
@@ -277,14 +300,17 @@ def shuffle_tables(inputs) -> List[DeviceTable]:
     lib.qhip_shuffle_tables.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(qhip_shuffle_input), C.c_int32, C.POINTER(C.c_void_p)]
     arr = (qhip_shuffle_input * len(inputs))()
     hold = []
-    for k, (table, keys, predicate, keep, all_gather) in enumerate(inputs):
+    for k, item in enumerate(inputs):
+        table, keys, predicate, keep, all_gather = item[:5]
+        bounds = item[5] if len(item) > 5 else None     # world - 1 ascending upper bounds: rows go to ranks by key RANGE
         ea = ExprArray()
         roots = [ea.lower(e) for e in keys]
         proot = ea.lower(predicate) if predicate is not None else -1
         exprs, n = ea.c_array()
         roots_c = int32_array(roots)
         keep_c = None if keep is None else int32_array([1 if v else 0 for v in keep])
-        hold.append((ea, exprs, roots_c, keep_c))
+        bounds_c = None if bounds is None else (C.c_int64 * max(1, len(bounds)))(*[int(b) for b in bounds])
+        hold.append((ea, exprs, roots_c, keep_c, bounds_c))
         arr[k].table = table.handle
         arr[k].exprs = exprs
         arr[k].n_exprs = n
@@ -293,6 +319,7 @@ def shuffle_tables(inputs) -> List[DeviceTable]:
         arr[k].predicate_root = proot
         arr[k].all_gather = int(all_gather)   # bit 0: all-gather; bit 1: a join on the keys follows (their value ranges travel)
         arr[k].keep_columns = keep_c
+        arr[k].range_bounds = bounds_c
     outs = (C.c_void_p * len(inputs))()
     ctx.check(lib.qhip_shuffle_tables(ctx.handle, get_comm(ctx), arr, len(inputs), outs))
     return [DeviceTable(ctx, C.c_void_p(outs[k])) for k in range(len(inputs))]
@@ -504,8 +531,12 @@ class LocalEngine:
     def keep_columns(self, table, mask):
         return keep_columns(table, mask)
 
-    def partition(self, table, keys, n_parts):
-        return partition_filtered(table, keys, n_parts)
+    def partition(self, table, keys, n_parts, range_bounds=None):
+        return partition_filtered(table, keys, n_parts, range_bounds=range_bounds)
+
+    def key_range(self, table, col: int):
+        """(min, max) of an integer key column of a rank-local table (a superset is fine: it only steers the routing)"""
+        return column_range(table, col)
 
     def pack(self, table):
         return pack_table(table)
@@ -709,20 +740,60 @@ class DistributedHashJoinExec(HashJoinExec):
         self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
         return keys
 
+    def _range_bounds_now(self, world, build_table):
+        """world - 1 ascending upper bounds when the rows are to be routed by KEY RANGE instead of by key hash, else None.
+        QHIP_EXCHANGE_RANGE=1 (off by default: DESIGN §7 "routing by key range"). Every rank contributes the [min, max] of its
+        build side's key column (a statistic of the resident table, computed once); when the ranks' ranges are disjoint and
+        ascending with the rank — tables sliced in key order, TPC-H's orders and lineitem — rank r gets the keys up to ITS maximum.
+        BOTH sides of the join are split by the same bounds, so the join is correct whatever the bounds are: a stale or
+        lopsided set costs balance or traffic only. The agreed bounds are kept and refreshed every HEAVY_REFRESH executions."""
+        if os.environ.get("QHIP_EXCHANGE_RANGE", "0") != "1" or len(self.on) != 1 or world < 2:
+            return None
+        import pyarrow as pa
+        from .expr import Column
+        lkey, rkey = self.on[0]
+        if not (isinstance(lkey, Column) and isinstance(rkey, Column)):
+            return None
+        lt_, rt_ = _expr_type(lkey, self.left.schema()), _expr_type(rkey, self.right.schema())
+        ok = lambda t: t is not None and (pa.types.is_integer(t) or pa.types.is_date(t))   # noqa: E731
+        if not (ok(lt_) and ok(rt_)):
+            return None
+        cached = getattr(self, "_range_cache", None)
+        if cached is not None and cached[0] == world and cached[2] > 0:
+            self._range_cache = (world, cached[1], cached[2] - 1)
+            return cached[1]
+        import torch
+        dist = _dist()
+        lo, hi = _engine().key_range(build_table, lkey.index)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        if dev.type == "cuda" and "h" in _COMM:
+            _COMM["ctx"].synchronize()   # (two RCCL communicators never active at once: see heavy_keys)
+        mine = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=dev)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        ranges = [tuple(t.cpu().tolist()) for t in everyone]
+        bounds = [r[1] for r in ranges[:-1]]
+        disjoint = all(ranges[r][0] <= ranges[r][1] for r in range(world)) and all(ranges[r][1] < ranges[r + 1][0] for r in range(world - 1))
+        bounds = bounds if disjoint else None
+        _STATS["range_rounds"] = _STATS.get("range_rounds", 0) + 1
+        self._range_cache = (world, bounds, HEAVY_REFRESH - 1)
+        return bounds
+
     def _exchange_inputs(self, world):
-        """(build table, probe table) of the local join: both sides repartitioned by key hash"""
+        """(build table, probe table) of the local join: both sides repartitioned by key hash — or by key range"""
         ls, rs = self.left.schema(), self.right.schema()
         lneed, rneed = self._needed_per_side()
         if _fast_exchange():
-            heavy = self._heavy_keys_now(world, rs, _wire_schema(rs, rneed))
+            lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
+            rt, rpred = _side_for_exchange(self.right, False)
+            bounds = self._range_bounds_now(world, lt)
+            heavy = None if bounds is not None else self._heavy_keys_now(world, rs, _wire_schema(rs, rneed))
             if not heavy:
                 # ONE call, ONE host wait for both sides; the build side may be a join of deferred size when nothing executes
                 # between it and the exchange (the probe side is a table access)
                 try:
-                    lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
-                    rt, rpred = _side_for_exchange(self.right, False)
-                    got = shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), 2),
-                                          (rt, [r for _, r in self.on], rpred, _keep_mask(len(rs), rneed), 2)])
+                    got = shuffle_tables([(lt, [l for l, _ in self.on], lpred, _keep_mask(len(ls), lneed), 2, bounds),
+                                          (rt, [r for _, r in self.on], rpred, _keep_mask(len(rs), rneed), 2, bounds)])
                     _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + got[1].num_rows
                     return got[0], got[1]
                 except _ffi.UnsupportedError:
@@ -741,6 +812,12 @@ class DistributedHashJoinExec(HashJoinExec):
         left = E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed))
         right = E.keep_columns(E.execute(self.right), _keep_mask(len(rs), rneed))
         lw, rw = _wire_schema(ls, lneed), _wire_schema(rs, rneed)
+        bounds = self._range_bounds_now(world, left)
+        if bounds is not None:   # by key range: both sides split by the same bounds, no heavy-hitter handling (co-located rows stay)
+            lt = exchange_device_tables(E.partition(left, [l for l, _ in self.on], world, bounds), lw)
+            rt = exchange_device_tables(E.partition(right, [r for _, r in self.on], world, bounds), rw)
+            _STATS["probe_rows_received"] = _STATS.get("probe_rows_received", 0) + E.num_rows(rt)
+            return lt, rt
         heavy_l = heavy_r = None
         # heavy hitters (one key column, join types in which a result row belongs to exactly one probe row): their probe rows
         # stay on this rank, their build rows go to every rank; everything else is repartitioned by key hash

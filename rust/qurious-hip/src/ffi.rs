@@ -162,6 +162,8 @@ pub struct qhip_shuffle_input {
     pub predicate_root: i32,
     pub all_gather: i32,
     pub keep_columns: *const i32,
+    /// NULL: rows go to rank hash(key) % world; else world - 1 ascending upper bounds of ONE integer-like key
+    pub range_bounds: *const i64,
 }
 
 extern "C" {
@@ -313,6 +315,20 @@ extern "C" {
         n_parts: i32,
         out_parts: *mut *mut qhip_table,
     ) -> c_int;
+    pub fn qhip_partition_filtered_by_range(
+        ctx: *mut qhip_ctx,
+        input: *const qhip_table,
+        exprs: *const qhip_expr,
+        n_exprs: i32,
+        key_roots: *const i32,
+        n_keys: i32,
+        predicate_root: i32,
+        keep_columns: *const i32,
+        upper_bounds: *const i64,
+        n_parts: i32,
+        out_parts: *mut *mut qhip_table,
+    ) -> c_int;
+    pub fn qhip_table_column_range(ctx: *mut qhip_ctx, t: *const qhip_table, col: i64, out_min: *mut i64, out_max: *mut i64) -> c_int;
     pub fn qhip_table_forget_statistics(t: *mut qhip_table) -> c_int;
     pub fn qhip_table_aux_bytes(t: *const qhip_table) -> i64;
     pub fn qhip_table_concat(ctx: *mut qhip_ctx, tables: *const *const qhip_table, n: i32, out: *mut *mut qhip_table) -> c_int;
