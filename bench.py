@@ -405,6 +405,10 @@ class Q3:
             if USE_DIST and strategy == "broadcast":
                 # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
                 p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, agg_cls=ex.DistributedHashAggregate)
+            elif USE_DIST and strategy == "range":
+                # join 1 broadcasts the customer keys and leaves the orders in place; join 2 routes BOTH its sides by the ranks'
+                # order-key ranges (QHIP_EXCHANGE_RANGE): tables sliced in key order exchange their border rows only
+                p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, join2_cls=ex.DistributedHashJoinExec)
             else:
                 p = queries.q3(*self.tabs, join_cls=ex.DistributedHashJoinExec if USE_DIST else None)
             if USE_DIST:
@@ -413,7 +417,13 @@ class Q3:
         return self.plans[strategy]
 
     def step(self, strategy=None):
-        self.out = self.plan(strategy or self.strategy).execute_device()
+        strategy = strategy or self.strategy
+        if strategy == "range":
+            os.environ["QHIP_EXCHANGE_RANGE"] = "1"
+        try:
+            self.out = self.plan(strategy).execute_device()
+        finally:
+            os.environ.pop("QHIP_EXCHANGE_RANGE", None)
         return self.out
 
     def totals(self, torch, dist):
@@ -653,8 +663,9 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="lineitem rows of the q1_* / filter workloads (whole job; default: 100 M for q1_mini, SF10's for q1_full)")
     ap.add_argument("--batch-rows", type=int, default=1 << 20)
     ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of Q3 (whole job, sliced over the ranks)")
-    ap.add_argument("--strategy", default="broadcast", choices=["broadcast", "repartition"],
-                    help="Q3 on several GPUs: all-gather the small build sides (default) or repartition both sides of every join by key")
+    ap.add_argument("--strategy", default="broadcast", choices=["broadcast", "repartition", "range"],
+                    help="Q3 on several GPUs: all-gather the small build sides (default), repartition both sides of every join by key hash, "
+                         "or broadcast join 1's build side and route join 2 by the ranks' key ranges")
     ap.add_argument("--skew", type=float, default=0.0, help="Q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
     ap.add_argument("--slice", default="", help="Q3 on ONE GPU over rank R's 1/N slice of every table, as R/N (configs[4]: --sf 100 --skew 1.1 --slice 0/8)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16 << 20, help="rows of a q1_* workload timed through the CPU oracle (per run)")
@@ -757,8 +768,12 @@ def main():
     records["q1_sf10"], _ = q1.record(args, clock, with_cpu)
     records["q3_sf10"], _ = q3.record(args, clock, torch, dist, with_cpu)
     if USE_DIST:
-        other = "repartition" if args.strategy == "broadcast" else "broadcast"
-        records[f"q3_sf10_{other}"], _ = q3.record(args, clock, torch, dist, False, strategy=other)
+        for other in ("broadcast", "repartition", "range"):
+            if other != args.strategy:
+                try:
+                    records[f"q3_sf10_{other}"], _ = q3.record(args, clock, torch, dist, False, strategy=other)
+                except Exception as e:   # (an alternative strategy's record never takes the headline line down)
+                    records[f"q3_sf10_{other}_error"] = f"{type(e).__name__}: {e}"
     if USE_DIST and os.environ.get("QHIP_BENCH_NO_SF100") != "1":
         # BASELINE configs[4]: Q3 with Zipf(1.1) join keys, every rank holding what ONE OF EIGHT ranks holds at SF100 (12.5
         # scale-factor units per rank: exactly SF100 at N = 8, SF25 / SF50 at N = 2 / 4) — the size at which a rank's local

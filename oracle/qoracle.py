@@ -675,6 +675,16 @@ def _mix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
+def partition_ids_by_range(key_array, upper_bounds: Sequence[int]) -> np.ndarray:
+    """numpy restatement of qhip_partition_filtered_by_range's row -> part mapping (csrc/device/qhip_device.hpp qh_part_range):
+    part = the number of bounds the key is GREATER than (bounds ascending; part p takes (bounds[p - 1], bounds[p]], the last part
+    everything above); a NULL key goes where 0 goes."""
+    a = key_array.combine_chunks() if isinstance(key_array, pa.ChunkedArray) else key_array
+    t = a.type
+    v = np.array(a.cast(pa.int32() if (pa.types.is_date32(t) or pa.types.is_time32(t)) else pa.int64()).fill_null(0)).astype(np.int64)
+    return np.searchsorted(np.asarray(list(upper_bounds), dtype=np.int64), v, side="left").astype(np.int64)
+
+
 def partition_ids(key_arrays: Sequence[pa.Array], n_parts: int) -> np.ndarray:
     """numpy restatement of qhip_partition_by_key's row -> part mapping (csrc/device/qhip_device.hpp qh_part_hash over the key
     words of csrc/codegen.cpp emit_key_words): ints/dates sign-extended to 64 bits, Decimal128 as (lo, hi), Utf8 <= 31 bytes

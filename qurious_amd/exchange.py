@@ -538,6 +538,11 @@ class LocalEngine:
         """(min, max) of an integer key column of a rank-local table (a superset is fine: it only steers the routing)"""
         return column_range(table, col)
 
+    def key_share_in_range(self, table, schema, key, lo_excl, hi_incl) -> float:
+        """fraction of a strided sample of `table`'s rows whose key lies in (lo_excl, hi_incl] (None = open): how much of a probe
+        side would stay on this rank under range routing"""
+        return _sample_share_in_range(table, schema, key, lo_excl, hi_incl)
+
     def pack(self, table):
         return pack_table(table)
 
@@ -694,6 +699,34 @@ def _local_top_keys(table: DeviceTable, schema, key: PhysicalExpr, dtype):
     return [(k, c) for k, c in rows if k is not None], sample.num_rows
 
 
+def _sample_share_in_range(table: DeviceTable, schema, key: PhysicalExpr, lo_excl, hi_incl) -> float:
+    from .datatypes import Operator, ScalarValue
+    from .expr import BinaryExpr, CountAggregateExpr, Literal
+    from .plan import Filter, NoGroupingAggregate
+    import pyarrow as pa
+    ctx = table.ctx
+    out = C.c_void_p()
+    ctx.check(ctx.lib.qhip_table_stride_sample(ctx.handle, table.handle, HEAVY_SAMPLE_STRIDE, C.byref(out)))
+    sample = DeviceTable(ctx, out)
+    if sample.num_rows == 0:
+        return 1.0
+    dtype = _expr_type(key, schema)
+    pred = None
+    for bound, op in ((lo_excl, Operator.Gt), (hi_incl, Operator.LtEq)):
+        if bound is None:
+            continue
+        lit = _key_literal(bound, dtype)
+        if lit is None:
+            return 0.0
+        term = BinaryExpr(key, op, lit)
+        pred = term if pred is None else BinaryExpr(pred, Operator.And, term)
+    src = DeviceSource(schema, sample)
+    node = src if pred is None else Filter(src, pred)
+    agg = NoGroupingAggregate(pa.schema([pa.field("n", pa.int64())]), node, [CountAggregateExpr(Literal(ScalarValue.Int64(1)))])
+    n = sum(b.column(0).to_pylist()[0] for b in agg.execute())
+    return float(n) / float(sample.num_rows)
+
+
 class DistributedHashJoinExec(HashJoinExec):
     """HashJoinExec whose inputs are this rank's slices: both sides are repartitioned by the join key across the ranks of
     ``torch.distributed``'s default group, then joined locally. Row order across ranks is not the single-process order
@@ -740,13 +773,15 @@ class DistributedHashJoinExec(HashJoinExec):
         self._heavy_cache = (world, keys, HEAVY_REFRESH - 1)
         return keys
 
-    def _range_bounds_now(self, world, build_table):
+    def _range_bounds_now(self, world, build_table, probe_table):
         """world - 1 ascending upper bounds when the rows are to be routed by KEY RANGE instead of by key hash, else None.
         QHIP_EXCHANGE_RANGE=1 (off by default: DESIGN §7 "routing by key range"). Every rank contributes the [min, max] of its
         build side's key column (a statistic of the resident table, computed once); when the ranks' ranges are disjoint and
         ascending with the rank — tables sliced in key order, TPC-H's orders and lineitem — rank r gets the keys up to ITS maximum.
         BOTH sides of the join are split by the same bounds, so the join is correct whatever the bounds are: a stale or
-        lopsided set costs balance or traffic only. The agreed bounds are kept and refreshed every HEAVY_REFRESH executions."""
+        lopsided set costs balance or traffic only. It is taken only when the PROBE side is laid out the same way (a rank's probe
+        keys reach no further than its neighbours' build ranges): routing unordered or skewed probe rows by range would give up
+        the hash's balance and the heavy-hitter handling. The agreed bounds are kept and refreshed every HEAVY_REFRESH executions."""
         if os.environ.get("QHIP_EXCHANGE_RANGE", "0") != "1" or len(self.on) != 1 or world < 2:
             return None
         import pyarrow as pa
@@ -764,17 +799,32 @@ class DistributedHashJoinExec(HashJoinExec):
             return cached[1]
         import torch
         dist = _dist()
+        rank = dist.get_rank()
         lo, hi = _engine().key_range(build_table, lkey.index)
+        plo, phi = _engine().key_range(probe_table, rkey.index)
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         if dev.type == "cuda" and "h" in _COMM:
             _COMM["ctx"].synchronize()   # (two RCCL communicators never active at once: see heavy_keys)
-        mine = torch.tensor([int(lo), int(hi)], dtype=torch.int64, device=dev)
+        mine = torch.tensor([int(lo), int(hi), int(plo), int(phi)], dtype=torch.int64, device=dev)
         everyone = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         ranges = [tuple(t.cpu().tolist()) for t in everyone]
         bounds = [r[1] for r in ranges[:-1]]
         disjoint = all(ranges[r][0] <= ranges[r][1] for r in range(world)) and all(ranges[r][1] < ranges[r + 1][0] for r in range(world - 1))
-        bounds = bounds if disjoint else None
+        # the probe slices follow the build slices: rank r's probe keys lie between the build ranges of ranks r - 1 and r + 1
+        aligned = all((r < 2 or ranges[r][2] > ranges[r - 2][1]) and (r + 2 >= world or ranges[r][3] < ranges[r + 2][0]) for r in range(world)
+                      if ranges[r][2] <= ranges[r][3])
+        bounds = bounds if (disjoint and aligned) else None
+        if bounds is not None:
+            # ... and most of every rank's probe rows would stay where they are (a strided sample): unordered or skewed probe keys
+            # inside aligned RANGES (Zipf-drawn foreign keys) keep the hash's balance and heavy-hitter handling
+            share = _engine().key_share_in_range(probe_table, self.right.schema(), rkey, bounds[rank - 1] if rank > 0 else None,
+                                                 bounds[rank] if rank < world - 1 else None)
+            mine = torch.tensor([int(share * 1000)], dtype=torch.int64, device=dev)
+            everyone = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            if min(int(t.cpu().item()) for t in everyone) < 800:   # (co-located tables: > 0.95; keys drawn at random: 1 / world)
+                bounds = None
         _STATS["range_rounds"] = _STATS.get("range_rounds", 0) + 1
         self._range_cache = (world, bounds, HEAVY_REFRESH - 1)
         return bounds
@@ -786,7 +836,7 @@ class DistributedHashJoinExec(HashJoinExec):
         if _fast_exchange():
             lt, lpred = _side_for_exchange(self.left, _is_table_access(self.right))
             rt, rpred = _side_for_exchange(self.right, False)
-            bounds = self._range_bounds_now(world, lt)
+            bounds = self._range_bounds_now(world, lt, rt)
             heavy = None if bounds is not None else self._heavy_keys_now(world, rs, _wire_schema(rs, rneed))
             if not heavy:
                 # ONE call, ONE host wait for both sides; the build side may be a join of deferred size when nothing executes
@@ -812,7 +862,7 @@ class DistributedHashJoinExec(HashJoinExec):
         left = E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed))
         right = E.keep_columns(E.execute(self.right), _keep_mask(len(rs), rneed))
         lw, rw = _wire_schema(ls, lneed), _wire_schema(rs, rneed)
-        bounds = self._range_bounds_now(world, left)
+        bounds = self._range_bounds_now(world, left, right)
         if bounds is not None:   # by key range: both sides split by the same bounds, no heavy-hitter handling (co-located rows stay)
             lt = exchange_device_tables(E.partition(left, [l for l, _ in self.on], world, bounds), lw)
             rt = exchange_device_tables(E.partition(right, [r for _, r in self.on], world, bounds), rw)

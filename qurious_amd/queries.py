@@ -54,7 +54,7 @@ def q1_partial(table: MemoryTable) -> HashAggregate:
     return HashAggregate(pa.schema([pa.field(n, t) for n, t in zip(names, types)]), full.input, full.group_exprs, aggs)
 
 
-def q3(customer, orders, lineitem, join_cls=None, agg_cls=None):
+def q3(customer, orders, lineitem, join_cls=None, agg_cls=None, join2_cls=None):
     """configs[3]: TPC-H Q3 (tests/tpch/q3.slt:2-24) up to the HashAggregate output, in the plan shape the reference's
     optimizer produces: filters pushed into the scans, build side = left child, no side swapping.
     customer / orders / lineitem are MemoryTables over synth.{CUSTOMER,ORDERS,LINEITEM_Q3}_SCHEMA."""
@@ -62,13 +62,14 @@ def q3(customer, orders, lineitem, join_cls=None, agg_cls=None):
     from .plan import HashJoinExec
     from .synth import CUSTOMER_SCHEMA, LINEITEM_Q3_SCHEMA, ORDERS_SCHEMA
     join_cls = join_cls or HashJoinExec
+    join2_cls = join2_cls or join_cls      # (multi-GPU: the two joins may take different exchange strategies, exchange.py)
     day = _date("1995-03-15")
     c_scan = Scan(CUSTOMER_SCHEMA, customer, None, BinaryExpr(Column("c_mktsegment", 1), Operator.Eq, Literal(ScalarValue.Utf8("BUILDING"))))
     o_scan = Scan(ORDERS_SCHEMA, orders, None, BinaryExpr(Column("o_orderdate", 2), Operator.Lt, day))
     l_scan = Scan(LINEITEM_Q3_SCHEMA, lineitem, None, BinaryExpr(Column("l_shipdate", 1), Operator.Gt, day))
     j1 = join_cls.try_new(c_scan, o_scan, JoinType.Inner, [(Column("c_custkey", 0), Column("o_custkey", 1))], None)
     # j1 schema: c_custkey c_mktsegment | o_orderkey o_custkey o_orderdate o_shippriority
-    j2 = join_cls.try_new(j1, l_scan, JoinType.Inner, [(Column("o_orderkey", 2), Column("l_orderkey", 0))], None)
+    j2 = join2_cls.try_new(j1, l_scan, JoinType.Inner, [(Column("o_orderkey", 2), Column("l_orderkey", 0))], None)
     # j2 schema: j1 (6) | l_orderkey l_shipdate l_extendedprice l_discount
     one = CastExpr(Literal(ScalarValue.Int64(1)), pa.decimal128(20, 0))
     revenue = BinaryExpr(Column("l_extendedprice", 8), Operator.Mul, BinaryExpr(one, Operator.Sub, Column("l_discount", 9)))

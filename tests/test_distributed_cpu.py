@@ -361,9 +361,30 @@ def _stub_engine():
             cols = [c if m else pa.nulls(table.num_rows, type=c.type) for c, m in zip(table.columns, mask)]
             return pa.RecordBatch.from_arrays(cols, schema=table.schema)
 
-        def partition(self, table, keys, n_parts):
-            pid = qoracle.partition_ids([table.column(k.index) for k in keys], n_parts) if table.num_rows else np.zeros(0, dtype=np.int64)
+        def partition(self, table, keys, n_parts, range_bounds=None):
+            if not table.num_rows:
+                pid = np.zeros(0, dtype=np.int64)
+            elif range_bounds is not None:
+                self.log["range_partitions"] += 1
+                pid = qoracle.partition_ids_by_range(table.column(keys[0].index), range_bounds)
+            else:
+                pid = qoracle.partition_ids([table.column(k.index) for k in keys], n_parts)
             return [table.filter(pa.array(pid == p)) for p in range(n_parts)]
+
+        def key_share_in_range(self, table, schema, key, lo_excl, hi_incl):
+            v = table.column(key.index).drop_null().to_numpy(zero_copy_only=False)[::8]
+            if not len(v):
+                return 1.0
+            m = np.ones(len(v), dtype=bool)
+            if lo_excl is not None:
+                m &= v > lo_excl
+            if hi_incl is not None:
+                m &= v <= hi_incl
+            return float(m.mean())
+
+        def key_range(self, table, col):
+            v = table.column(col).drop_null().to_numpy(zero_copy_only=False)
+            return (int(v.min()), int(v.max())) if len(v) else (0, -1)
 
         def pack(self, table):
             self.log["packed"] += 1
@@ -474,3 +495,71 @@ def test_exchange_operators_end_to_end_with_a_stub_local_engine_world2_gloo(tmp_
     port = _free_port()
     mp.spawn(_worker_operators, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert int(open(tmp_path / "ok_operators").read()) > 50
+
+
+def _worker_range(rank, world, port, out_dir):
+    """QHIP_EXCHANGE_RANGE=1: tables sliced in KEY order (TPC-H's orders / lineitem) are routed by key range — almost nothing
+    moves; tables whose slices overlap in key space fall back to hash routing; either way the union equals the single-process join"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), QHIP_EXCHANGE_RANGE="1")
+    import torch.distributed as dist
+    from oracle import qoracle
+    from qurious_amd import exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    engine = _stub_engine()
+    exchange.set_local_engine(engine)
+    try:
+        rng = np.random.default_rng(3)
+        n_orders, n_items = 4000, 15000
+        os_ = pa.schema([pa.field("o_key", I64), pa.field("o_v", I64)])
+        ls_ = pa.schema([pa.field("l_key", I64), pa.field("l_v", I64)])
+        ob = pa.RecordBatch.from_arrays([pa.array(np.arange(n_orders) * 4 + 1, type=I64), pa.array(rng.integers(0, 100, n_orders), type=I64)], schema=os_)
+        lk = np.sort(rng.integers(0, n_orders, n_items)) * 4 + 1
+        lb = pa.RecordBatch.from_arrays([pa.array(lk, type=I64, mask=rng.random(n_items) < 0.01), pa.array(np.arange(n_items), type=I64)], schema=ls_)
+        cut = lambda b: b.slice(b.num_rows * rank // world, b.num_rows * (rank + 1) // world - b.num_rows * rank // world)   # noqa: E731
+        on = [(col("o_key", 0), col("l_key", 0))]
+        results = {}
+        # (1) both tables in key order, sliced by row ranges: the ranks' order-key ranges are disjoint -> range routing
+        exchange.exchange_stats(reset=True)
+        for jt in (JoinType.Inner, JoinType.Left, JoinType.Full):
+            plan = exchange.DistributedHashJoinExec.try_new(table_scan(os_, [cut(ob)]), table_scan(ls_, [cut(lb)]), jt, on)
+            results["sorted-" + jt.name] = rows_of([engine.execute(plan)])
+        st = exchange.exchange_stats(reset=True)
+        assert engine.log["range_partitions"] == 6 and st["range_rounds"] == 3
+        moved_sorted = st["bytes_sent"]
+        # (2) the same rows shuffled before slicing: every rank's key range covers everything -> hash routing, as before
+        perm_o, perm_l = rng.permutation(n_orders), rng.permutation(n_items)
+        ob2, lb2 = ob.take(pa.array(perm_o)), lb.take(pa.array(perm_l))
+        plan = exchange.DistributedHashJoinExec.try_new(table_scan(os_, [cut(ob2)]), table_scan(ls_, [cut(lb2)]), JoinType.Inner, on)
+        results["shuffled"] = rows_of([engine.execute(plan)])
+        st = exchange.exchange_stats(reset=True)
+        assert engine.log["range_partitions"] == 6 and st["range_rounds"] == 1       # asked, ranges overlap, hash
+        moved_hashed = st["bytes_sent"]
+        # (3) orders in key order but the probe keys drawn at random over ALL orders: the ranges are aligned, the rows are not
+        lb3 = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, n_orders, n_items) * 4 + 1, type=I64), pa.array(np.arange(n_items), type=I64)], schema=ls_)
+        plan = exchange.DistributedHashJoinExec.try_new(table_scan(os_, [cut(ob)]), table_scan(ls_, [cut(lb3)]), JoinType.Inner, on)
+        results["random-probe"] = rows_of([engine.execute(plan)])
+        assert engine.log["range_partitions"] == 6                                     # hash again
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (results, moved_sorted, moved_hashed))
+        if rank == 0:
+            union = lambda name: sorted((r for g in gathered for r in g[0][name]), key=repr)   # noqa: E731
+            for jt in (JoinType.Inner, JoinType.Left, JoinType.Full):
+                full = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb]), jt, on)
+                assert union("sorted-" + jt.name) == sorted(rows_of(qoracle.execute(full)), key=repr), jt
+            full = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb]), JoinType.Inner, on)
+            assert union("shuffled") == sorted(rows_of(qoracle.execute(full)), key=repr)
+            full3 = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb3]), JoinType.Inner, on)   # (same seed on every rank: lb3 is the whole table)
+            assert union("random-probe") == sorted(rows_of(qoracle.execute(full3)), key=repr)
+            # three range-routed joins moved less than a tenth of what ONE hash-routed join moves (only rows at the slice borders)
+            assert sum(g[1] for g in gathered) * 10 < sum(g[2] for g in gathered) * 3, [(g[1], g[2]) for g in gathered]
+            open(os.path.join(out_dir, "ok_range"), "w").write("ok")
+    finally:
+        exchange.set_local_engine(None)
+        dist.destroy_process_group()
+
+
+def test_exchange_by_key_range_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_range, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "ok_range").read() == "ok"

@@ -159,3 +159,28 @@ def test_many_rows_per_unit_and_many_units(ctx, oracle, monkeypatch):
         monkeypatch.setenv("QHIP_PART_ROWS_PER_UNIT", rpu)
         parts = exchange.partition_filtered(dev, [col("k", 0)], 8, keep=[True, False, True, False, True, True, False, True, True])
         _check_parts(parts, batch, pid, None, [True, False, True, False, True, True, False, True, True])
+
+
+def test_partition_by_key_range(ctx, oracle):
+    """Round 4 (qhip_partition_filtered_by_range): the part of a row chosen by the RANGE its key falls in — bounds that cut between,
+    exactly at and outside the key values, equal bounds (an empty part), negative keys, a Date32 key, NULL keys (they go where 0
+    goes), a scan filter and dropped columns alongside, 2 .. 17 parts; every part keeps the input's row order. And what the
+    exchange relies on: two tables split by the same bounds are co-located key by key."""
+    schema, batch = _mixed_batch(60_007, 77, null_frac=0.05)
+    dev = table_scan(schema, [batch.slice(0, 20_000), batch.slice(20_000)]).execute_device()
+    for bounds in ([1000], [-60, 0, 4999], [-50, -50, 10, 10, 2500, 7000], list(range(-40, 4800, 300))):
+        parts = exchange.partition_filtered(dev, [col("k", 0)], len(bounds) + 1, range_bounds=bounds)
+        pid = oracle.partition_ids_by_range(batch.column("k"), bounds)
+        _check_parts(parts, batch, pid)
+        assert sum(p.num_rows for p in parts) == batch.num_rows
+    pred = q.BinaryExpr(col("i", 4), Operator.Gt, q.Literal(q.ScalarValue.Int32(0)))
+    keep = [True, False, True, False, True, True, False, True, False]
+    bounds = [8500, 9000, 9900]
+    parts = exchange.partition_filtered(dev, [col("t", 7)], 4, predicate=pred, keep=keep, range_bounds=bounds)
+    passes = np.array(pc.fill_null(pc.greater(batch.column("i"), 0), False))
+    _check_parts(parts, batch, oracle.partition_ids_by_range(batch.column("t"), bounds), passes, keep)
+    with pytest.raises(q.UnsupportedError):
+        exchange.partition_filtered(dev, [col("s", 1)], 3, range_bounds=[1, 2])           # not an integer-like key
+    with pytest.raises(Exception):
+        exchange.partition_filtered(dev, [col("k", 0)], 3, range_bounds=[5, 1])           # bounds not ascending
+    assert exchange.column_range(dev, 0)[0] <= -50 and exchange.column_range(dev, 0)[1] >= 4999

@@ -50,11 +50,20 @@ def two_rank_worker(rank, world, port, sf, out_dir, skew=0.0):
         mine = (q.MemoryTable.try_new(synth.CUSTOMER_SCHEMA, c), q.MemoryTable.try_new(synth.ORDERS_SCHEMA, o),
                 q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
         results = {}
+        # "range" (round 4, DESIGN §7 "routing by key range"): join 1 broadcasts the customer keys and leaves the orders where they
+        # are, so that join 2's build side keeps its order-key range and BOTH its sides are routed by the ranks' key ranges —
+        # tables sliced in key order exchange only the rows at the slice borders (and groups stay disjoint: no aggregate exchange)
         for name, plan in (("repartition", queries.q3(*mine, join_cls=exchange.DistributedHashJoinExec)),
-                           ("broadcast", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate))):
+                           ("broadcast", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)),
+                           ("range", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, join2_cls=exchange.DistributedHashJoinExec))):
             exchange.prune_exchange_columns(plan)
             exchange.exchange_stats()
-            local = rows_of(plan.execute_device().to_batches())
+            if name == "range":
+                os.environ["QHIP_EXCHANGE_RANGE"] = "1"
+            try:
+                local = rows_of(plan.execute_device().to_batches())
+            finally:
+                os.environ.pop("QHIP_EXCHANGE_RANGE", None)
             st = exchange.exchange_stats()
             gathered = [None] * world
             dist.all_gather_object(gathered, (local, st["bytes_sent"], st["heavy_keys"], st["probe_rows_received"]))
@@ -71,6 +80,9 @@ def two_rank_worker(rank, world, port, sf, out_dir, skew=0.0):
                 assert all(g[1] > 0 for g in gathered)            # every rank really sent rows to the others
                 print(f"[rehearsal] {world} processes, {name}: {len(got)} groups in all ({[len(g[0]) for g in gathered]} per rank) equal to the "
                       f"single-process plan; bytes sent per rank {[g[1] for g in gathered]}")
+                if name == "range" and skew == 0:
+                    # uniform TPC-H-shaped tables, sliced in key order: far less than the repartitioned plan moves
+                    assert sum(g[1] for g in gathered) * 4 < sum(g[1] for g in results["repartition"]), "range routing moved as much as hash routing"
                 if skew > 0 and name == "repartition":
                     # Zipf keys: the repartitioned joins found heavy hitters, kept their probe rows local, and the ranks'
                     # probe sides stay balanced
