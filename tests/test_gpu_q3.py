@@ -197,7 +197,7 @@ def test_multi_rank_code_path_rehearsal_on_one_gpu():
     # the host): real cross-rank partition / transport / unpack / join / merge; the union equals the single-process plan
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2"],
                        env=dict(os.environ), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and r.stdout.count("equal to the single-process plan") == 2, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode == 0 and "REHEARSAL OK" in r.stdout and r.stdout.count("equal to the single-process plan") == 3, r.stdout[-2000:] + r.stderr[-4000:]
     # ... and with Zipf(1.1) join keys: the repartitioned joins detect the heavy keys on a sample, keep their probe rows local and
     # broadcast their build rows (exchange.DistributedHashJoinExec); the ranks' probe sides stay within 1.3x of the mean
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_rehearsal.py"), "--sf", "0.1", "--world", "2", "--skew", "1.1"],
