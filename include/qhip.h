@@ -534,27 +534,8 @@ int qhip_sort_execute(qhip_ctx* ctx, const qhip_table* in, const qhip_expr* expr
  * (fetch < 0 = no fetch limit). */
 int qhip_limit_execute(qhip_ctx* ctx, const qhip_table* in, int64_t skip, int64_t fetch, qhip_table** out);
 
-/* ---------------------------------------------------------------- measurement aid (SURVEY §8d "achievable-copy ceiling") */
-/* Reads `bytes` of a scratch HBM buffer with a plain 16-byte-per-lane streaming kernel (non-temporal loads, the fastest
- * variant found on MI355X; `iters` timed launches after one warm-up) and returns the achieved read bandwidth in GB/s: the practical ceiling the filter+aggregate kernel's
- * roofline fraction can be compared with, next to the 8 TB/s data-sheet peak. */
-int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double* gb_per_s);
-
-/* ---------------------------------------------------------------- synthetic TPC-H-shaped inputs */
-/* Counter-based generators (splitmix64, seed 0x515552494F555301) writing Arrow-layout host
- * buffers the caller allocated. Row i of every column depends only on (seed, column, i). */
-int qhip_synth_lineitem(int64_t first_row, int64_t n_rows,
-                        int32_t* l_shipdate, int32_t* l_returnflag_offsets, uint8_t* l_returnflag_data,
-                        int32_t* l_linestatus_offsets, uint8_t* l_linestatus_data,
-                        void* l_quantity /* i128[] */, void* l_extendedprice, void* l_discount, void* l_tax);
-/* Q3 tables: customers first_key.. (c_custkey 1-based; seg_data holds 10*n bytes), orders with ordinal first_k.. (TPC-H's
- * sparse o_orderkey, o_custkey uniform over 1..n_customers), and the 1..7 lineitems of those orders in order. */
-int qhip_synth_customer(int64_t first_key, int64_t n, int64_t* c_custkey, int32_t* seg_offsets, uint8_t* seg_data);
-int qhip_synth_orders(int64_t first_k, int64_t n, int64_t n_customers, int64_t* o_orderkey, int64_t* o_custkey,
-                      int32_t* o_orderdate, int64_t* o_shippriority);
-int64_t qhip_synth_q3_lineitem_count(int64_t first_k, int64_t n_orders);
-int qhip_synth_q3_lineitem(int64_t first_k, int64_t n_orders, int64_t* l_orderkey, int32_t* l_shipdate,
-                           void* l_extendedprice, void* l_discount);
+/* (The synthetic-table generators and the streaming-read yardstick bench.py uses are NOT part of this boundary: include/qhip_bench.h,
+ * built into libqhip_bench.so.) */
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,6 @@ def load_library() -> C.CDLL:
             "qhip_ctx_set_timing": (C.c_int, [vp, i32]),
             "qhip_ctx_allow_deferred_sizes": (C.c_int, [vp, i32]),
             "qhip_ctx_forget_plans": (C.c_int, [vp]),
-            "qhip_measure_stream_read": (C.c_int, [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
             "qhip_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
             "qhip_table_from_arrow": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
             "qhip_table_from_arrow_lazy": (C.c_int, [vp, vp, P(vp), i64, P(vp)]),
@@ -167,11 +166,6 @@ def load_library() -> C.CDLL:
             "qhip_table_keep_columns": (C.c_int, [vp, vp, P(i32), i32, P(vp)]),
             "qhip_table_pack": (C.c_int, [vp, vp, vp, i64]),
             "qhip_table_unpack_concat": (C.c_int, [vp, P(C.c_char_p), P(qhip_dtype), i32, P(i64), P(vp), i32, P(vp)]),
-            "qhip_synth_lineitem": (C.c_int, [i64, i64] + [vp] * 9),
-            "qhip_synth_customer": (C.c_int, [i64, i64, vp, vp, vp]),
-            "qhip_synth_orders": (C.c_int, [i64, i64, i64, vp, vp, vp, vp]),
-            "qhip_synth_q3_lineitem_count": (i64, [i64, i64]),
-            "qhip_synth_q3_lineitem": (C.c_int, [i64, i64, vp, vp, vp, vp]),
             "qhip_jit_compile_to_cache": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
         }
         for name, (res, args) in sigs.items():
@@ -180,6 +174,34 @@ def load_library() -> C.CDLL:
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+BENCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libqhip_bench.so")
+_BENCH_LIB = None
+
+
+def load_bench_library():
+    """libqhip_bench.so (include/qhip_bench.h): the synthetic TPC-H-shaped table generators and the streaming-read yardstick —
+    benchmark support, kept out of the product library"""
+    global _BENCH_LIB
+    if _BENCH_LIB is None:
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise ImportError(f"{BENCH_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(BENCH_LIB_PATH)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        for name, (res, args) in {
+            "qhip_synth_lineitem": (C.c_int, [i64, i64] + [vp] * 9),
+            "qhip_synth_customer": (C.c_int, [i64, i64, vp, vp, vp]),
+            "qhip_synth_orders": (C.c_int, [i64, i64, i64, vp, vp, vp, vp]),
+            "qhip_synth_q3_lineitem_count": (i64, [i64, i64]),
+            "qhip_synth_q3_lineitem": (C.c_int, [i64, i64, vp, vp, vp, vp]),
+            "qhip_bench_stream_read": (C.c_int, [i32, i64, i32, C.POINTER(C.c_double)]),
+        }.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _BENCH_LIB = lib
+    return _BENCH_LIB
 
 
 class Context:
@@ -242,9 +264,13 @@ class Context:
         return _cm()
 
     def measure_stream_read(self, nbytes: int = 1 << 32, iters: int = 5) -> float:
-        """Achieved GB/s of a plain streaming-read kernel over `nbytes` of HBM (the practical bandwidth ceiling)."""
+        """Achieved GB/s of a plain streaming-read kernel over `nbytes` of HBM (the practical bandwidth ceiling): benchmark
+        support, libqhip_bench.so (include/qhip_bench.h), not the product library."""
         out = C.c_double(0.0)
-        self.check(self.lib.qhip_measure_stream_read(self.handle, int(nbytes), int(iters), C.byref(out)))
+        self.synchronize()
+        rc = load_bench_library().qhip_bench_stream_read(int(os.environ.get("QHIP_DEVICE", "0")), int(nbytes), int(iters), C.byref(out))
+        if rc != 0:
+            raise HipError(QHIP_HIP_ERROR, f"qhip_bench_stream_read failed ({rc})")
         return out.value
 
     def device_name(self) -> str:

@@ -457,24 +457,6 @@ int qhip_ctx_last_stats(const qhip_ctx* ctx, qhip_exec_stats* out) {
   return QHIP_OK;
 }
 
-int qhip_measure_stream_read(qhip_ctx* ctx, int64_t bytes, int32_t iters, double* gb_per_s) {
-  if (!ctx || !gb_per_s || bytes < (1 << 20) || iters < 1) return QHIP_INVALID_ARGUMENT;
-  return guarded(ctx, [&] {
-    QHIP_HIP_CHECK(hipSetDevice(ctx->device));
-    DevBuf buf((size_t)bytes), sink(4);
-    QHIP_HIP_CHECK(hipMemsetAsync(buf.ptr, 1, (size_t)bytes, ctx->stream));
-    const unsigned blocks = (unsigned)ctx->num_cus * (unsigned)std::max(1, env_int("QHIP_STREAM_BLOCKS_PER_CU", 8));
-    launch_stream_read(buf.ptr, (uint64_t)bytes, sink.as<uint32_t>(), blocks, ctx->stream);
-    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[2], ctx->stream));
-    for (int k = 0; k < iters; ++k) launch_stream_read(buf.ptr, (uint64_t)bytes, sink.as<uint32_t>(), blocks, ctx->stream);
-    QHIP_HIP_CHECK(hipEventRecord(ctx->ev[3], ctx->stream));
-    QHIP_HIP_CHECK(sync_event(ctx->ev[3]));
-    float ms = 0;
-    QHIP_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-    *gb_per_s = (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
-  });
-}
-
 int qhip_ctx_device_name(const qhip_ctx* ctx, char* buf, size_t buflen) {
   if (!ctx || !buf || !buflen) return QHIP_INVALID_ARGUMENT;
   snprintf(buf, buflen, "%s", ctx->device_name.c_str());

@@ -63,35 +63,6 @@ __global__ __launch_bounds__(QH_BLOCK) void k_compact_slots(const u64* table, u3
   }
 }
 
-// plain streaming read (16 B per lane, grid-stride): the achievable-bandwidth yardstick of bench.py
-template <int U, bool NT>
-__global__ __launch_bounds__(QH_BLOCK) void k_stream_read(const qh_v4u* p, u64 n16, u32* sink) {
-  u32 acc = 0;
-  const u64 stride = (u64)gridDim.x * QH_BLOCK;
-  u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x;
-  for (; i + (U - 1) * stride < n16; i += U * stride) {
-    qh_v4u v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(&p[i + u * stride]) : p[i + u * stride];
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-  }
-  for (; i < n16; i += stride) { const qh_v4u v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
-  if (acc == 0x9e3779b9u) *sink = acc;   // keeps the loads alive; practically never taken
-}
-void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned blocks, hipStream_t s) {
-  const char* uv = getenv("QHIP_STREAM_UNROLL");
-  const char* nv = getenv("QHIP_STREAM_NT");
-  const int U = uv ? atoi(uv) : 1;
-  const bool nt = !(nv && *nv == '0');   // non-temporal loads by default: the fastest plain reader found (tools/stream_sweep.py)
-#define LAUNCH(UU, NN) hipLaunchKernelGGL((k_stream_read<UU, NN>), dim3(blocks), dim3(QH_BLOCK), 0, s, (const qh_v4u*)p, (u64)(bytes / 16), sink)
-  if (U >= 8) { if (nt) LAUNCH(8, true); else LAUNCH(8, false); }
-  else if (U >= 4) { if (nt) LAUNCH(4, true); else LAUNCH(4, false); }
-  else if (U >= 2) { if (nt) LAUNCH(2, true); else LAUNCH(2, false); }
-  else { if (nt) LAUNCH(1, true); else LAUNCH(1, false); }
-#undef LAUNCH
-}
-
 static inline unsigned grid_for(uint64_t n, unsigned cap = 2048) {
   uint64_t g = (n + QH_BLOCK - 1) / QH_BLOCK;
   if (g < 1) g = 1;

@@ -8,7 +8,6 @@ namespace qhip {
 constexpr uint32_t kNullIdx = 0xFFFFFFFFu;   // NULL row index in u32 index vectors (tables hold < 2^32 - 1 rows)
 
 // group table -> dense slot array (kernels.hip)
-void launch_stream_read(const void* p, uint64_t bytes, uint32_t* sink, unsigned blocks, hipStream_t s);
 void launch_compact_slots(const uint64_t* table, uint32_t nslots, int slot_words, uint64_t* out, uint32_t* counter,
                           uint32_t out_capacity, hipStream_t s, uint64_t* out_host = nullptr, uint32_t cap_host = 0);   // out_host: page-locked host memory for the first cap_host slots
 

@@ -4,7 +4,9 @@
 #include <cstdint>
 #include <cstring>
 
-#include "../../include/qhip.h"
+#include "../../include/qhip_bench.h"
+
+enum { QHIP_OK = 0, QHIP_INVALID_ARGUMENT = 1 };   // (the values of include/qhip.h; this library does not depend on it)
 
 namespace {
 constexpr uint64_t kSeed = 0x515552494F555301ULL;   // "QURIOUS\x01"

@@ -24,6 +24,14 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "qurious_amd", "libqhip.so"))
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, f"declared in include/qhip.h but not exported by libqhip.so: {missing}"
+    # benchmark support lives in a library of its own: include/qhip_bench.h <-> libqhip_bench.so, and the
+    # product library neither declares nor exports the generators
+    bench_header = open(os.path.join(ROOT, "include", "qhip_bench.h")).read()
+    bench_names = set(re.findall(r"^(?:int64_t|int)\s+(qhip_[a-z0-9_]+)\s*\(", bench_header, re.M))
+    assert len(bench_names) >= 6 and not (bench_names & names)
+    bench = ctypes.CDLL(os.path.join(ROOT, "qurious_amd", "libqhip_bench.so"))
+    assert not [n for n in sorted(bench_names) if not hasattr(bench, n)]
+    assert not [n for n in sorted(bench_names) if hasattr(lib, n)], "the product library exports benchmark generators"
 
 
 def test_no_cpu_fallback_without_device():

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../include/qhip_plan.hpp"
+#include "../include/qhip_bench.h"   // the synthetic tables (benchmark support: libqhip_bench.so)
 
 using namespace qurious_hip;
 
