@@ -406,9 +406,10 @@ class Q3:
                 # the small build sides are all-gathered, the big probe sides stay where they are, partial groups are merged
                 p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, agg_cls=ex.DistributedHashAggregate)
             elif USE_DIST and strategy == "range":
-                # join 1 broadcasts the customer keys and leaves the orders in place; join 2 routes BOTH its sides by the ranks'
-                # order-key ranges (QHIP_EXCHANGE_RANGE): tables sliced in key order exchange their border rows only
-                p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, join2_cls=ex.DistributedHashJoinExec)
+                # join 1 broadcasts the customer keys and leaves the orders in place; join 2 leaves BOTH big tables in place and sends
+                # a build row only to the ranks whose lineitem keys can reach it (RangeBroadcastHashJoinExec, QHIP_EXCHANGE_RANGE,
+                # DESIGN §7): tables sliced in key order exchange the orders at their slice borders; partial groups are merged
+                p = queries.q3(*self.tabs, join_cls=ex.BroadcastHashJoinExec, join2_cls=ex.RangeBroadcastHashJoinExec, agg_cls=ex.DistributedHashAggregate)
             else:
                 p = queries.q3(*self.tabs, join_cls=ex.DistributedHashJoinExec if USE_DIST else None)
             if USE_DIST:
@@ -665,7 +666,7 @@ def main():
     ap.add_argument("--sf", type=float, default=10.0, help="TPC-H scale factor of Q3 (whole job, sliced over the ranks)")
     ap.add_argument("--strategy", default="broadcast", choices=["broadcast", "repartition", "range"],
                     help="Q3 on several GPUs: all-gather the small build sides (default), repartition both sides of every join by key hash, "
-                         "or broadcast join 1's build side and route join 2 by the ranks' key ranges")
+                         "or broadcast join 1's build side and send join 2's build rows only where the ranks' probe key ranges can reach them")
     ap.add_argument("--skew", type=float, default=0.0, help="Q3: re-draw the join keys from Zipf(s) (configs[4] uses 1.1); 0 = uniform")
     ap.add_argument("--slice", default="", help="Q3 on ONE GPU over rank R's 1/N slice of every table, as R/N (configs[4]: --sf 100 --skew 1.1 --slice 0/8)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16 << 20, help="rows of a q1_* workload timed through the CPU oracle (per run)")

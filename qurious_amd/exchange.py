@@ -132,7 +132,7 @@ def _comm_stats_into(reset: bool):
 
 # bytes this rank handed to the transport and wall time spent inside the exchanges (BASELINE configs[3]/[4]: xGMI GB/s)
 _STATS = {"bytes_sent": 0, "bytes_received": 0, "bytes_packed": 0, "seconds": 0.0, "exchanges": 0, "heavy_keys": 0, "probe_rows_received": 0,
-          "transport_waits": 0, "heavy_key_rounds": 0, "range_rounds": 0}
+          "transport_waits": 0, "heavy_key_rounds": 0, "range_rounds": 0, "build_rows_received": 0}
 
 
 def exchange_stats(reset: bool = True) -> dict:
@@ -142,7 +142,7 @@ def exchange_stats(reset: bool = True) -> dict:
     out["send_GBps"] = out["bytes_sent"] / out["seconds"] / 1e9 if out["seconds"] > 0 else None
     if reset:
         _STATS.update(bytes_sent=0, bytes_received=0, bytes_packed=0, seconds=0.0, exchanges=0, heavy_keys=0, probe_rows_received=0,
-                      transport_waits=0, heavy_key_rounds=0, range_rounds=0)
+                      transport_waits=0, heavy_key_rounds=0, range_rounds=0, build_rows_received=0)
     return out
 
 
@@ -978,6 +978,91 @@ class BroadcastHashJoinExec(HashJoinExec):
     def try_new(left, right, join_type, on, filter=None) -> "BroadcastHashJoinExec":
         base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
         return BroadcastHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)
+
+
+class RangeBroadcastHashJoinExec(BroadcastHashJoinExec):
+    """BroadcastHashJoinExec that sends a build row only to the ranks whose PROBE keys can match it (round 4, DESIGN §7 "routing
+    by key range"; QHIP_EXCHANGE_RANGE=1, else exactly BroadcastHashJoinExec). Every rank all-gathers the [min, max] of its probe
+    side's key column (a statistic of the resident table); a rank then receives the build rows whose key lies in ITS probe range —
+    which is all an Inner / Right join of its probe rows can ever match, whatever the ranges are — and joins them, together with
+    its own build rows, with its probe side IN PLACE (fused scan filter, nothing of the big side is copied or moved). With tables
+    sliced in key order (TPC-H's orders and lineitem) a rank's probe range is its neighbours' border at most: the exchange carries
+    a few rows and every rank does 1/n of the single-GPU work. When the probe ranges overlap widely (unordered keys) every rank
+    would ask for nearly everything: plain broadcast then. The ranges are gathered at EVERY execution (a stale range would lose
+    matches, and a refresh must be collective)."""
+
+    def _probe_ranges(self, world):
+        if os.environ.get("QHIP_EXCHANGE_RANGE", "0") != "1" or len(self.on) != 1 or world < 2 or not _is_table_access(self.right):
+            return None
+        import pyarrow as pa
+        import torch
+        from .expr import Column
+        lkey, rkey = self.on[0]
+        if not (isinstance(lkey, Column) and isinstance(rkey, Column)):
+            return None
+        lt_, rt_ = _expr_type(lkey, self.left.schema()), _expr_type(rkey, self.right.schema())
+        ok = lambda t: t is not None and (pa.types.is_int64(t) or pa.types.is_int32(t) or pa.types.is_date32(t))   # noqa: E731
+        if not (ok(lt_) and ok(rt_)):
+            return None
+        E = _engine()
+        dist = _dist()
+        plo, phi = E.key_range(E.base_table(self.right), rkey.index)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        if dev.type == "cuda" and "h" in _COMM:
+            _COMM["ctx"].synchronize()   # (two RCCL communicators never active at once: see heavy_keys)
+        mine = torch.tensor([int(plo), int(phi)], dtype=torch.int64, device=dev)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        ranges = [tuple(t.cpu().tolist()) for t in everyone]
+        _STATS["range_rounds"] = _STATS.get("range_rounds", 0) + 1
+        live = [r for r in ranges if r[0] <= r[1]]
+        if not live:
+            return ranges
+        span = max(r[1] for r in live) - min(r[0] for r in live) + 1
+        if sum(r[1] - r[0] + 1 for r in live) > 1.5 * span:      # the ranks' probe keys interleave: everybody would ask for everything
+            return None
+        return ranges
+
+    def _gather_build(self) -> DeviceTable:
+        world = _exchange_world(_dist())
+        ranges = self._probe_ranges(world) if self.join_type in (JoinType.Inner, JoinType.Right) else None
+        if ranges is None:
+            return BroadcastHashJoinExec._gather_build(self)
+        from .datatypes import Operator
+        from .expr import BinaryExpr
+        E = _engine()
+        ctx = E.context()
+        ls = self.left.schema()
+        lneed, _ = self._needed_per_side()
+        lkey = self.on[0][0]
+        dtype = _expr_type(lkey, ls)
+        me = _dist().get_rank()
+
+        def in_range(lo, hi):
+            return BinaryExpr(BinaryExpr(lkey, Operator.GtEq, _key_literal(lo, dtype)), Operator.And, BinaryExpr(lkey, Operator.LtEq, _key_literal(hi, dtype)))
+
+        def run():
+            build = E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed))
+            # the few local build rows another rank's probe keys can reach, in ONE pass; then split per destination
+            wanted = None
+            for r, (lo, hi) in enumerate(ranges):
+                if r != me and lo <= hi:
+                    term = in_range(lo, hi)
+                    wanted = term if wanted is None else BinaryExpr(wanted, Operator.Or, term)
+            foreign = E.filter(build, wanted if wanted is not None else in_range(1, 0))
+            parts = [E.filter(foreign, in_range(*ranges[r]) if (r != me and ranges[r][0] <= ranges[r][1]) else in_range(1, 0)) for r in range(world)]
+            received = exchange_device_tables(parts, _wire_schema(ls, lneed))
+            _STATS["build_rows_received"] = _STATS.get("build_rows_received", 0) + E.num_rows(received)
+            return E.concat([build, received])
+        if not hasattr(ctx, "no_deferred_sizes"):
+            return run()
+        with ctx.no_deferred_sizes():
+            return run()
+
+    @staticmethod
+    def try_new(left, right, join_type, on, filter=None) -> "RangeBroadcastHashJoinExec":
+        base = HashJoinExec.try_new(left, right, JoinType(join_type), on, filter)
+        return RangeBroadcastHashJoinExec(base.left, base.right, base.join_type, base.on, base.filter, base._schema, base.column_indices)
 
 
 def merge_aggregate_exprs(aggregate_exprs, n_groups: int):

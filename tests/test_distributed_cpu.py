@@ -539,10 +539,27 @@ def _worker_range(rank, world, port, out_dir):
         plan = exchange.DistributedHashJoinExec.try_new(table_scan(os_, [cut(ob)]), table_scan(ls_, [cut(lb3)]), JoinType.Inner, on)
         results["random-probe"] = rows_of([engine.execute(plan)])
         assert engine.log["range_partitions"] == 6                                     # hash again
+        # (4) RangeBroadcastHashJoinExec: the probe side never moves; a rank receives the build rows inside ITS probe key range —
+        # key-ordered slices: the orders at the slice border only; shuffled slices: the ranges cover each other -> plain broadcast
+        exchange.exchange_stats(reset=True)
+        for jt in (JoinType.Inner, JoinType.Right):
+            plan = exchange.RangeBroadcastHashJoinExec.try_new(table_scan(os_, [cut(ob)]), table_scan(ls_, [cut(lb)]), jt, on)
+            results["rb-" + jt.name] = rows_of([engine.execute(plan)])
+        st = exchange.exchange_stats(reset=True)
+        assert st["range_rounds"] == 2 and st["build_rows_received"] <= 100, st      # (the orders around the slice border: the two tables are cut by row counts)
+        plan = exchange.RangeBroadcastHashJoinExec.try_new(table_scan(os_, [cut(ob2)]), table_scan(ls_, [cut(lb2)]), JoinType.Inner, on)
+        results["rb-shuffled"] = rows_of([engine.execute(plan)])
+        st = exchange.exchange_stats(reset=True)
+        assert st["build_rows_received"] == 0 and st["bytes_sent"] > 10_000          # the whole build side was all-gathered instead
         gathered = [None] * world
         dist.all_gather_object(gathered, (results, moved_sorted, moved_hashed))
         if rank == 0:
             union = lambda name: sorted((r for g in gathered for r in g[0][name]), key=repr)   # noqa: E731
+            for jt in (JoinType.Inner, JoinType.Right):
+                full = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb]), jt, on)
+                assert union("rb-" + jt.name) == sorted(rows_of(qoracle.execute(full)), key=repr), jt
+            full = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb]), JoinType.Inner, on)
+            assert union("rb-shuffled") == sorted(rows_of(qoracle.execute(full)), key=repr)
             for jt in (JoinType.Inner, JoinType.Left, JoinType.Full):
                 full = q.HashJoinExec.try_new(table_scan(os_, [ob]), table_scan(ls_, [lb]), jt, on)
                 assert union("sorted-" + jt.name) == sorted(rows_of(qoracle.execute(full)), key=repr), jt

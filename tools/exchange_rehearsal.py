@@ -51,11 +51,13 @@ def two_rank_worker(rank, world, port, sf, out_dir, skew=0.0):
                 q.MemoryTable.try_new(synth.LINEITEM_Q3_SCHEMA, l))
         results = {}
         # "range" (round 4, DESIGN §7 "routing by key range"): join 1 broadcasts the customer keys and leaves the orders where they
-        # are, so that join 2's build side keeps its order-key range and BOTH its sides are routed by the ranks' key ranges —
-        # tables sliced in key order exchange only the rows at the slice borders (and groups stay disjoint: no aggregate exchange)
+        # are; join 2 leaves orders AND lineitem where they are and sends a build row only to the ranks whose lineitem keys can
+        # reach it (RangeBroadcastHashJoinExec) — tables sliced in key order exchange the orders at the slice borders; the partial
+        # groups of an order whose lineitems straddle a border are merged (DistributedHashAggregate)
         for name, plan in (("repartition", queries.q3(*mine, join_cls=exchange.DistributedHashJoinExec)),
                            ("broadcast", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, agg_cls=exchange.DistributedHashAggregate)),
-                           ("range", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, join2_cls=exchange.DistributedHashJoinExec))):
+                           ("range", queries.q3(*mine, join_cls=exchange.BroadcastHashJoinExec, join2_cls=exchange.RangeBroadcastHashJoinExec,
+                                                agg_cls=exchange.DistributedHashAggregate))):
             exchange.prune_exchange_columns(plan)
             exchange.exchange_stats()
             if name == "range":
