@@ -987,8 +987,10 @@ class RangeBroadcastHashJoinExec(BroadcastHashJoinExec):
     which is all an Inner / Right join of its probe rows can ever match, whatever the ranges are — and joins them, together with
     its own build rows, with its probe side IN PLACE (fused scan filter, nothing of the big side is copied or moved). With tables
     sliced in key order (TPC-H's orders and lineitem) a rank's probe range is its neighbours' border at most: the exchange carries
-    a few rows and every rank does 1/n of the single-GPU work. When the probe ranges overlap widely (unordered keys) every rank
-    would ask for nearly everything: plain broadcast then. The ranges are gathered at EVERY execution (a stale range would lose
+    a few rows and every rank does 1/n of the single-GPU work: ONE range partition of the small side (a row goes to the rank whose
+    probe range ends at or above its key), the keys at which two neighbours' ranges overlap sent to the next rank as well, one
+    all-to-all. When the ranks' probe ranges do not ascend with the rank or reach beyond their direct neighbours (unordered keys):
+    plain broadcast. The ranges are gathered at EVERY execution (a stale range would lose
     matches, and a refresh must be collective)."""
 
     def _probe_ranges(self, world):
@@ -1016,12 +1018,15 @@ class RangeBroadcastHashJoinExec(BroadcastHashJoinExec):
         ranges = [tuple(t.cpu().tolist()) for t in everyone]
         _STATS["range_rounds"] = _STATS.get("range_rounds", 0) + 1
         live = [r for r in ranges if r[0] <= r[1]]
-        if not live:
-            return ranges
-        span = max(r[1] for r in live) - min(r[0] for r in live) + 1
-        if sum(r[1] - r[0] + 1 for r in live) > 1.5 * span:      # the ranks' probe keys interleave: everybody would ask for everything
-            return None
-        return ranges
+        if len(live) < world:
+            return None        # (a rank without probe rows: nothing to gain, the plain broadcast covers it)
+        # the ranks' probe ranges ascend with the rank and reach at most into their direct neighbour's (tables sliced in key order)
+        ascending = all(ranges[r][0] <= ranges[r + 1][0] and ranges[r][1] <= ranges[r + 1][1] for r in range(world - 1))
+        shallow = all(ranges[r + 2][0] > ranges[r][1] for r in range(world - 2))
+        # ... and overlap in a small part of the key space only (what overlaps is sent twice)
+        span = ranges[-1][1] - ranges[0][0] + 1
+        overlap = sum(max(0, ranges[r][1] - ranges[r + 1][0] + 1) for r in range(world - 1))
+        return ranges if (ascending and shallow and overlap * 10 <= span) else None
 
     def _gather_build(self) -> DeviceTable:
         world = _exchange_world(_dist())
@@ -1036,24 +1041,26 @@ class RangeBroadcastHashJoinExec(BroadcastHashJoinExec):
         lneed, _ = self._needed_per_side()
         lkey = self.on[0][0]
         dtype = _expr_type(lkey, ls)
-        me = _dist().get_rank()
-
-        def in_range(lo, hi):
-            return BinaryExpr(BinaryExpr(lkey, Operator.GtEq, _key_literal(lo, dtype)), Operator.And, BinaryExpr(lkey, Operator.LtEq, _key_literal(hi, dtype)))
+        uppers = [r[1] for r in ranges[:-1]]          # part r = the keys in (max of rank r - 1, max of rank r]; the last part the rest
 
         def run():
             build = E.keep_columns(E.execute(self.left), _keep_mask(len(ls), lneed))
-            # the few local build rows another rank's probe keys can reach, in ONE pass; then split per destination
-            wanted = None
-            for r, (lo, hi) in enumerate(ranges):
-                if r != me and lo <= hi:
-                    term = in_range(lo, hi)
-                    wanted = term if wanted is None else BinaryExpr(wanted, Operator.Or, term)
-            foreign = E.filter(build, wanted if wanted is not None else in_range(1, 0))
-            parts = [E.filter(foreign, in_range(*ranges[r]) if (r != me and ranges[r][0] <= ranges[r][1]) else in_range(1, 0)) for r in range(world)]
-            received = exchange_device_tables(parts, _wire_schema(ls, lneed))
-            _STATS["build_rows_received"] = _STATS.get("build_rows_received", 0) + E.num_rows(received)
-            return E.concat([build, received])
+            # ONE range partition of the (small) build side: a row goes to the rank whose probe range ends at or above its key ...
+            parts = E.partition(build, [lkey], world, uppers)
+            # ... and a key at which two neighbours' probe ranges OVERLAP (an order whose lineitems straddle the slice border) to
+            # the next rank as well: those few rows are found by one Filter and split by the same bounds
+            overlap = None
+            for r in range(world - 1):
+                lo, hi = ranges[r + 1][0], ranges[r][1]
+                if lo <= hi:
+                    term = BinaryExpr(BinaryExpr(lkey, Operator.GtEq, _key_literal(lo, dtype)), Operator.And, BinaryExpr(lkey, Operator.LtEq, _key_literal(hi, dtype)))
+                    overlap = term if overlap is None else BinaryExpr(overlap, Operator.Or, term)
+            if overlap is not None:
+                again = E.partition(E.filter(build, overlap), [lkey], world, uppers)
+                parts = [parts[d] if d == 0 else E.concat([parts[d], again[d - 1]]) for d in range(world)]
+            got = exchange_device_tables(parts, _wire_schema(ls, lneed))
+            _STATS["build_rows_received"] = _STATS.get("build_rows_received", 0) + E.num_rows(got) - E.num_rows(parts[_dist().get_rank()])
+            return got
         if not hasattr(ctx, "no_deferred_sizes"):
             return run()
         with ctx.no_deferred_sizes():
