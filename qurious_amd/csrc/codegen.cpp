@@ -461,6 +461,14 @@ void ExprGen::emit(int k, std::string& out) {
     }
     case QHIP_EXPR_LIKE: {
       emit(n.left, out);
+      if (n.right >= 0 && es_.at(n.right).kind == QHIP_EXPR_COLUMN) {
+        // a pattern per row (like.rs:28-43 -> arrow `like` over two arrays)
+        emit(n.right, out);
+        if (n.nullable) o << "    const bool " << nn << " = " << ok(n.left) << " && " << ok(n.right) << ";\n";
+        o << "    const bool " << v << " = " << (n.nullable ? nn + " && " : std::string("")) << (n.op ? "!" : "") << "qh_like_raw(" << ptr(n.left) << ", "
+          << len(n.left) << ", " << ptr(n.right) << ", " << len(n.right) << ");\n";
+        break;
+      }
       if (n.lit_null) {
         o << "    const bool " << v << " = false;\n    const bool " << nn << " = false;\n";
         break;

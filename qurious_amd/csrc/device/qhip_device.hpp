@@ -118,6 +118,27 @@ __device__ __forceinline__ int qh_next_char(const u8* s, int i, int n) {
   while (i < n && (s[i] & 0xC0) == 0x80) ++i;
   return i;
 }
+// ... with the pattern as it stands in a COLUMN (round 4: like.rs:28-43 evaluates the pattern per row — arrow's `like` over two
+// arrays): % and _ are wildcards, a backslash makes the next byte stand for itself (a trailing one is a plain backslash).
+__device__ __forceinline__ bool qh_like_raw(const u8* s, int n, const u8* pat, int m) {
+  int i = 0, p = 0, star = -1, mark = 0;
+  while (i < n) {
+    bool adv = false;
+    if (p < m) {
+      const u8 c = pat[p];
+      if (c == (u8)'%') { star = p; mark = i; ++p; adv = true; }
+      else if (c == (u8)'_') { i = qh_next_char(s, i, n); ++p; adv = true; }
+      else if (c == (u8)'\\' && p + 1 < m) { if (pat[p + 1] == s[i]) { ++i; p += 2; adv = true; } }
+      else if (c == s[i]) { ++i; ++p; adv = true; }
+    }
+    if (!adv) {
+      if (star < 0) return false;
+      p = star + 1; mark = qh_next_char(s, mark, n); i = mark;
+    }
+  }
+  while (p < m && pat[p] == (u8)'%') ++p;
+  return p == m;
+}
 __device__ __forceinline__ bool qh_like(const u8* s, int n, const u8* pat, int m) {
   int i = 0, p = 0, star = -1, mark = 0;
   while (i < n) {

@@ -312,7 +312,14 @@ void ExprSet::build(const qhip_expr* ex, int n, const std::vector<InputCol>& inp
         const ENode &x = nodes[(size_t)e.left], &pat = nodes[(size_t)e.right];
         if (x.type.id != QHIP_UTF8 || pat.type.id != QHIP_UTF8)
           fail(QHIP_INVALID_ARGUMENT, "Invalid argument error: Invalid string operation: " + dtype_name(x.type) + " LIKE " + dtype_name(pat.type));
-        if (pat.kind != QHIP_EXPR_LITERAL) fail(QHIP_UNSUPPORTED, "LIKE with a non-literal pattern is not accelerated");
+        if (pat.kind != QHIP_EXPR_LITERAL) {
+          // the pattern is a column (or any Utf8 expression the generator can address): matched per row, raw (qh_like_raw)
+          if (pat.kind != QHIP_EXPR_COLUMN) fail(QHIP_UNSUPPORTED, "LIKE with a computed pattern is not accelerated");
+          nd.type = DType(QHIP_BOOL); nd.nullable = x.nullable || pat.nullable; nd.lit_null = false;
+          nd.s.clear();
+          nd.canon = std::string(e.op ? "nlike(" : "like(") + x.canon + "," + pat.canon + ")";
+          break;
+        }
         nd.type = DType(QHIP_BOOL); nd.nullable = x.nullable || pat.lit_null; nd.lit_null = pat.lit_null;
         nd.s = canonical_like_pattern(pat.s);
         nd.canon = std::string(e.op ? "nlike(" : "like(") + x.canon + "," + pat.canon + ")";

@@ -312,8 +312,9 @@ impl ExprArray {
                 Ok(acc)
             }
             LogicalExpr::Like(like) => {
-                if !matches!(like.pattern.as_ref(), LogicalExpr::Literal(ScalarValue::Utf8(Some(_)))) {
-                    return unsupported("LIKE with a non-literal pattern");
+                // a literal pattern or a pattern COLUMN (matched per row, like.rs:28-43); a computed pattern stays with the CPU node
+                if !matches!(like.pattern.as_ref(), LogicalExpr::Literal(ScalarValue::Utf8(Some(_))) | LogicalExpr::Column(_)) {
+                    return unsupported("LIKE with a computed pattern");
                 }
                 let value = self.lower(&like.expr, schema)?;
                 let pattern = self.lower(&like.pattern, schema)?;
