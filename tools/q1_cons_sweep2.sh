@@ -1,4 +1,5 @@
 #!/bin/bash
+# (second Q1 sweep of round 4: the two-register-set loop without consecutive rows, and q1_mini; profiles/r04_q1_consecutive_rows.txt)
 OUT=$1
 run() {
   WL=$1; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the third Q1 sweep of round 4: QHIP_AGG_STEADY — a steady-state tile loop — existed for this sweep only; profiles/r04_q1_consecutive_rows.txt)
 OUT=$1
 run() {
   WL=$1; shift
