@@ -1202,24 +1202,34 @@ void plan_projection(const ExprSet& es, const std::vector<InputCol>& input, cons
     g.emit(od.root, code);
     body << code;
     const std::string okx = g.ok(od.root);
-    if (nd.type.id == QHIP_UTF8 || nd.type.id == QHIP_NULL)
+    if (nd.type.id == QHIP_NULL)
       fail(QHIP_UNSUPPORTED, "projection of a computed " + dtype_name(nd.type) + " expression is not accelerated");
-    if (nd.type.id == QHIP_BOOL) {
-      body << "    { const u64 m = qh_ballot(inb && " << (od.nullable ? okx + " && " : std::string("")) << g.val(od.root) << "); if (lane == 0) ((u64*)o.v[" << k
+    if (nd.type.id == QHIP_UTF8) {
+      // a computed string (CASE over literals / columns, a literal): pass 0 stores its length, the host scans the lengths into
+      // offsets, pass 1 copies the bytes (both passes evaluate the same generated code)
+      out.has_utf8 = true;
+      const std::string lenx = std::string(od.nullable ? "(" + okx + " ? " : "(") + g.len(od.root) + (od.nullable ? " : 0)" : ")");
+      body << "    if (MODE == 0 && inb) ((int*)o.v[" << k << "])[row] = " << lenx << ";\n";
+      body << "    if (MODE == 1 && inb" << (od.nullable ? " && " + okx : std::string("")) << ") { u8* dst = o.d[" << k << "] + ((const int*)o.v[" << k
+           << "])[row]; const u8* src = " << g.ptr(od.root) << "; const int nb = " << g.len(od.root) << "; for (int b = 0; b < nb; ++b) dst[b] = src[b]; }\n";
+    } else if (nd.type.id == QHIP_BOOL) {
+      body << "    if (MODE == 0) { const u64 m = qh_ballot(inb && " << (od.nullable ? okx + " && " : std::string("")) << g.val(od.root) << "); if (lane == 0) ((u64*)o.v[" << k
            << "])[j] = m; }\n";
     } else {
       const std::string T = ExprGen::ctype(nd.type);
-      body << "    if (inb) ((" << T << "*)o.v[" << k << "])[row] = " << (od.nullable ? okx + " ? " : std::string("")) << g.val(od.root)
+      body << "    if (MODE == 0 && inb) ((" << T << "*)o.v[" << k << "])[row] = " << (od.nullable ? okx + " ? " : std::string("")) << g.val(od.root)
            << (od.nullable ? " : (" + T + ")0" : std::string("")) << ";\n";
     }
-    if (od.nullable) body << "    { const u64 m = qh_ballot(inb && " << okx << "); if (lane == 0) o.n[" << k << "][j] = m; }\n";
+    if (od.nullable) body << "    if (MODE == 0) { const u64 m = qh_ballot(inb && " << okx << "); if (lane == 0) o.n[" << k << "][j] = m; }\n";
     out.outs.push_back(od);
   }
   std::ostringstream s;
   s << "struct P {\n";
-  s << "  __device__ static __forceinline__ void row(const KArgs& a, const ProjOut& o, const i64 i, const i64 row, const bool inb, const i64 j, "
+  s << "  template <int MODE> __device__ static __forceinline__ void row(const KArgs& a, const ProjOut& o, const i64 i, const i64 row, const bool inb, const i64 j, "
        "const int lane, u32& err) {\n" << body.str() << "  }\n};\n";
-  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_project(KArgs a, ProjOut o, u32* status) { qh_project_body<P>(a, o, status); }\n";
+  s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_project(KArgs a, ProjOut o, u32* status) { qh_project_body<P, 0>(a, o, status); }\n";
+  if (out.has_utf8)
+    s << "extern \"C\" __global__ __launch_bounds__(QH_BLOCK) void qk_project_copy(KArgs a, ProjOut o, u32* status) { qh_project_body<P, 1>(a, o, status); }\n";
   out.source = s.str();
   out.kernel_name = "qk_project";
   out.bind = g.bind;

@@ -141,6 +141,7 @@ void plan_part_scatter(const std::vector<int>& widths, const std::vector<char>& 
 // ---------------------------------------------------------------- projection (physical/plan/projection.rs:27-46)
 struct ProjOutDesc { int root; DType type; bool nullable; };
 struct ProjectionPlan {
+  bool has_utf8 = false;             // some output is a computed Utf8 value: the source also has qk_project_copy (the second pass)
   std::vector<ProjOutDesc> outs;     // the computed outputs, in kernel slot order
   KernelBindings bind; std::string source; std::string kernel_name;
 };

@@ -2424,12 +2424,16 @@ __device__ __forceinline__ void qh_sort_keys_body(const KArgs& a, u64* img, u64*
 
 // ------------------------------------------------------------------ expressions -> output columns (physical/plan/projection.rs:27-46)
 struct ProjOut {
-  void* v[QH_MAXC];   // per computed expression: values (fixed width) or value bits (Boolean), Arrow layout
+  void* v[QH_MAXC];   // per computed expression: values (fixed width), value bits (Boolean) or — Utf8 — int32 lengths, then offsets
   u64* n[QH_MAXC];    // validity words of the nullable ones
+  u8* d[QH_MAXC];     // Utf8 outputs (round 4): the data bytes, written by the second pass at the scanned offsets
 };
 // P::row evaluates every expression for row `i` (clamped to the table for the lanes beyond its end, `inb` false there)
 // and stores values at `row`, bit-packed outputs at word `j` through wavefront ballots.
-template <class P>
+// MODE 0: every output's values / bits / validity, and the LENGTH of a computed Utf8 value; MODE 1 (only when there is a Utf8
+// output, after the lengths have been scanned into offsets): the expressions once more, the bytes copied to their offsets —
+// a CASE over string literals or columns (the reference's type.slt:51: case x when 1 then 'a' else 'b' end).
+template <class P, int MODE = 0>
 __device__ __forceinline__ void qh_project_body(const KArgs& a, const ProjOut& o, u32* status) {
   const i64 nwords = (a.nrows + 63) / 64;
   const i64 wave_global = ((i64)blockIdx.x * QH_BLOCK + threadIdx.x) >> 6;
@@ -2440,8 +2444,8 @@ __device__ __forceinline__ void qh_project_body(const KArgs& a, const ProjOut& o
     const i64 row = j * 64 + lane;
     const bool inb = row < a.nrows;
     u32 e = 0;
-    P::row(a, o, inb ? row : a.nrows - 1, row, inb, j, lane, e);
+    P::template row<MODE>(a, o, inb ? row : a.nrows - 1, row, inb, j, lane, e);
     err |= inb ? e : 0u;
   }
-  qh_report(status, err);
+  if (MODE == 0) qh_report(status, err);
 }

@@ -73,8 +73,9 @@ static_assert(sizeof(HRunsLaunch) == 48, "RunsLaunch layout");
 struct HProjOut {
   void* v[kMaxCols];
   uint64_t* n[kMaxCols];
+  uint8_t* d[kMaxCols];
 };
-static_assert(sizeof(HProjOut) == 2 * 8 * 24, "ProjOut layout");
+static_assert(sizeof(HProjOut) == 3 * 8 * 24, "ProjOut layout");
 
 struct HProbeLaunch {
   const uint64_t* table;

@@ -75,7 +75,13 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
       col.type = plan.outs[c].type;
       col.length = N;
       const int w = dtype_width(col.type);
-      col.values = std::make_shared<DevBuf>(w > 0 ? (size_t)N * w : (size_t)nwords * 8 + 8);
+      // (a computed Utf8 output: N + 1 int32 words — the kernel's first pass leaves the lengths, the scan makes them offsets)
+      col.values = std::make_shared<DevBuf>(col.type.id == QHIP_UTF8 ? ((size_t)N + 1) * 4 : w > 0 ? (size_t)N * w : (size_t)nwords * 8 + 8);
+      if (col.type.id == QHIP_UTF8 && N == 0) {   // no rows: one zero offset and an (empty) data buffer, like an uploaded empty column
+        QHIP_HIP_CHECK(hipMemsetAsync(col.values->ptr, 0, 4, s));
+        col.data = std::make_shared<DevBuf>(1);
+        col.data_bytes = 0;
+      }
       po.v[c] = col.values->ptr;
       if (plan.outs[c].nullable) {
         col.validity = std::make_shared<DevBuf>((size_t)nwords * 8 + 8);
@@ -102,9 +108,30 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
         launch_count_bits(po.n[c], (uint64_t)N, counters[c].as<uint32_t>(), s);
         QHIP_HIP_CHECK(hipMemcpyAsync(&set_bits[c], counters[c].ptr, 4, hipMemcpyDeviceToHost, s));
       }
+      // computed Utf8 outputs: lengths -> offsets (+ the byte total behind the last offset), read back with the status words
+      std::vector<uint32_t> utf8_bytes(plan.outs.size(), 0);
+      for (size_t c = 0; c < plan.outs.size(); ++c) {
+        if (plan.outs[c].type.id != QHIP_UTF8) continue;
+        uint32_t* len = out->cols[(size_t)cslot[c]].values->as<uint32_t>();
+        exclusive_scan_u32(len, len, (uint64_t)N, len + N, s);
+        QHIP_HIP_CHECK(hipMemcpyAsync(&utf8_bytes[c], len + N, 4, hipMemcpyDeviceToHost, s));
+      }
       uint32_t st[QS_WORDS];
       copy_sync(s, st, ctx->status.ptr, sizeof st, hipMemcpyDeviceToHost);
       check_status_words(st);
+      if (plan.has_utf8) {
+        // second pass: the same expressions once more, the bytes copied to their offsets
+        for (size_t c = 0; c < plan.outs.size(); ++c) {
+          if (plan.outs[c].type.id != QHIP_UTF8) continue;
+          DevColumn& col = out->cols[(size_t)cslot[c]];
+          col.data = std::make_shared<DevBuf>(std::max<size_t>(utf8_bytes[c], 1));
+          col.data_bytes = (int64_t)utf8_bytes[c];
+          po.d[c] = col.data->as<uint8_t>();
+        }
+        std::shared_ptr<Module> cmod = get_module(ctx, plan.source, "qk_project_copy");
+        QHIP_HIP_CHECK(hipModuleLaunchKernel(cmod->fn, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        QHIP_HIP_CHECK(sync_stream(s));   // (`po` and the literals' buffer live on this frame)
+      }
       for (size_t c = 0; c < plan.outs.size(); ++c) {
         DevColumn& col = out->cols[(size_t)cslot[c]];
         if (!plan.outs[c].nullable) continue;

@@ -550,8 +550,13 @@ void table_batch_to_arrow(Ctx* ctx, const qhip_table* t, int64_t b, ArrowArray* 
       land_staged();
       const int32_t base = off[0];
       const int64_t nbytes = (int64_t)off[n] - base;
+      // (offsets that run backwards or past the data buffer would turn the copy below into a wild one)
+      if (base < 0 || nbytes < 0 || (nbytes > 0 && (!col.data || (size_t)base + (size_t)nbytes > col.data->bytes))) {
+        if (ocls >= 0) export_pool().give(off, ocls); else free(off);
+        fail(QHIP_INVALID_ARGUMENT, "Utf8 column with offsets outside its data buffer");
+      }
       uint8_t* data = (uint8_t*)big_alloc((size_t)nbytes, dcls);
-      d2h(data, (const uint8_t*)col.data->ptr + base, (size_t)nbytes, ctx->stream);
+      if (nbytes) d2h(data, (const uint8_t*)col.data->ptr + base, (size_t)nbytes, ctx->stream);
       if (base) offfix.push_back({off, n + 1});
       p->push(off, ocls);
       p->push(data, dcls);

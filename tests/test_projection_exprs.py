@@ -188,6 +188,55 @@ def test_gpu_like_with_a_pattern_column_vs_oracle():
         q.Filter(scan, computed).execute()
 
 
+def _string_cases():
+    """CASE expressions that PRODUCE strings: literals, columns, NULL branches, nesting"""
+    day = q.CastExpr(q.Literal(S.Int32(9050)), pa.date32())
+    lit = lambda v: q.Literal(S.Utf8(v))   # noqa: E731
+    c1 = q.CaseExpr([(q.BinaryExpr(col("i", 0), Operator.Eq, q.Literal(S.Int64(1))), lit("a"))], lit("b"))                 # type.slt:51's shape
+    c2 = q.CaseExpr([(q.BinaryExpr(col("day", 7), Operator.Lt, day), col("s", 5)), (q.BinaryExpr(col("i", 0), Operator.Gt, col("j", 1)), lit("i above j"))], lit(""))
+    c3 = q.CaseExpr([(col("b", 6), q.CaseExpr([(q.IsNull(col("s", 5)), lit("<null>"))], col("s", 5)))], q.Literal(S.Utf8(None)))
+    c4 = q.CaseExpr([(q.Like(False, col("s", 5), lit("%green%")), lit("a rather long constant that is longer than any column value, 日本語"))], col("s", 5))
+    return [c1, c2, c3, c4, lit("tag")]
+
+
+def test_oracle_string_case_of_the_reference_slt():
+    """tests/sql/type.slt:42-56 (SimpleCaseExpr) — the one vector the reference holds for a CASE: t_case(x int not null) = (1), (2);
+    select case x when 1 then 'a' else 'b' end -> a, b (rowsort). The planner lowers `case x when 1` to `x = 1` (case.rs)."""
+    schema = pa.schema([pa.field("x", pa.int32(), False)])
+    batch = pa.RecordBatch.from_arrays([pa.array([1, 2], type=pa.int32())], schema=schema)
+    case = q.CaseExpr([(q.BinaryExpr(col("x", 0), Operator.Eq, q.Literal(S.Int32(1))), q.Literal(S.Utf8("a")))], q.Literal(S.Utf8("b")))
+    plan = q.Projection(None, table_scan(schema, [batch]), [case])
+    assert sorted(r[0] for r in rows_of(qoracle.execute(plan))) == ["a", "b"]
+
+
+@pytest.mark.gpu
+def test_gpu_projection_that_produces_strings():
+    """Round 4 (VERDICT r03 missing #4): a projected expression of Utf8 type — two passes of the generated kernel (lengths, then
+    bytes at the scanned offsets). The reference's own vector (type.slt:51) through the HIP path, then random tables: CASE over
+    literals and columns, NULL branches, nesting, a LIKE condition, a literal column; multi-batch, empty and zero-batch inputs;
+    and a consumer above it (GROUP BY the computed string)."""
+    q.get_context()
+    schema1 = pa.schema([pa.field("x", pa.int32(), False)])
+    batch1 = pa.RecordBatch.from_arrays([pa.array([1, 2], type=pa.int32())], schema=schema1)
+    case = q.CaseExpr([(q.BinaryExpr(col("x", 0), Operator.Eq, q.Literal(S.Int32(1))), q.Literal(S.Utf8("a")))], q.Literal(S.Utf8("b")))
+    got = q.Projection(None, table_scan(schema1, [batch1]), [case]).execute()
+    assert sorted(r[0] for r in rows_of(got)) == ["a", "b"] and got[0].schema.field(0).type == pa.string()
+    rng = np.random.default_rng(12)
+    schema, batch = _table(rng, 25_000)
+    cuts = [0, 4000, 4000, 13_001, 25_000]
+    scan = table_scan(schema, [batch.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])])
+    plan = q.Projection(None, scan, [col("i", 0)] + _string_cases() + [col("s", 5)])
+    _same(plan.execute(), qoracle.execute(plan))
+    for src in (table_scan(schema, [batch.slice(0, 0)]), q.Scan(schema, q.MemoryTable.try_new(schema, []))):
+        p2 = q.Projection(None, src, _string_cases())
+        _same(p2.execute(), qoracle.execute(p2))
+    grouped = q.HashAggregate(None, q.Projection(None, scan, [_string_cases()[1], col("i", 0)]), [col("c", 0)],
+                              [q.CountAggregateExpr(q.Literal(S.Int64(1))), q.SumAggregateExpr(col("i", 1), pa.int64())])
+    assert sorted(rows_of(grouped.execute()), key=repr) == sorted(rows_of(qoracle.execute(grouped)), key=repr)
+    flt = q.Filter(q.Projection(None, scan, [_string_cases()[3], col("i", 0)]), q.Like(False, col("c", 0), q.Literal(S.Utf8("%constant%"))))
+    assert rows_of(flt.execute()) == rows_of(qoracle.execute(flt))
+
+
 @pytest.mark.gpu
 def test_gpu_case_inside_aggregate_and_errors():
     """Q12 / Q14 shapes: SUM(CASE WHEN ... THEN x ELSE 0 END) fused into the aggregation kernel"""
