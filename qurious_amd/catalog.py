@@ -139,6 +139,9 @@ def catalog_sources():
     case = E.CaseExpr([(like, E.Column("l_extendedprice", 4))], E.CastExpr(E.Literal(ScalarValue.Int64(0)), pa.decimal128(15, 2)))
     ratio = E.BinaryExpr(E.Column("l_extendedprice", 4), Operator.Div, E.Column("l_quantity", 3))
     out.append(("projection CASE/LIKE", planning.projection_source(LINEITEM_SCHEMA, [E.Column("l_shipdate", 0), case, ratio])))
+    # a CASE that PRODUCES strings (the reference's type.slt:51 shape): the two-pass policy (qk_project + qk_project_copy)
+    label = E.CaseExpr([(like, E.Literal(ScalarValue.Utf8("returned")))], E.Column("l_linestatus", 2))
+    out.append(("projection CASE -> Utf8 (two passes)", planning.projection_source(LINEITEM_SCHEMA, [label])))
     return out
 
 
