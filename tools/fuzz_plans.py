@@ -73,6 +73,20 @@ def random_predicate(rng, schema, p):
     return e
 
 
+def string_exprs(rng, c):
+    """round 4: expressions of Utf8 type (CASE over literals / columns / NULL, nested) and LIKE with a pattern column"""
+    lit = lambda v: q.Literal(S.Utf8(v))   # noqa: E731
+    pool = [
+        q.CaseExpr([(c("b"), c("s"))], lit("none")),
+        q.CaseExpr([(q.IsNull(c("flag")), lit(None))], c("flag")),
+        q.CaseExpr([(q.BinaryExpr(c("i"), Operator.Gt, q.Literal(S.Int32(0))), lit("positive")), (q.IsNull(c("i")), c("s"))],
+                   q.CaseExpr([(c("b"), lit(""))], c("flag"))),
+        q.Like(bool(rng.random() < 0.5), c("s"), c("flag")),
+        q.CaseExpr([(q.Like(False, c("s"), lit("%str1%")), lit("has a one, それ"))], c("s")),
+    ]
+    return [pool[int(k)] for k in rng.choice(len(pool), size=int(rng.integers(0, 4)), replace=False)]
+
+
 def scan_of(rng, schema, batches, p, lazy=False):
     table = q.MemoryTable(schema, batches, lazy_upload=lazy)
     return q.Scan(schema, table, None, random_predicate(rng, schema, p) if rng.random() < 0.6 else None)
@@ -111,7 +125,7 @@ def random_plan(rng):
         if rng.random() < 0.5:
             c = lambda name: col(ls, "l_" + name)   # noqa: E731
             plan = q.Projection(None, plan, [c("flag"), q.BinaryExpr(c("d"), Operator.Div, c("d")), q.Negative(c("i")), q.IsNull(c("s")),
-                                              q.CaseExpr([(c("b"), c("f"))], q.Literal(S.Float64(0.5)))])
+                                              q.CaseExpr([(c("b"), c("f"))], q.Literal(S.Float64(0.5)))] + string_exprs(rng, c))
     elif kind == 5:  # ORDER BY (several keys of every type, top-N) straight over a scan, then maybe a window
         names = [str(x) for x in rng.choice(["d", "f", "s", "flag", "day", "i", "k", "b"], size=int(rng.integers(1, 4)), replace=False)]
         keys = [q.PhysicalSortExpr(col(ls, "l_" + name), q.SortOptions(bool(rng.random() < 0.5), bool(rng.random() < 0.5))) for name in names]
@@ -141,7 +155,7 @@ def random_plan(rng):
         else:
             plan = q.HashJoinExec.try_new(left, right, jt, on, jf)
         js = plan.schema()
-        top = int(rng.integers(0, 4))
+        top = int(rng.integers(0, 5))
         if top == 0:
             plan, unordered = random_aggregate(rng, plan, js, "l_")
         elif top == 1:
@@ -149,6 +163,10 @@ def random_plan(rng):
             plan = q.Sort(keys, plan, int(rng.integers(0, 50)) if rng.random() < 0.5 else None)
         elif top == 2:
             plan = q.Limit(plan, int(rng.integers(0, 100)) if rng.random() < 0.7 else None, int(rng.integers(0, 50)))
+        elif top == 4 and jt in (JoinType.Inner, JoinType.Left, JoinType.Right, JoinType.Full):
+            # a projection over the join's (index-vector) output, strings computed from both sides
+            c = lambda name: col(js, "l_" + name)   # noqa: E731
+            plan = q.Projection(None, plan, [c("k"), col(js, "r_flag")] + string_exprs(rng, c))
     return plan, unordered
 
 
