@@ -77,6 +77,17 @@ def catalog_sources():
         out.append(("q3 aggregate, 1 row/thread, indirect columns", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
         os.environ["QHIP_PLAN_DEV_ROWS"] = "1"
         out.append(("q3 aggregate, 1 row/thread, indirect columns, device-side row count", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+        # ... the columns of one source table as fields of its record copy (ColRange::rec_buf): price | discount of lineitem in
+        # 8-byte records (both narrow), date | priority of orders in 16-byte ones
+        js = j2.schema()
+        os.environ["QHIP_PLAN_VALUE_BITS"] = f"{js.get_field_index('l_extendedprice')}:24,{js.get_field_index('l_discount')}:4"
+        os.environ["QHIP_PLAN_RECORDS"] = (f"{js.get_field_index('l_extendedprice')}:8,{js.get_field_index('l_discount')}:8,"
+                                           f"{js.get_field_index('o_orderdate')}:16,{js.get_field_index('o_shippriority')}:16")
+        try:
+            out.append(("q3 aggregate, indirect columns from record copies", planning.aggregate_source(j2.schema(), None, agg.group_exprs, agg.aggregate_exprs)))
+        finally:
+            os.environ.pop("QHIP_PLAN_VALUE_BITS", None)
+            os.environ.pop("QHIP_PLAN_RECORDS", None)
         os.environ.pop("QHIP_PLAN_INDIRECT", None)   # (join 2's build side gathers its key: measured faster than the indirect read)
         out.append(("q3 join-1 output build entries, device-side row count", planning.scatter_source(j1.schema(), [j2.on[0][0]])))
     finally:

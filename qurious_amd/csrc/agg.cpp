@@ -121,6 +121,15 @@ void fill_kargs(Ctx* ctx, const qhip_table* t, const KernelBindings& b, HKArgs& 
       if (!indirect_eligible(c0)) fail(QHIP_HIP_ERROR, "a column planned as an indirect read has been gathered meanwhile (internal error)");
       a.c[s].v = c0.deferred->src.values->ptr;
       a.c[s].d = (const uint8_t*)c0.deferred->idx->ptr;
+      if (s < b.rec.size() && b.rec[s]) {   // ... as a field of the source's record copy (ColRange::rec_buf)
+        const DevColumn& src = c0.deferred->src;
+        const ColRange& sh = *src.range;
+        const int w = s < b.narrow.size() && b.narrow[s] ? (int)b.narrow[s] : dtype_width(src.type);
+        if (!sh.rec_buf || sh.rec_stride != (int)b.rec[s] || sh.rec_width != w || sh.rec_src != src.values->ptr || sh.rec_rows != src.length)
+          fail(QHIP_HIP_ERROR, "an indirect column planned with a record copy has none of that layout (internal error)");
+        a.c[s].v = (const uint8_t*)sh.rec_buf->ptr + sh.rec_offset;
+        continue;
+      }
       if (s < b.narrow.size() && b.narrow[s]) {   // ... from the source's narrow copy (the object every copy of the column shares)
         const DevColumn& src = c0.deferred->src;
         const ColRange& sh = *src.range;
@@ -275,12 +284,14 @@ static qhip_table* hash_aggregate(Ctx* ctx, const qhip_table* in, const qhip_exp
   // |value| bounds of the Int64 / Decimal128 columns (cached per column; computed only on inputs big enough to pay for the
   // reduction): the generated code multiplies and accumulates in 32 / 64 bits where the bounds allow
   if (env_int("QHIP_AGG_NO_BOUNDS", 0) == 0) ensure_value_bounds(ctx, in, exprs, n_exprs, icols, (int64_t)env_int("QHIP_STATS_MIN_ROWS", 1 << 22));   // (the switch: tests / the fuzzer run the statistics paths on small tables)
+  // columns read through one index vector: one record per row and source table instead of one array per column
+  ensure_indirect_records(ctx, in, exprs, n_exprs, icols, (int64_t)env_int("QHIP_STATS_MIN_ROWS", 1 << 22));
   // lowered plans are cached per context: a repeated query (same expression PODs over the same column signature) skips
   // typing and code generation; literal VALUES are part of the key because they are bound into the plan's KernelBindings
   std::string key = "agg|";
   auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
   for (auto& ic : icols) {
-    const int v[8] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0, ic.narrow_bytes};
+    const int v[9] = {ic.type.id, ic.type.precision, ic.type.scale, ic.has_nulls ? 1 : 0, ic.utf8_max_len, ic.utf8_fixed1 ? 1 : 0, ic.indirect ? 1 : 0, ic.narrow_bytes, ic.rec_stride};
     put(&ic.value_maxabs, sizeof ic.value_maxabs);   // (a whole number of bits, see ensure_value_bounds)
     put(v, sizeof v);
   }

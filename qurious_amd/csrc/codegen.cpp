@@ -108,6 +108,7 @@ int ExprGen::col_slot(int table_col) {
   bind.cols.push_back(table_col);
   bind.indirect.push_back(table_col >= 0 && table_col < (int)in_.size() && in_[(size_t)table_col].indirect ? 1 : 0);
   bind.narrow.push_back(table_col >= 0 && table_col < (int)in_.size() ? (char)in_[(size_t)table_col].narrow_bytes : (char)0);
+  bind.rec.push_back(table_col >= 0 && table_col < (int)in_.size() ? (char)in_[(size_t)table_col].rec_stride : (char)0);
   return (int)bind.cols.size() - 1;
 }
 
@@ -204,7 +205,9 @@ void ExprGen::emit(int k, std::string& out) {
           // 64-bit shift-add per column and row (a tile is far smaller than 4 GB / 16)
           const std::string T = LT;
           const bool ind = in_[(size_t)n.column].indirect;   // late materialisation: source[index[row]] (random access, no streaming hint)
-          const std::string addr = ind ? "((const " + T + "*)a.c[" + S + "].v)[((const u32*)a.c[" + S + "].d)[" + row_ + "]]"
+          const int rec = ind ? in_[(size_t)n.column].rec_stride : 0;   // a field of the source's record copy (KCol::v = records + field offset)
+          const std::string addr = rec ? "(*(const " + T + "*)((const char*)a.c[" + S + "].v + (size_t)((const u32*)a.c[" + S + "].d)[" + row_ + "] * " + std::to_string(rec) + "u))"
+                                   : ind ? "((const " + T + "*)a.c[" + S + "].v)[((const u32*)a.c[" + S + "].d)[" + row_ + "]]"
                                    : base_.empty() ? "((const " + T + "*)a.c[" + S + "].v)[" + idx_ + "]"
                                                  : "(*(const " + T + "*)((const char*)((const " + T + "*)a.c[" + S + "].v" + base_ + ") + (size_t)((u32)(" + idx_ +
                                                        ") * (u32)sizeof(" + T + "))))";

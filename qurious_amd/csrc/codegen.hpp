@@ -15,6 +15,7 @@ struct KernelBindings {
   std::vector<int> cols;          // slot -> input column index
   std::vector<char> indirect;     // slot -> read through the deferred gather's index vector (InputCol::indirect)
   std::vector<char> narrow;       // slot -> 0, or the width in bytes of the narrow copy the kernel reads (InputCol::narrow_bytes)
+  std::vector<char> rec;          // slot -> 0, or the stride of the record copy an indirect column is read from (InputCol::rec_stride)
   std::vector<uint64_t> lit_lo;
   std::vector<int64_t> lit_hi;
   std::string strlits;            // concatenated Utf8 literals

@@ -105,6 +105,12 @@ struct ColRange {
   uint64_t maxabs = 0;
   int reads = 0;
   std::shared_ptr<DevBuf> narrow_buf; int narrow_bytes = 0; const void* narrow_src = nullptr; int64_t narrow_rows = 0;
+  // ... and the RECORD copy (relops.cpp ensure_indirect_records): this column's 4- / 8-byte values (narrow where it has a narrow
+  // copy) as field `rec_offset` of `rec_stride`-byte records shared with other columns of the same table, so that a kernel
+  // that reads several of them through ONE index vector touches one 64-byte line per row instead of one per column. Valid for
+  // exactly the buffer and length it was made from; once made it is kept (a column belongs to at most one record).
+  std::shared_ptr<DevBuf> rec_buf; int rec_stride = 0, rec_offset = 0, rec_width = 0; const void* rec_src = nullptr; int64_t rec_rows = 0;
+  int rec_reads = 0;
 };
 // One column of a device table, concatenated over all batches, Arrow layout.
 struct DevColumn {

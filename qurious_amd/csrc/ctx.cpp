@@ -436,6 +436,7 @@ int64_t qhip_table_aux_bytes(const qhip_table* t) {
     const DevColumn& col = c.pending_upload && c.pending_upload->done ? c.pending_upload->result : c;
     if (col.narrow && col.narrow->buf) b += (int64_t)col.narrow->buf->bytes;
     if (col.range && col.range->narrow_buf && !col.range_inherited) b += (int64_t)col.range->narrow_buf->bytes;   // (made for readers behind an index vector)
+    if (col.range && col.range->rec_buf && col.range->rec_offset == 0 && !col.range_inherited) b += (int64_t)col.range->rec_buf->bytes;   // (the record copy, counted with its first field)
   }
   return b;
 }

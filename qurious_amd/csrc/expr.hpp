@@ -37,6 +37,10 @@ struct InputCol {
   // a gathered copy: what an aggregate / a join build reads from a join output are a few short columns, each a gather launch
   // and a write + read of the copy otherwise (KCol::v = the source values, KCol::d = the u32 index vector)
   bool indirect = false;
+  // ... from a RECORD copy of its source (ColRange::rec_buf: the source's values interleaved with those of the other columns
+  // the same kernel reads through the same index vector — one random 64-byte access per row and table instead of one per
+  // column): the stride in bytes, 0 = the column's own array
+  int rec_stride = 0;
 };
 
 struct ExprSet {

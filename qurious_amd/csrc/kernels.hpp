@@ -30,6 +30,7 @@ void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* ou
 // out[i] = the low 4 / 8 bytes of the 16-byte value i (the narrow copy of a Decimal128 column whose values fit, DevColumn::narrow)
 // (src_words = 1: the source is an Int64 column, bytes = 4)
 void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words = 2);
+void launch_pack_field(const void* values, uint64_t n, int width, void* records, uint32_t stride, uint32_t offset, hipStream_t s);
 // out[0] / out[1] (zero-filled u64 words): order-preserving images of the max / the complement of the min of an integer column
 void launch_value_range(const void* values, uint64_t n, int width, bool is_signed, uint64_t* out, hipStream_t s);
 void launch_store_u32(uint32_t* p, uint32_t v, hipStream_t s);

@@ -1206,6 +1206,18 @@ void launch_value_maxabs(const void* values, uint64_t n, int words, uint64_t* ou
   if (words == 2) hipLaunchKernelGGL(k_value_maxabs<2>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out, (u32*)narrow32);
   else hipLaunchKernelGGL(k_value_maxabs<1>, g, b, 0, s, (const u64*)values, (u64)n, (u64*)out, (u32*)narrow32);
 }
+// field `offset` of `stride`-byte records <- a contiguous array of 4- / 8-byte values (ColRange::rec_buf)
+template <class T>
+__global__ __launch_bounds__(QH_BLOCK) void k_pack_field(const T* __restrict__ in, u8* __restrict__ out, u64 n, u32 stride, u32 offset) {
+  for (u64 i = (u64)blockIdx.x * QH_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * QH_BLOCK)
+    *(T*)(out + i * stride + offset) = __builtin_nontemporal_load(&in[i]);
+}
+void launch_pack_field(const void* values, uint64_t n, int width, void* records, uint32_t stride, uint32_t offset, hipStream_t s) {
+  if (!n) return;
+  const dim3 g(grid_for(n, QH_BLOCK * 4, 4096)), b(QH_BLOCK);
+  if (width == 4) hipLaunchKernelGGL(k_pack_field<u32>, g, b, 0, s, (const u32*)values, (u8*)records, (u64)n, (u32)stride, (u32)offset);
+  else hipLaunchKernelGGL(k_pack_field<u64>, g, b, 0, s, (const u64*)values, (u8*)records, (u64)n, (u32)stride, (u32)offset);
+}
 void launch_narrow_decimal(const void* values, uint64_t n, int bytes, void* out, hipStream_t s, int src_words) {
   if (!n) return;
   const dim3 g(grid_for(n, QH_BLOCK * 8, 2048)), b(QH_BLOCK);

@@ -50,6 +50,16 @@ static std::vector<InputCol> make_input(const qhip_dtype* t, const int32_t* has_
   // a join build over a join output sees at run time, InputCol::indirect)
   if (env_int("QHIP_PLAN_INDIRECT", 0))
     for (auto& c : v) if (dtype_width(c.type) > 0) { c.indirect = true; c.has_nulls = false; }
+  // QHIP_PLAN_RECORDS="5:8,6:8": these indirect columns are read as fields of `stride`-byte record copies of their source
+  // tables (relops.cpp ensure_indirect_records, InputCol::rec_stride)
+  if (const char* e = getenv("QHIP_PLAN_RECORDS")) {
+    int col = 0, stride = 0, used = 0;
+    while (*e && sscanf(e, "%d:%d%n", &col, &stride, &used) == 2) {
+      if (col >= 0 && col < n && v[(size_t)col].indirect && (stride == 8 || stride == 16)) v[(size_t)col].rec_stride = stride;
+      e += used;
+      if (*e == ',') ++e;
+    }
+  }
   return v;
 }
 static int give(const std::string& s, char* buf, size_t buflen, size_t* needed) {

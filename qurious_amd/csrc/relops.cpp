@@ -225,6 +225,66 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
   }
 }
 
+// An aggregate over a join output reads each of its arguments through the join's index vectors: source[index[row]] — one random
+// 64-byte access per row and COLUMN, and the memory system serves ~35-40 G of those per second whatever their size (DESIGN §9
+// item 0): Q3's aggregate reads four columns that way (price and discount of lineitem, date and priority of orders) and spends
+// its time there. Columns of ONE source table read through ONE index vector are therefore interleaved into records (4- / 8-byte
+// fields, a stride of 8 or 16 bytes: a record never straddles a 64-byte line), built once per table at the second such read
+// like the narrow copies and kept in the objects the table's columns share (ColRange): one access per row and TABLE.
+void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
+  if (env_int("QHIP_INDIRECT_RECORDS", 1) == 0) return;
+  struct Cand { int column; const DevColumn* src; const void* vals; int width; };
+  struct Group { const void* idx; int64_t rows; std::vector<Cand> cols; };
+  std::vector<Group> groups;
+  std::vector<char> seen(t->cols.size(), 0);
+  for (int k = 0; k < n_exprs; ++k) {
+    const qhip_expr& e = exprs[k];
+    if (e.kind != QHIP_EXPR_COLUMN || e.column < 0 || e.column >= (int)t->cols.size() || seen[(size_t)e.column]) continue;
+    seen[(size_t)e.column] = 1;
+    if (!icols[(size_t)e.column].indirect) continue;
+    const DeferredGather& d = *t->cols[(size_t)e.column].deferred;
+    const DevColumn& src = d.src;
+    if (src.range_inherited || src.length < min_rows || !src.values) continue;   // (base columns only: an intermediate result lives for one query)
+    ColRange& sh = *src.range;
+    int w = dtype_width(src.type);
+    const void* vals = src.values->ptr;
+    if (const int nb = icols[(size_t)e.column].narrow_bytes) {   // the field holds what the kernel would read from the narrow copy
+      w = nb;
+      if (sh.narrow_buf && sh.narrow_bytes == nb && sh.narrow_src == src.values->ptr && sh.narrow_rows == src.length) vals = sh.narrow_buf->ptr;
+      else if (src.narrow && src.narrow->buf && src.narrow->bytes == nb && src.narrow->src == src.values->ptr && src.narrow->rows == src.length) vals = src.narrow->buf->ptr;
+      else continue;
+    }
+    if (w != 4 && w != 8) continue;
+    if (sh.rec_buf && sh.rec_src == src.values->ptr && sh.rec_rows == src.length) {
+      if (sh.rec_width == w) icols[(size_t)e.column].rec_stride = sh.rec_stride;   // (a record made earlier, maybe with other partners)
+      continue;
+    }
+    Group* g = nullptr;
+    for (Group& x : groups) if (x.idx == (const void*)d.idx.get() && x.rows == src.length) g = &x;
+    if (!g) { groups.push_back(Group{(const void*)d.idx.get(), src.length, {}}); g = &groups.back(); }
+    g->cols.push_back(Cand{e.column, &src, vals, w});
+  }
+  for (Group& g : groups) {
+    if (g.cols.size() < 2) continue;
+    if (++g.cols[0].src->range->rec_reads < 2 && env_int("QHIP_NARROW_FIRST_USE", 0) == 0) continue;   // (the second read earns the copy)
+    std::stable_sort(g.cols.begin(), g.cols.end(), [](const Cand& a, const Cand& b) { return a.width > b.width; });
+    std::vector<std::pair<const Cand*, int>> fields;
+    int end = 0;
+    for (const Cand& c : g.cols) if (end + c.width <= 16) { fields.emplace_back(&c, end); end += c.width; }
+    if (fields.size() < 2) continue;
+    const int stride = end <= 8 ? 8 : 16;
+    std::shared_ptr<DevBuf> buf;
+    try { buf = std::make_shared<DevBuf>((size_t)g.rows * (size_t)stride); } catch (const Error&) { continue; }   // (no room: the columns' own arrays serve)
+    for (auto& f : fields) {
+      const DevColumn& src = *f.first->src;
+      launch_pack_field(f.first->vals, (uint64_t)g.rows, f.first->width, buf->ptr, (uint32_t)stride, (uint32_t)f.second, ctx->stream);
+      ColRange& sh = *src.range;
+      sh.rec_buf = buf; sh.rec_stride = stride; sh.rec_offset = f.second; sh.rec_width = f.first->width; sh.rec_src = src.values->ptr; sh.rec_rows = src.length;
+      icols[(size_t)f.first->column].rec_stride = stride;
+    }
+  }
+}
+
 // Int64 columns read by a big probe side (join keys: TPC-H's order and customer keys) whose values fit 32 bits get a 4-byte
 // narrow copy too (DevColumn::narrow), decided from the column's value RANGE (DevColumn::range: computed once per table column,
 // key_range_of) — Q3's lineitem probe then streams 8 instead of 12 bytes per row.

@@ -47,6 +47,8 @@ void ensure_utf8_key_lengths(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
 // (one reduction + one read-back per column, cached on the column) only for inputs of `min_rows` rows or more
 void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 // 4-byte narrow copies of the Int64 columns (join keys) a big probe side's expressions reference, where the value range allows
+// (round 4) columns an aggregate reads through ONE index vector get a shared record copy of their source columns (ColRange::rec_buf)
+void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 void ensure_narrow_int_columns(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows);
 // [mn, mx] of an integer-like column's values (cached on the column and shared with its source table, DevColumn::range);
 // false when the column has no values to look at / is not integer-like

@@ -323,3 +323,55 @@ def test_narrow_copy_for_columns_only_ever_read_through_an_index_vector(ctx, ora
         assert sorted(map(repr, rows_of(plan.execute()))) == want
         read.append(ctx.last_stats()["bytes_per_row_read"])
     assert read[-1] < read[0] - 20, read          # price and disc: 16 -> 4 bytes each; wide stays 16
+
+
+@pytest.mark.gpu
+def test_record_copies_for_columns_read_through_one_index_vector(ctx, oracle, monkeypatch):
+    """Round 4: an aggregate over a join output reads each column as source[index[row]] — one random 64-byte access per row and
+    COLUMN. Columns of one source table behind one index vector (Q3: price | discount of lineitem, date | priority of orders) are
+    interleaved into 8- / 16-byte records at the second such read (ColRange::rec_buf, relops.cpp ensure_indirect_records) and
+    the generated kernel reads fields of those. Results must not change from execution to execution; the copies show up in the
+    tables' auxiliary bytes; a column of 16 bytes stays out; the switch turns it off."""
+    import decimal
+    monkeypatch.setenv("QHIP_STATS_MIN_ROWS", "1")
+    rng = np.random.default_rng(21)
+    nb, npr = 4000, 150_000
+    D = pa.decimal128(15, 2)
+    dec = lambda v: pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in v], type=D)   # noqa: E731
+    ls = pa.schema([pa.field("bk", I64, False), pa.field("g1", pa.int32(), False), pa.field("g2", pa.date32(), False), pa.field("g3", I64, False)])
+    lb = pa.RecordBatch.from_arrays([pa.array(np.arange(nb) * 2, I64), pa.array(rng.integers(0, 30, nb), pa.int32()),
+                                     pa.array(rng.integers(9000, 9004, nb), pa.int32()).cast(pa.date32()), pa.array(rng.integers(-10**12, 10**12, nb), I64)], schema=ls)
+    big = rng.integers(-10**6, 10**6, npr).astype(object)
+    big[3] = 1 << 40
+    rs = pa.schema([pa.field("pk", I64, False), pa.field("price", D, False), pa.field("disc", D, False), pa.field("qty", pa.int32(), False), pa.field("wide", D, False)])
+    rb = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 2 * nb, npr), I64), dec(rng.integers(100, 10**7, npr)), dec(rng.integers(0, 11, npr)),
+                                     pa.array(rng.integers(1, 51, npr), pa.int32()), dec(big)], schema=rs)
+    lscan, rscan = table_scan(ls, [lb]), table_scan(rs, [rb.slice(0, 50_000), rb.slice(50_000)])
+    join = q.HashJoinExec.try_new(lscan, rscan, JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
+    one = q.CastExpr(q.Literal(S.Int64(1)), pa.decimal128(20, 0))
+    rev = q.BinaryExpr(col("price", 5), Operator.Mul, q.BinaryExpr(one, Operator.Sub, col("disc", 6)))
+    plan = q.HashAggregate(None, join, [col("g1", 1), col("g2", 2)],
+                           [q.SumAggregateExpr(rev, pa.decimal128(38, 4)), q.SumAggregateExpr(col("g3", 3), I64), q.MinAggregateExpr(col("qty", 7), pa.int32()),
+                            q.SumAggregateExpr(col("wide", 8), D), q.CountAggregateExpr(q.Literal(S.Int64(1)))])
+    want = sorted(map(repr, rows_of(oracle.execute(plan))))
+    aux = []
+    for _ in range(6):
+        assert sorted(map(repr, rows_of(plan.execute()))) == want
+        aux.append((lscan.datasource.device_table().aux_bytes, rscan.datasource.device_table().aux_bytes))
+    # build side: g1 | g2 | g3 = 4 + 4 + 8 bytes -> 16-byte records; probe side: price | disc (narrow, 4 + 4) | qty (4) -> 16-byte
+    # records beside the two narrow copies (`wide` has no narrow copy and stays a 16-byte gather)
+    assert aux[-1][0] >= nb * 16 and aux[0][0] == 0, aux
+    assert aux[-1][1] >= npr * (16 + 4 + 4) and aux[-1][1] > aux[1][1], aux
+    # a second plan over the same tables that reads ONE of those columns per side uses the records that exist
+    plan2 = q.HashAggregate(None, join, [col("g1", 1)], [q.MaxAggregateExpr(col("qty", 7), pa.int32())])
+    for _ in range(2):
+        assert sorted(map(repr, rows_of(plan2.execute()))) == sorted(map(repr, rows_of(oracle.execute(plan2))))
+    assert (lscan.datasource.device_table().aux_bytes, rscan.datasource.device_table().aux_bytes) == aux[-1]
+    # ... and with the switch off nothing is made
+    monkeypatch.setenv("QHIP_INDIRECT_RECORDS", "0")
+    l2, r2 = table_scan(ls, [lb]), table_scan(rs, [rb])
+    j2 = q.HashJoinExec.try_new(l2, r2, JoinType.Inner, [(col("bk", 0), col("pk", 0))], None)
+    p3 = q.HashAggregate(None, j2, plan.group_exprs, plan.aggregate_exprs)
+    for _ in range(4):
+        assert sorted(map(repr, rows_of(p3.execute()))) == want
+    assert l2.datasource.device_table().aux_bytes == 0
