@@ -232,7 +232,9 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
 // fields, a stride of 8 or 16 bytes: a record never straddles a 64-byte line), built once per table at the second such read
 // like the narrow copies and kept in the objects the table's columns share (ColRange): one access per row and TABLE.
 void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
-  if (env_int("QHIP_INDIRECT_RECORDS", 1) == 0) return;
+  // (off by default: the execution that builds the records re-lowers the plan — its key holds the stride — so a repeated query
+  // reaches its steady state one execution later, and the measured gain is a tenth of the aggregate kernel)
+  if (env_int("QHIP_INDIRECT_RECORDS", 0) == 0) return;
   struct Cand { int column; const DevColumn* src; const void* vals; int width; };
   struct Group { const void* idx; int64_t rows; std::vector<Cand> cols; };
   std::vector<Group> groups;

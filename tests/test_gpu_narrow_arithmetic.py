@@ -334,6 +334,7 @@ def test_record_copies_for_columns_read_through_one_index_vector(ctx, oracle, mo
     tables' auxiliary bytes; a column of 16 bytes stays out; the switch turns it off."""
     import decimal
     monkeypatch.setenv("QHIP_STATS_MIN_ROWS", "1")
+    monkeypatch.setenv("QHIP_INDIRECT_RECORDS", "1")
     rng = np.random.default_rng(21)
     nb, npr = 4000, 150_000
     D = pa.decimal128(15, 2)
