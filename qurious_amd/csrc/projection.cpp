@@ -89,16 +89,14 @@ qhip_table* project_table(Ctx* ctx, const qhip_table* in, const qhip_expr* exprs
       }
     }
     if (N > 0 && plan.has_utf8) {
-      // int32 offsets (Arrow Utf8): the lengths are summed in 32 bits on the device, so the output is bounded on the host first
-      // — rows x the longest value any branch can produce — and only a bound below 2^32 runs; the exact total is checked below
-      uint64_t longest = plan.bind.strlits.size();
-      for (int ci : plan.bind.cols) {
-        if (icols[(size_t)ci].type.id != QHIP_UTF8) continue;
-        const int known = icols[(size_t)ci].utf8_max_len;
-        longest = std::max<uint64_t>(longest, known >= 0 ? (uint64_t)known : (uint64_t)std::max<int64_t>(resolved(ctx, in->cols[(size_t)ci]).data_bytes, 0));
-      }
-      if ((unsigned __int128)longest * (uint64_t)N >= ((unsigned __int128)1 << 32))
-        fail(QHIP_UNSUPPORTED, "computed Utf8 column that may exceed 2 GiB (needs LargeUtf8 offsets)");
+      // int32 offsets (Arrow Utf8): the lengths are summed in 32 bits on the device, so the output is bounded on the host first.
+      // A row's value is a literal or the value of a Utf8 column AT THAT ROW, so all rows together hold at most rows x (the
+      // literals' bytes) + the data bytes of every referenced Utf8 column; only a bound below 2^32 runs, and the exact total is
+      // checked below.
+      unsigned __int128 bound = (unsigned __int128)plan.bind.strlits.size() * (uint64_t)N;
+      for (int ci : plan.bind.cols)
+        if (icols[(size_t)ci].type.id == QHIP_UTF8) bound += (uint64_t)std::max<int64_t>(resolved(ctx, in->cols[(size_t)ci]).data_bytes, 0);
+      if (bound >= ((unsigned __int128)1 << 32)) fail(QHIP_UNSUPPORTED, "computed Utf8 column that may exceed 2 GiB (needs LargeUtf8 offsets)");
     }
     if (N > 0) {
       std::shared_ptr<Module> mod = get_module(ctx, plan.source, plan.kernel_name);

@@ -204,6 +204,7 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     q.get_context()
     bad = 0
+    skipped = {}
     for seed in range(first, first + n):
         rng = np.random.default_rng(seed)
         try:
@@ -233,7 +234,8 @@ def main():
             gerr = f"{type(e).__name__}: {e}"
         if (gerr is None) != (werr is None):
             if gerr and ("not accelerated" in gerr or "not supported" in gerr or "Unsupported" in gerr):
-                continue   # a documented QHIP_UNSUPPORTED (the shim would fall back to the CPU node)
+                skipped[gerr[:90]] = skipped.get(gerr[:90], 0) + 1
+                continue   # a documented QHIP_UNSUPPORTED (the shim would fall back to the CPU node); counted and listed below
             print(f"seed {seed}: error mismatch: hip={gerr} oracle={werr} plan={type(plan).__name__}", flush=True)
             bad += 1
         elif gerr is None:
@@ -247,6 +249,8 @@ def main():
                 bad += 1
         if seed % 25 == 0:
             print(f"... seed {seed} done, {bad} problems so far", flush=True)
+    for reason, count in sorted(skipped.items()):
+        print(f"   {count} plans not accelerated: {reason}")
     print(f"{n} plans, {bad} problems")
     return 1 if bad else 0
 
