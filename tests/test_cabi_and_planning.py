@@ -195,6 +195,15 @@ def test_catalog_holds_the_kernel_variants_a_repeated_q3_launches():
     # the probe side's Int64 key as its 4-byte narrow copy, four rows per lane (16-byte loads)
     dpn = srcs["q3 lineitem dense probe, narrow key"]
     assert dpn != dp and "static constexpr int PROBE_R = 4;" in dpn and "static constexpr int PROBE_R = 2;" in dp
+    # round 4: indirect columns as fields of their source table's record copy (ColRange::rec_buf): a strided load per field — 8-byte
+    # records for lineitem's two narrow decimals, 16-byte ones for orders' date and priority — and none of it without the switch
+    rec = srcs["q3 aggregate, indirect columns from record copies"]
+    assert rec.count("].d)[(tb + (i64)o)] * 8u))") == 2 and rec.count("].d)[(tb + (i64)o)] * 16u))") == 2
+    assert "* 8u))" not in agg_ind and "* 16u))" not in agg_ind
+    # ... and the projection that PRODUCES strings: one policy, two entry points (lengths, then bytes)
+    sp = srcs["projection CASE -> Utf8 (two passes)"]
+    assert "qh_project_body<P, 0>" in sp and "qh_project_body<P, 1>" in sp and "qk_project_copy(" in sp
+    assert "qk_project_copy(" not in srcs["projection CASE/LIKE"]
 
 
 def test_retry_protocol_of_the_host_mirror():
