@@ -518,7 +518,9 @@ int qhip_cross_join_execute(qhip_ctx* ctx, const qhip_table* left, const qhip_ta
 /* ---------------------------------------------------------------- projection */
 /* Projection::execute (physical/plan/projection.rs:27-46): one output column per expression, evaluated over every
  * input batch (batch structure kept). A plain Column expression shares the input column's buffers; everything else is
- * computed by ONE generated kernel for all expressions together. */
+ * computed by ONE generated kernel for all expressions together — run twice when an expression is of Utf8 type (a CASE over
+ * strings, tests/sql/type.slt:51): lengths, a scan into int32 offsets, then the bytes. A computed Utf8 column that could exceed
+ * 2 GiB returns QHIP_UNSUPPORTED (LargeUtf8 does not cross this ABI). */
 int qhip_projection_execute(qhip_ctx* ctx, const qhip_table* in, const qhip_expr* exprs, int32_t n_exprs,
                             const int32_t* roots, int32_t n_out, const char* const* out_names, qhip_table** out);
 
