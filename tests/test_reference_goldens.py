@@ -314,3 +314,77 @@ def test_q1_avg_is_truncating_division(engine, golden):
         out = engine.execute(plan)[0]
         assert out.column(1).type == pa.decimal128(19, 6)
         assert out.column(1)[0].as_py() == avg_qty, row[:2]
+
+
+# ---------------------------------------------------------------- filter.slt / select.slt / basic_test.slt / type.slt (round 4)
+_OPS = {"gt": Operator.Gt, "lt": Operator.Lt, "ge": Operator.GtEq, "le": Operator.LtEq, "eq": Operator.Eq, "and": Operator.And, "or": Operator.Or}
+
+
+def _tree(node, names):
+    """[operator, left, right] -> BinaryExpr in the SQL text's operand order (`3 > v1` keeps the literal on the left)"""
+    if isinstance(node, str):
+        return col(node, names.index(node))
+    if isinstance(node, int):
+        return lit_i64(node)
+    return q.BinaryExpr(_tree(node[1], names), _OPS[node[0]], _tree(node[2], names))
+
+
+def test_slt_filter(engine, golden):
+    """tests/sql/filter.slt: nested AND / OR over comparisons with the literal on either side; the second table arrives in two
+    inserts = two batches (Filter keeps one output batch per input batch, filter.rs:34)"""
+    g = golden["slt"]["filter"]
+    names = ["v1", "v2"]
+    schema = pa.schema([pa.field(n, I64, False) for n in names])
+    one_batch = lambda rows: pa.RecordBatch.from_arrays([pa.array([r[k] for r in rows], I64) for k in range(2)], schema=schema)   # noqa: E731
+    for rows_key, queries, batches in (("t1", g["t1_queries"], [g["t1"]]), ("t2", g["t2_queries"], g["t2_batches"])):
+        for case in queries:
+            scan = table_scan(schema, [one_batch(b) for b in batches])
+            k = names.index(case["select"])
+            out = engine.execute(_filter(scan, _tree(case["where"], names)))
+            assert len(out) == len(batches), case
+            got = [r[k] for r in rows_of(out)]
+            assert (sorted(got) if case["rowsort"] else got) == case["expect"], case
+
+
+def test_slt_select_and_basic(engine, golden):
+    """tests/sql/select.slt (projection arithmetic, aggregates with and without GROUP BY, a comparison of two aggregates projected
+    over the aggregate) and basic_test.slt's MultiRowsMultiColumn"""
+    g = golden["slt"]["select"]
+    t = lambda: _t(["v1", "v2", "v3"], g["rows"])   # noqa: E731
+    v1, v2, v3 = col("v1", 0), col("v2", 1), col("v3", 2)
+    out = rows_of(engine.execute(q.Projection(None, t(), [q.BinaryExpr(v1, Operator.Add, v2)])))
+    assert [r[0] for r in out] == g["v1_plus_v2"]
+    assert rows_of(engine.execute(_agg(t(), [], [_sum(v1), _sum(v2)]))) == [tuple(g["sum_v1__sum_v2"])]
+    # `group by v2, v2`: the planner keeps one key per distinct expression
+    agg = q.HashAggregate(None, t(), [v2], [_sum(v1), q.CountAggregateExpr(v3), q.MinAggregateExpr(v3, I64), q.MaxAggregateExpr(v1, I64)])
+    assert sorted(r[1:] for r in rows_of(engine.execute(agg))) == sorted(tuple(r) for r in g["group_by_v2__sum_v1__count_v3__min_v3__max_v1"])
+    agg = q.HashAggregate(None, t(), [v2], [q.CountAggregateExpr(v3), q.MinAggregateExpr(v3, I64)])
+    cmp = q.Projection(None, agg, [q.BinaryExpr(col("c1", 1), Operator.Eq, col("c2", 2))])
+    assert sorted(r[0] for r in rows_of(engine.execute(cmp))) == g["group_by_v2__count_v3_eq_min_v3"]
+    agg = q.HashAggregate(None, t(), [v2], [q.CountAggregateExpr(v3)])
+    assert sorted((r[1], r[0]) for r in rows_of(engine.execute(agg))) == sorted(tuple(r) for r in g["group_by_v2__count_v3__v2"])
+    assert sorted(r[0] for r in rows_of(engine.execute(q.HashAggregate(None, t(), [v2], [])))) == g["group_by_v2__v2"]
+    out = rows_of(engine.execute(q.Projection(None, _filter(t(), q.BinaryExpr(v2, Operator.Gt, lit_i64(3))), [v1, v3])))
+    assert sorted(out) == sorted(tuple(r) for r in g["v1_v3_where_v2_gt_3"])
+
+
+def test_slt_type(engine, golden):
+    """tests/sql/type.slt: Int16 arithmetic, a Date32 comparison against a literal date, ORDER BY a Boolean column, SimpleCaseExpr"""
+    import datetime
+    g = golden["slt"]["type"]
+    a = col("a", 0)
+    t = table_scan(pa.schema([pa.field("a", pa.int16(), False)]), [pa.RecordBatch.from_arrays([pa.array(g["smallint_a"], pa.int16())], names=["a"])])
+    out = engine.execute(q.Projection(None, t, [q.BinaryExpr(a, op, a) for op in (Operator.Add, Operator.Sub, Operator.Mul, Operator.Div)]))
+    assert rows_of(out) == [tuple(g["smallint_a_plus_minus_times_div_a"])] and all(f.type == pa.int16() for f in out[0].schema)
+    days = [datetime.date.fromisoformat(s) for s in g["date_rows"]]
+    t = table_scan(pa.schema([pa.field("v1", pa.date32(), False)]), [pa.RecordBatch.from_arrays([pa.array(days, pa.date32())], names=["v1"])])
+    bound = q.CastExpr(q.Literal(S.Utf8(g["date_lt"])), pa.date32())
+    out = rows_of(engine.execute(_filter(t, q.BinaryExpr(col("v1", 0), Operator.Lt, bound))))
+    assert [r[0] for r in out] == [datetime.date.fromisoformat(s) for s in g["date_kept"]]
+    # each INSERT is a batch of its own
+    t = table_scan(pa.schema([pa.field("a", pa.bool_(), True)]), [pa.RecordBatch.from_arrays([pa.array([v], pa.bool_())], names=["a"]) for v in g["bool_rows"]])
+    out = rows_of(engine.execute(q.Sort([q.PhysicalSortExpr(col("a", 0), q.SortOptions(False, True))], t)))
+    assert [r[0] for r in out] == g["bool_order_by_asc"]
+    t = table_scan(pa.schema([pa.field("x", I64, False)]), [pa.RecordBatch.from_arrays([pa.array(g["case_x"], I64)], names=["x"])])
+    case = q.CaseExpr([(q.BinaryExpr(col("x", 0), Operator.Eq, lit_i64(1)), q.Literal(S.Utf8("a")))], q.Literal(S.Utf8("b")))
+    assert sorted(r[0] for r in rows_of(engine.execute(q.Projection(None, t, [case])))) == g["case_x_when_1_then_a_else_b"]
