@@ -234,7 +234,12 @@ void ensure_value_bounds(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, 
 void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exprs, int n_exprs, std::vector<InputCol>& icols, int64_t min_rows) {
   // (off by default: the execution that builds the records re-lowers the plan — its key holds the stride — so a repeated query
   // reaches its steady state one execution later, and the measured gain is a tenth of the aggregate kernel)
-  if (env_int("QHIP_INDIRECT_RECORDS", 0) == 0) return;
+  const int mode = env_int("QHIP_INDIRECT_RECORDS", 0);
+  if (mode == 0) return;
+  // mode 2 (not validated on the device yet — DESIGN §9's short list): EVERY sighting of an indirect base column counts, also
+  // while it is still 16 bytes wide, so that a group whose members get their narrow copies in the second execution gets its
+  // record in that same execution and the plan is lowered once more, not twice
+  const bool count_sightings = mode >= 2;
   struct Cand { int column; const DevColumn* src; const void* vals; int width; };
   struct Group { const void* idx; int64_t rows; std::vector<Cand> cols; };
   std::vector<Group> groups;
@@ -248,6 +253,7 @@ void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
     const DevColumn& src = d.src;
     if (src.range_inherited || src.length < min_rows || !src.values) continue;   // (base columns only: an intermediate result lives for one query)
     ColRange& sh = *src.range;
+    if (count_sightings) ++sh.rec_reads;
     int w = dtype_width(src.type);
     const void* vals = src.values->ptr;
     if (const int nb = icols[(size_t)e.column].narrow_bytes) {   // the field holds what the kernel would read from the narrow copy
@@ -268,7 +274,10 @@ void ensure_indirect_records(Ctx* ctx, const qhip_table* t, const qhip_expr* exp
   }
   for (Group& g : groups) {
     if (g.cols.size() < 2) continue;
-    if (++g.cols[0].src->range->rec_reads < 2 && env_int("QHIP_NARROW_FIRST_USE", 0) == 0) continue;   // (the second read earns the copy)
+    int reads = 0;
+    if (count_sightings) { for (const Cand& c : g.cols) reads = std::max(reads, c.src->range->rec_reads); }
+    else reads = ++g.cols[0].src->range->rec_reads;
+    if (reads < 2 && env_int("QHIP_NARROW_FIRST_USE", 0) == 0) continue;   // (the second read earns the copy)
     std::stable_sort(g.cols.begin(), g.cols.end(), [](const Cand& a, const Cand& b) { return a.width > b.width; });
     std::vector<std::pair<const Cand*, int>> fields;
     int end = 0;
